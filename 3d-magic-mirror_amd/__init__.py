@@ -1,0 +1,4 @@
+"""MI355X-native differentiable render + reconstruction-loss path for 3D-Magic-Mirror (gfx950 HIP kernels behind a
+C-ABI; host side mirrors the reference's DiffRender API).  Import as ``importlib.import_module('3d-magic-mirror_amd')``
+or through the root-level ``mm_amd`` alias."""
+from . import obj_io, template, synthetic  # noqa: F401

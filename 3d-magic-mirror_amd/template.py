@@ -1,0 +1,111 @@
+"""Template-mesh preparation: everything DiffRender.__init__ derives from the OBJ once, on the host.
+
+Restates /root/reference/networks.py:165-256 plus the kaolin helpers it calls
+(``index_vertices_by_faces``, ``uniform_laplacian``, ``generate_perspective_projection``), and adds the static
+vertex->corner adjacency (CSR) that the HIP vertex-stage backward gathers through instead of scattering atomics.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def generate_perspective_projection(fovyangle, ratio=1.0, dtype=torch.float):
+    """kaolin.render.camera.generate_perspective_projection: (3,1) = [1/(ratio*tan), 1/tan, -1]."""
+    t = math.tan(fovyangle / 2.0)
+    return torch.tensor([[1.0 / (ratio * t)], [1.0 / t], [-1.0]], dtype=dtype)
+
+
+def index_vertices_by_faces(vertices_features, faces):
+    """kaolin.ops.mesh.index_vertices_by_faces: (B,V,C),(F,3) -> (B,F,3,C)."""
+    return vertices_features[:, faces.reshape(-1)].reshape(vertices_features.shape[0], faces.shape[0], faces.shape[1], -1)
+
+
+def normalize_template(vertices, init_ellipsoid=1):
+    """networks.py:183-194: per-axis min/max to [-1,1]; z/2 (and x,z / e) unless init_ellipsoid == -1; scale 0.9."""
+    v = vertices.clone().float()
+    vmax = v.max(0, True)[0]
+    vmin = v.min(0, True)[0]
+    v = (v - vmin) / (vmax - vmin)
+    v = v * 2.0 - 1.0
+    if not init_ellipsoid == -1:
+        v[:, 2] = v[:, 2] / 2
+        if init_ellipsoid != 1:
+            v[:, 0] = v[:, 0] / init_ellipsoid
+            v[:, 2] = v[:, 2] / init_ellipsoid
+    v *= 0.9
+    return v
+
+
+def flip_pairing(vertices_init):
+    """networks.py:215-217: index of the nearest vertex to the z-mirrored position."""
+    mirrored = vertices_init.clone()
+    mirrored[:, 2] *= -1
+    return torch.cdist(vertices_init, mirrored).min(1)[1]
+
+
+def edge_tables(faces):
+    """networks.py:220-246: unique sorted undirected edges (E,2) and the (E,2) table of the faces sharing each edge.
+
+    Faces within a row are listed in ascending face id (the reference's order depends on an unstable sort; only the
+    pair matters to calc_reg_loss, which is symmetric in it).  A boundary edge keeps 0 in its second slot like the
+    reference's zero-initialised table; an edge shared by more than two faces raises (the reference would index out
+    of bounds there).
+    """
+    f = faces.cpu().numpy().astype(np.int64)
+    F = f.shape[0]
+    raw = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0)
+    raw.sort(axis=1)
+    face_ids = np.tile(np.arange(F, dtype=np.int64), 3)
+    edges, inverse = np.unique(raw, axis=0, return_inverse=True)
+    inverse = inverse.reshape(-1)
+    order = np.lexsort((face_ids, inverse))
+    e_sorted, f_sorted = inverse[order], face_ids[order]
+    first = np.flatnonzero(np.r_[True, e_sorted[1:] != e_sorted[:-1]])
+    sub = np.arange(e_sorted.shape[0]) - np.repeat(first, np.diff(np.r_[first, e_sorted.shape[0]]))
+    if sub.max() > 1:
+        raise ValueError("non-manifold template: an edge is shared by more than two faces")
+    edge2faces = np.zeros((edges.shape[0], 2), dtype=np.int64)
+    edge2faces[e_sorted, sub] = f_sorted
+    return torch.from_numpy(edges), torch.from_numpy(edge2faces)
+
+
+def uniform_laplacian(num_vertices, faces):
+    """kaolin.ops.mesh.uniform_laplacian: dense (V,V), L = A/deg with -1 on the diagonal, NaN rows -> 0."""
+    f = faces.cpu().numpy().astype(np.int64)
+    A = np.zeros((num_vertices, num_vertices), dtype=np.float32)
+    for a, b in ((0, 1), (1, 2), (2, 0)):
+        A[f[:, a], f[:, b]] = 1.0
+        A[f[:, b], f[:, a]] = 1.0
+    deg = A.sum(1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        L = A / deg
+    np.fill_diagonal(L, -1.0)
+    L[np.isnan(L)] = 0.0
+    return torch.from_numpy(L)
+
+
+def sparse_laplacian_rows(num_vertices, faces):
+    """CSR form of :func:`uniform_laplacian` without the diagonal: (offsets (V+1) int32, neighbours int32); the weight
+    of every neighbour of vertex i is 1/deg(i)."""
+    f = faces.cpu().numpy().astype(np.int64)
+    nb = [set() for _ in range(num_vertices)]
+    for a, b, c in f:
+        nb[a].update((b, c)); nb[b].update((a, c)); nb[c].update((a, b))
+    offsets = np.zeros(num_vertices + 1, dtype=np.int32)
+    items = []
+    for i, s in enumerate(nb):
+        items.extend(sorted(s))
+        offsets[i + 1] = len(items)
+    return torch.from_numpy(offsets), torch.from_numpy(np.asarray(items, dtype=np.int32))
+
+
+def vertex_corner_adjacency(num_vertices, faces):
+    """Static CSR vertex -> incident (face*3+corner) list, ascending; the vertex-stage backward of the HIP path
+    gathers per-corner gradients through it (deterministic, no atomics)."""
+    f = faces.cpu().numpy().astype(np.int64).reshape(-1)
+    order = np.argsort(f, kind="stable").astype(np.int32)
+    counts = np.bincount(f, minlength=num_vertices)
+    offsets = np.zeros(num_vertices + 1, dtype=np.int32)
+    offsets[1:] = np.cumsum(counts)
+    return torch.from_numpy(offsets), torch.from_numpy(order)

@@ -1,0 +1,92 @@
+"""Pins the CPU oracle and the host-side template logic against fixtures minted from the importable parts of the
+reference (tests/golden/make_golden.py): smr_utils camera math, DiffRender.__init__, DiffRender.recon_data."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, TEMPLATES, load_template_npz
+
+
+def test_camera_matches_smr_utils(oracle):
+    z = np.load(os.path.join(GOLDEN, "camera.npz"))
+    T = oracle.camera(z["dist"], z["elev"], z["azim"], z["bias"])
+    np.testing.assert_allclose(T, z["transform"], rtol=0, atol=2e-6)
+    # camera position is recoverable: t = -cam @ R  =>  cam = -t @ R^T
+    cam = -np.einsum("bj,bij->bi", T[:, 3], T[:, :3])
+    np.testing.assert_allclose(cam, z["camera_position"], atol=5e-6)
+    T64 = oracle.camera(z["dist"], z["elev"], z["azim"], z["bias"], dtype=np.float64)
+    np.testing.assert_allclose(T64, z["transform"], atol=2e-6)
+
+
+@pytest.mark.parametrize("name,ell,ratio", [("sphere", 1, 1), ("smpl_uv_642", 1, 1), ("ellipsoid", 1, 1),
+                                            ("smpl_uv_642", 2, 2), ("sphere", -1, 1)])
+def test_template_prep_matches_reference_init(pkg, name, ell, ratio):
+    t = pkg.template
+    z = np.load(os.path.join(GOLDEN, "template_%s_e%d_r%d.npz" % (name, ell, ratio)))
+    m = load_template_npz(name)
+    v = t.normalize_template(torch.from_numpy(m["vertices"]), ell)
+    np.testing.assert_array_equal(v.numpy(), z["vertices_init"])
+    np.testing.assert_array_equal(t.flip_pairing(v).numpy(), z["flip_index"])
+    faces = torch.from_numpy(m["faces"]).long()
+    edges, e2f = t.edge_tables(faces)
+    np.testing.assert_array_equal(edges.numpy(), z["edges"])
+    np.testing.assert_array_equal(np.sort(e2f.numpy(), axis=1), z["edge2faces_sorted"])
+    fu = t.index_vertices_by_faces(torch.from_numpy(m["uvs"])[None], torch.from_numpy(m["face_uvs_idx"]).long())
+    np.testing.assert_array_equal(fu.numpy(), z["face_uvs"])
+    proj = t.generate_perspective_projection(np.arctan(1.0 / 2.5) * 2, ratio=1 / ratio)
+    np.testing.assert_array_equal(proj.numpy(), z["cam_proj"])
+    L = t.uniform_laplacian(v.shape[0], faces)
+    np.testing.assert_allclose(L.sum(1).numpy(), z["laplacian_rowsum"], atol=1e-6)
+    assert int((L != 0).sum()) == int(z["laplacian_nnz"])
+    np.testing.assert_array_equal(torch.sign(v[:, 2]).numpy(), z["sign_init"])
+    # CSR forms agree with the dense/reference tables
+    off, items = t.vertex_corner_adjacency(v.shape[0], faces)
+    flat = faces.reshape(-1).numpy()
+    for vid in (0, 17, v.shape[0] - 1):
+        assert set(items[off[vid]:off[vid + 1]].tolist()) == set(np.flatnonzero(flat == vid).tolist())
+    loff, lnb = t.sparse_laplacian_rows(v.shape[0], faces)
+    for vid in (0, 5, v.shape[0] - 1):
+        assert set(lnb[loff[vid]:loff[vid + 1]].tolist()) == set(np.flatnonzero(L[vid].numpy() > 0).tolist())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/template"), reason="reference tree not present")
+@pytest.mark.parametrize("name", ["sphere", "smpl_uv_642", "ellipsoid"])
+def test_obj_parser_reproduces_template_fixture(pkg, name):
+    m = pkg.obj_io.import_mesh("/root/reference/template/%s.obj" % name)
+    z = load_template_npz(name)
+    np.testing.assert_array_equal(m.vertices.numpy(), z["vertices"])
+    np.testing.assert_array_equal(m.faces.numpy(), z["faces"])
+    np.testing.assert_array_equal(m.uvs.numpy(), z["uvs"])
+    np.testing.assert_array_equal(m.face_uvs_idx.numpy(), z["face_uvs_idx"])
+
+
+def test_obj_roundtrip_and_edge_cases(pkg, tmp_path):
+    p = tmp_path / "t.obj"
+    p.write_text("# c\nmtllib x.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvt 0 0\nvt 1 0\nvt 0 1\nvn 0 0 1\n"
+                 "f 1/1/1 2/2/1 3/3/1\nf -1/1 -2/2 -3/3\nf 1 2 4\n")
+    m = pkg.obj_io.import_mesh(str(p))
+    assert m.vertices.shape == (4, 3) and m.faces.tolist() == [[0, 1, 2], [3, 2, 1], [0, 1, 3]]
+    assert m.face_uvs_idx.tolist() == [[0, 1, 2], [0, 1, 2], [-1, -1, -1]]
+    q = tmp_path / "o.obj"
+    pkg.obj_io.save_mesh(str(q), m.vertices, m.faces, m.uvs)
+    m2 = pkg.obj_io.import_mesh(str(q))
+    np.testing.assert_allclose(m2.vertices.numpy(), m.vertices.numpy())
+    assert m2.faces.tolist() == m.faces.tolist() and m2.uvs.shape == (3, 2)
+    (tmp_path / "quad.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+    with pytest.raises(ValueError):
+        pkg.obj_io.import_mesh(str(tmp_path / "quad.obj"))
+    npz = pkg.obj_io.load_template(os.path.join(TEMPLATES, "sphere.npz"))
+    assert npz.vertices.shape == (642, 3) and npz.faces.dtype == torch.int64
+
+
+@pytest.mark.parametrize("contour", [0.0, 0.5])
+def test_recon_data_matches_reference(oracle, contour):
+    z = np.load(os.path.join(GOLDEN, "losses.npz"))
+    pred = z["rd_pred_nhwc"].transpose(0, 3, 1, 2)          # NCHW view of NHWC storage, like render's output
+    for dt, tol in ((np.float32, 2e-6), (np.float64, 1e-6)):
+        loss, dpred = oracle.recon_data(pred.astype(dt).transpose(0, 2, 3, 1).copy().transpose(0, 3, 1, 2), z["rd_gt"],
+                                        image_weight=0.1, contour=contour, want_grad=True, dtype=dt)
+        assert abs(loss - float(z["recon_data_c%g" % contour])) < tol
+        np.testing.assert_allclose(dpred.transpose(0, 2, 3, 1), z["recon_data_c%g__d_pred_nhwc" % contour], rtol=1e-4, atol=1e-9)

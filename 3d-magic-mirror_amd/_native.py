@@ -1,0 +1,97 @@
+"""ctypes binding of the C ABI in include/mm_render.h (lib/libmm_render.so).
+
+The product path has NO fallback: if the shared library cannot be loaded, or a call returns a negative MMStatus, a
+RuntimeError is raised.  torch is used here only for device memory and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmm_render.so")
+_LIB = None
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int32
+c_p = ctypes.c_void_p
+
+
+class MMRenderDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("V", c_i), ("F", c_i), ("Ht", c_i), ("Wt", c_i), ("no_mask", c_i),
+                ("knum", c_i), ("proj", c_f * 3), ("sigmainv", c_f), ("boxlen", c_f), ("multiplier", c_f), ("eps", c_f),
+                ("faces", c_p), ("face_uvs", c_p), ("vc_offsets", c_p), ("vc_items", c_p),
+                ("vertices", c_p), ("textures", c_p), ("lights", c_p), ("bg", c_p), ("azimuths", c_p), ("elevations", c_p),
+                ("distances", c_p), ("biases", c_p),
+                ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
+                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
+class MMRenderGrads(ctypes.Structure):
+    _fields_ = [("grad_rgba", c_p), ("grad_face_normals", c_p), ("grad_vertices", c_p), ("grad_textures", c_p),
+                ("grad_lights", c_p), ("grad_bg", c_p), ("grad_azimuths", c_p), ("grad_elevations", c_p),
+                ("grad_distances", c_p), ("grad_biases", c_p)]
+
+
+class MMReconDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("pred", c_p), ("pred_strides", ctypes.c_int64 * 4), ("gt", c_p),
+                ("image_weight", c_f), ("contour", c_f), ("loss", c_p), ("grad_loss", c_p), ("grad_pred", c_p),
+                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
+EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",
+           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_status_string",
+           "mm_abi_version")
+
+
+def lib():
+    """Load libmm_render.so (building it in-tree first if the sources are newer and hipcc is available)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    try:
+        from . import build_native
+        if build_native.needs_build() and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            build_native.build()
+    except Exception as e:  # a stale-but-present library is still usable; a missing one is fatal below
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmm_render.so is missing and could not be built: %s" % e)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libmm_render.so not found at %s (run __graft_entry__.build())" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError("libmm_render.so does not export %s" % name)
+    L.mm_query_workspace.restype = ctypes.c_size_t
+    L.mm_query_workspace.argtypes = [ctypes.POINTER(MMRenderDesc)]
+    L.mm_render_forward.argtypes = [ctypes.POINTER(MMRenderDesc), c_p]
+    L.mm_render_backward.argtypes = [ctypes.POINTER(MMRenderDesc), ctypes.POINTER(MMRenderGrads), c_p]
+    L.mm_recon_query_workspace.restype = ctypes.c_size_t
+    L.mm_recon_query_workspace.argtypes = [ctypes.POINTER(MMReconDesc)]
+    L.mm_recon_data_forward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
+    L.mm_recon_data_backward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
+    L.mm_build_vertex_corner_csr.argtypes = [c_i, c_i, c_p, c_p, c_p]
+    L.mm_status_string.restype = ctypes.c_char_p
+    L.mm_status_string.argtypes = [ctypes.c_int]
+    _LIB = L
+    return L
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError("%s failed: %s (MMStatus %d)" % (what, lib().mm_status_string(status).decode(), status))
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("the MI355X render path needs tensors in device memory (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)

@@ -1,0 +1,117 @@
+// mm_abi.hip -- extern "C" entry points of libmm_render.so (declared in include/mm_render.h): argument validation,
+// workspace carving and launch sequencing.  No allocation, no host synchronisation, no global state.
+#include "mm_device.h"
+
+namespace mm {
+int launch_vertex_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
+int launch_vertex_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
+int launch_raster_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
+int launch_raster_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
+size_t recon_workspace_bytes(const MMReconDesc*);
+int launch_recon_fwd(const MMReconDesc*, hipStream_t);
+int launch_recon_bwd(const MMReconDesc*, hipStream_t);
+}  // namespace mm
+
+static int check_render(const MMRenderDesc* d, bool backward) {
+    if (!d) return MM_ERR_NULL_POINTER;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->V <= 0 || d->F <= 0 || d->Ht <= 0 || d->Wt <= 0) return MM_ERR_BAD_SHAPE;
+    if (d->knum <= 0) return MM_ERR_UNSUPPORTED;
+    if (!d->faces || !d->face_uvs || !d->vertices || !d->textures || !d->lights || !d->azimuths || !d->elevations ||
+        !d->distances || !d->biases || !d->rgba || !d->face_idx || !d->face_normals)
+        return MM_ERR_NULL_POINTER;
+    if (d->no_mask && !d->bg) return MM_ERR_NULL_POINTER;
+    if (backward && (!d->vc_offsets || !d->vc_items)) return MM_ERR_NULL_POINTER;
+    if (!d->workspace || d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_WORKSPACE;
+    return MM_OK;
+}
+
+extern "C" {
+
+size_t mm_query_workspace(const MMRenderDesc* d) {
+    if (!d || d->B <= 0 || d->F <= 0) return 0;
+    return mm::carve_workspace(nullptr, d->B, d->F).bytes;
+}
+
+int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
+    int st = check_render(d, false);
+    if (st != MM_OK) return st;
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->F);
+    hipStream_t s = (hipStream_t)stream;
+    st = mm::launch_vertex_fwd(d, w, s);
+    if (st != MM_OK) return st;
+    return mm::launch_raster_fwd(d, w, s);
+}
+
+int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {
+    int st = check_render(d, true);
+    if (st != MM_OK) return st;
+    if (!g || !g->grad_rgba || !g->grad_vertices || !g->grad_textures || !g->grad_lights || !g->grad_azimuths ||
+        !g->grad_elevations || !g->grad_distances || !g->grad_biases)
+        return MM_ERR_NULL_POINTER;
+    if (d->no_mask && !g->grad_bg) return MM_ERR_NULL_POINTER;
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->F);
+    hipStream_t s = (hipStream_t)stream;
+    st = mm::launch_raster_bwd(d, g, w, s);
+    if (st != MM_OK) return st;
+    return mm::launch_vertex_bwd(d, g, w, s);
+}
+
+static int check_recon(const MMReconDesc* d, bool backward) {
+    if (!d) return MM_ERR_NULL_POINTER;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0) return MM_ERR_BAD_SHAPE;
+    if (!d->pred || !d->gt) return MM_ERR_NULL_POINTER;
+    if (!backward && !d->loss) return MM_ERR_NULL_POINTER;
+    if (backward && !d->grad_pred) return MM_ERR_NULL_POINTER;
+    if (d->contour > 0.f && (d->H < 4 || d->W < 4)) return MM_ERR_BAD_SHAPE;
+    if (!d->workspace || d->workspace_bytes < mm_recon_query_workspace(d)) return MM_ERR_WORKSPACE;
+    return MM_OK;
+}
+
+size_t mm_recon_query_workspace(const MMReconDesc* d) {
+    if (!d || d->B <= 0) return 0;
+    return mm::recon_workspace_bytes(d);
+}
+
+int mm_recon_data_forward(const MMReconDesc* d, mm_stream_t stream) {
+    int st = check_recon(d, false);
+    if (st != MM_OK) return st;
+    return mm::launch_recon_fwd(d, (hipStream_t)stream);
+}
+
+int mm_recon_data_backward(const MMReconDesc* d, mm_stream_t stream) {
+    int st = check_recon(d, true);
+    if (st != MM_OK) return st;
+    return mm::launch_recon_bwd(d, (hipStream_t)stream);
+}
+
+int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces, int32_t* offsets, int32_t* items) {
+    if (!faces || !offsets || !items) return MM_ERR_NULL_POINTER;
+    if (V <= 0 || F <= 0) return MM_ERR_BAD_SHAPE;
+    for (int i = 0; i <= V; ++i) offsets[i] = 0;
+    for (int i = 0; i < 3 * F; ++i) {
+        if (faces[i] < 0 || faces[i] >= V) return MM_ERR_BAD_SHAPE;
+        ++offsets[faces[i] + 1];
+    }
+    for (int i = 0; i < V; ++i) offsets[i + 1] += offsets[i];
+    // counting sort: corners visited ascending, so each vertex's list is ascending; offsets doubles as the cursor
+    for (int i = 0; i < 3 * F; ++i) items[offsets[faces[i]]++] = i;
+    for (int v = V; v > 0; --v) offsets[v] = offsets[v - 1];
+    offsets[0] = 0;
+    return MM_OK;
+}
+
+const char* mm_status_string(int status) {
+    switch (status) {
+        case MM_OK: return "ok";
+        case MM_ERR_NULL_POINTER: return "required pointer is NULL";
+        case MM_ERR_BAD_SHAPE: return "bad or inconsistent size";
+        case MM_ERR_WORKSPACE: return "workspace missing, misaligned or too small";
+        case MM_ERR_LAUNCH: return "HIP launch failed";
+        case MM_ERR_UNSUPPORTED: return "unsupported option";
+        default: return "unknown status";
+    }
+}
+
+int mm_abi_version(void) { return 1; }
+
+}  // extern "C"

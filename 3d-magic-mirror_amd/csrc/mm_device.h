@@ -1,0 +1,211 @@
+// mm_device.h -- device-side helpers shared by the gfx950 kernels of libmm_render.so.
+//
+// Exactness contract: everything that decides WHICH face wins a pixel (camera, vertex transform, projection, bbox,
+// edge functions, normalisation, z interpolation) is written as explicit fp32 expressions in a fixed order and the
+// library is compiled with -ffp-contract=off, IEEE-rounded '/' and sqrtf (hipcc's default for HIP).  The CPU oracle
+// (oracle/mm_oracle.inc) evaluates the same expressions in the same order, which is what makes face_idx comparable
+// bit for bit.  Semantics: SURVEY.md section 8(a); reference call sites /root/reference/networks.py:258-324.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mm_render.h"
+
+#define MM_WAVE 64
+#define MM_TILE_W 8           // pixels per wave tile, x
+#define MM_TILE_H 8           // pixels per wave tile, y
+#define MM_BLOCK_WAVES 4      // a 256-thread workgroup renders a 32x8 pixel strip: 4 wave tiles side by side
+
+namespace mm {
+
+struct Float3 { float x, y, z; };
+
+// ---- workspace carving (all offsets multiples of 256 bytes) ---------------------------------------------------------
+struct Workspace {
+    float* T;              // (B,12)   camera transform [R;t], row-major (4,3)
+    float4* bbox;          // (B,F)    xmin,ymin,xmax,ymax of the projected face, in multiplier units
+    float4* geo;           // (B,F,3)  {ax,ay,bx,by} {cx,cy,az,bz} {cz, unit normal z, 0, 0}; xy in multiplier units
+    uint64_t* valid;       // (B,ceil(F/64)) bit f%64 of word f/64: face_normals_z >= 0 (front facing)
+    float* dfxy;           // (B,F,3,2) backward accumulator: dL/d face_vertices_image (unscaled NDC)
+    float* dfn;            // (B,F,3)   backward accumulator: dL/d unit face normal (from the rasterised normals)
+    size_t bytes;
+};
+
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+__host__ __device__ inline Workspace carve_workspace(void* base, int B, int F) {
+    Workspace w;
+    char* p = (char*)base;
+    size_t o = 0;
+    w.T = (float*)(p + o);        o += align256((size_t)B * 12 * sizeof(float));
+    w.bbox = (float4*)(p + o);    o += align256((size_t)B * F * sizeof(float4));
+    w.geo = (float4*)(p + o);     o += align256((size_t)B * F * 3 * sizeof(float4));
+    w.valid = (uint64_t*)(p + o); o += align256((size_t)B * ((F + 63) / 64) * sizeof(uint64_t));
+    w.dfxy = (float*)(p + o);     o += align256((size_t)B * F * 6 * sizeof(float));
+    w.dfn = (float*)(p + o);      o += align256((size_t)B * F * 3 * sizeof(float));
+    w.bytes = o;
+    return w;
+}
+
+// ---- camera: smr_utils.py:257-311 + networks.py:278-282 -----------------------------------------------------------
+struct Camera {
+    float ce, se, ca, sa;
+    float cam[3], zv[3], zl, z[3], xv[3], xl, x[3], y[3];
+    float T[12];
+};
+
+__device__ inline void cross3(const float* a, const float* b, float* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+#define MM_DEG2RAD 0.017453292519943295f
+
+// trig values are produced by the caller (fp64 sin/cos rounded to fp32, one lane per value)
+__device__ inline void camera_build(float dist, float ce, float se, float ca, float sa, float bx, float by, Camera& c) {
+    const float up[3] = {0.f, 1.f, 0.f};
+    c.ce = ce; c.se = se; c.ca = ca; c.sa = sa;
+    c.cam[0] = (dist * ce) * sa;
+    c.cam[1] = dist * se;
+    c.cam[2] = (dist * ce) * ca;
+    const float at[3] = {bx, by, 0.f};
+    for (int i = 0; i < 3; ++i) c.zv[i] = c.cam[i] - at[i];
+    c.zl = sqrtf((c.zv[0] * c.zv[0] + c.zv[1] * c.zv[1]) + c.zv[2] * c.zv[2]);
+    for (int i = 0; i < 3; ++i) c.z[i] = c.zv[i] / c.zl;
+    cross3(up, c.z, c.xv);
+    c.xl = sqrtf((c.xv[0] * c.xv[0] + c.xv[1] * c.xv[1]) + c.xv[2] * c.xv[2]);
+    for (int i = 0; i < 3; ++i) c.x[i] = c.xv[i] / c.xl;
+    cross3(c.z, c.x, c.y);
+    for (int i = 0; i < 3; ++i) { c.T[i * 3 + 0] = c.x[i]; c.T[i * 3 + 1] = c.y[i]; c.T[i * 3 + 2] = c.z[i]; }
+    for (int j = 0; j < 3; ++j)
+        c.T[9 + j] = ((-c.cam[0]) * c.T[0 + j] + (-c.cam[1]) * c.T[3 + j]) + (-c.cam[2]) * c.T[6 + j];
+}
+
+// dT (4,3) -> d(dist, elev[deg], azim[deg], bias)
+__device__ inline void camera_backward(float dist, const Camera& c, const float* dT, float* ddist, float* delev,
+                                       float* dazim, float* dbias) {
+    const float up[3] = {0.f, 1.f, 0.f};
+    float dx[3], dy[3], dz[3], dcam[3], tmp[3];
+    for (int i = 0; i < 3; ++i) {
+        dx[i] = dT[i * 3 + 0] - c.cam[i] * dT[9 + 0];
+        dy[i] = dT[i * 3 + 1] - c.cam[i] * dT[9 + 1];
+        dz[i] = dT[i * 3 + 2] - c.cam[i] * dT[9 + 2];
+        dcam[i] = -((c.T[i * 3 + 0] * dT[9 + 0] + c.T[i * 3 + 1] * dT[9 + 1]) + c.T[i * 3 + 2] * dT[9 + 2]);
+    }
+    cross3(c.x, dy, tmp); for (int i = 0; i < 3; ++i) dz[i] += tmp[i];
+    cross3(dy, c.z, tmp); for (int i = 0; i < 3; ++i) dx[i] += tmp[i];
+    float xd = (c.x[0] * dx[0] + c.x[1] * dx[1]) + c.x[2] * dx[2];
+    float dxv[3]; for (int i = 0; i < 3; ++i) dxv[i] = (dx[i] - c.x[i] * xd) / c.xl;
+    cross3(dxv, up, tmp); for (int i = 0; i < 3; ++i) dz[i] += tmp[i];
+    float zd = (c.z[0] * dz[0] + c.z[1] * dz[1]) + c.z[2] * dz[2];
+    float dzv[3]; for (int i = 0; i < 3; ++i) dzv[i] = (dz[i] - c.z[i] * zd) / c.zl;
+    for (int i = 0; i < 3; ++i) dcam[i] += dzv[i];
+    dbias[0] = -dzv[0]; dbias[1] = -dzv[1];
+    *ddist = (dcam[0] * (c.ce * c.sa) + dcam[1] * c.se) + dcam[2] * (c.ce * c.ca);
+    float de = (dcam[0] * (-(dist * c.se) * c.sa) + dcam[1] * (dist * c.ce)) + dcam[2] * (-(dist * c.se) * c.ca);
+    float da = dcam[0] * ((dist * c.ce) * c.ca) + dcam[2] * (-(dist * c.ce) * c.sa);
+    *delev = de * MM_DEG2RAD; *dazim = da * MM_DEG2RAD;
+}
+
+// ---- prepare_vertices pieces ----------------------------------------------------------------------
+__device__ inline Float3 to_camera(const float* __restrict__ v, const float* T) {
+    Float3 r;
+    r.x = ((v[0] * T[0] + v[1] * T[3]) + v[2] * T[6]) + T[9];
+    r.y = ((v[0] * T[1] + v[1] * T[4]) + v[2] * T[7]) + T[10];
+    r.z = ((v[0] * T[2] + v[1] * T[5]) + v[2] * T[8]) + T[11];
+    return r;
+}
+
+// ---- pixel centre convention of kaolin's rasteriser -----------------------------------------------
+__device__ inline float pixel_x(int px, int W, float mult) { return (mult / (float)W) * (float)(2 * px + 1 - W); }
+__device__ inline float pixel_y(int py, int H, float mult) { return (mult / (float)H) * (float)(H - 2 * py - 1); }
+
+// barycentric weights exactly as packed_rasterize_forward (edge functions, copysign(eps) normalisation)
+__device__ inline void edge_weights(float ax, float ay, float bx, float by, float cx, float cy, float x0, float y0, float eps,
+                                    float& w0, float& w1, float& w2, float& nrm) {
+    float aex = ax - x0, aey = ay - y0, bex = bx - x0, bey = by - y0, cex = cx - x0, cey = cy - y0;
+    w0 = bex * cey - bey * cex;
+    w1 = cex * aey - cey * aex;
+    w2 = aex * bey - aey * bex;
+    nrm = (w0 + w1) + w2;
+    nrm += copysignf(eps, nrm);
+}
+
+// ---- bilinear texture fetch = grid_sample(align_corners=False, padding_mode='border') -------------
+struct Bilin { int x0, y0, x1, y1; float wnw, wne, wsw, wse, tx, ty, mx, my; };
+
+__device__ inline Bilin bilin_setup(float u, float v, int Ht, int Wt) {
+    Bilin s;
+    float gx = u * 2.f - 1.f;
+    float gy = -(v * 2.f - 1.f);
+    float ix = ((gx + 1.f) * (float)Wt - 1.f) / 2.f;
+    float iy = ((gy + 1.f) * (float)Ht - 1.f) / 2.f;
+    if (ix <= 0.f) { ix = 0.f; s.mx = 0.f; } else if (ix >= (float)(Wt - 1)) { ix = (float)(Wt - 1); s.mx = 0.f; } else s.mx = 1.f;
+    if (iy <= 0.f) { iy = 0.f; s.my = 0.f; } else if (iy >= (float)(Ht - 1)) { iy = (float)(Ht - 1); s.my = 0.f; } else s.my = 1.f;
+    float fx = floorf(ix), fy = floorf(iy);
+    s.x0 = (int)fx; s.y0 = (int)fy; s.x1 = s.x0 + 1; s.y1 = s.y0 + 1;
+    s.tx = ix - fx; s.ty = iy - fy;
+    float ex = (fx + 1.f) - ix, ey = (fy + 1.f) - iy;
+    s.wnw = ex * ey; s.wne = s.tx * ey; s.wsw = ex * s.ty; s.wse = s.tx * s.ty;
+    return s;
+}
+
+// ---- spherical harmonics -------------------------------------------------------------------------
+#define MM_SH_C0 0.28209479177f
+#define MM_SH_C1 0.4886025119f
+#define MM_SH_C4 1.09254843059f
+#define MM_SH_C6 0.94617469575f
+#define MM_SH_C6B 0.31539156525f
+#define MM_SH_C7 0.77254840404f
+#define MM_SH_C8 0.38627420202f
+
+__device__ inline void sh_bands(float x, float y, float z, float* b) {
+    b[0] = MM_SH_C0;
+    b[1] = MM_SH_C1 * x;
+    b[2] = MM_SH_C1 * z;
+    b[3] = MM_SH_C1 * y;
+    b[4] = MM_SH_C4 * (x * y);
+    b[5] = MM_SH_C4 * (y * z);
+    b[6] = MM_SH_C6 * (z * z) - MM_SH_C6B;
+    b[7] = MM_SH_C7 * (x * z);
+    b[8] = MM_SH_C8 * (x * x - y * y);
+}
+
+// ---- squared distance from p to segment u->v; region 0: clamped at u, 1: interior, 2: clamped at v ----------------
+__device__ inline float seg_dist2(float px, float py, float ux, float uy, float vx, float vy, int& region) {
+    float ex = vx - ux, ey = vy - uy, rx = px - ux, ry = py - uy;
+    float len2 = ex * ex + ey * ey;
+    float dot = rx * ex + ry * ey;
+    float t = (len2 > 0.f) ? dot / len2 : 0.f;
+    if (t <= 0.f) { region = 0; return rx * rx + ry * ry; }
+    if (t >= 1.f) { region = 2; float sx = px - vx, sy = py - vy; return sx * sx + sy * sy; }
+    region = 1;
+    float qx = px - (ux + t * ex), qy = py - (uy + t * ey);
+    return qx * qx + qy * qy;
+}
+
+// ---- workgroup -> (image, strip) mapping that keeps all strips of one image on one XCD ------------------------------
+// The dispatcher places workgroup i on XCD i % 8 (observed, used for L2 locality only: nothing depends on it for
+// correctness).  Images are dealt to XCDs in groups of 8 so that the face records of an image are read through a
+// single XCD's L2 instead of all eight.
+__device__ inline void map_block(int linear, int B, int tiles_per_image, int& b, int& tile) {
+    const int full = (B / 8) * 8 * tiles_per_image;
+    if (linear < full) {
+        const int xcd = linear & 7, k = linear >> 3;
+        b = (k / tiles_per_image) * 8 + xcd;
+        tile = k % tiles_per_image;
+    } else {
+        const int r = linear - full;
+        b = (B / 8) * 8 + r / tiles_per_image;
+        tile = r % tiles_per_image;
+    }
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace mm

@@ -1,0 +1,136 @@
+/*
+ * mm_render.h -- C ABI of libmm_render.so: the MI355X (gfx950) differentiable render + reconstruction-loss path of
+ * 3D-Magic-Mirror.
+ *
+ * This is the drop-in boundary for the path
+ *     DiffRender.render        /root/reference/networks.py:258-324
+ *     DiffRender.recon_data    /root/reference/networks.py:364-390
+ * and, below it, for what the reference reaches through kaolin (NVIDIAGameWorks/kaolin v0.12.0, not vendored):
+ *     kaolin.render.mesh.prepare_vertices / dibr_rasterization / texture_mapping / spherical_harmonic_lighting
+ *     (call sites networks.py:284-306) -> kaolin._C.render.mesh.{packed_rasterize_forward_cuda,
+ *     rasterize_backward_cuda, dibr_soft_mask_forward_cuda, dibr_soft_mask_backward_cuda},
+ *     kaolin.metrics.render.mask_iou (call site networks.py:377).
+ *
+ * Rules of the ABI
+ *   - plain C: raw DEVICE pointers, sizes and scalars only; no torch / C++ types.
+ *   - every function returns MM_OK (0) or a negative MMStatus; nothing throws across the boundary.
+ *   - the library never allocates: the caller owns every buffer including the workspace
+ *     (size from mm_query_workspace / mm_recon_query_workspace) and keeps the render workspace alive, unmodified,
+ *     between mm_render_forward and the matching mm_render_backward.
+ *   - all work is enqueued on the given HIP stream (pass the hipStream_t as a void*; NULL = the null stream);
+ *     no host synchronisation, no global state, re-entrant.
+ *   - all floating point is fp32; indices are int32.  Tensors are dense row-major unless strides are given.
+ */
+#ifndef MM_RENDER_H
+#define MM_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mm_stream_t; /* hipStream_t */
+
+typedef enum MMStatus {
+    MM_OK = 0,
+    MM_ERR_NULL_POINTER = -1,   /* a required pointer is NULL */
+    MM_ERR_BAD_SHAPE = -2,      /* a size is <= 0 or inconsistent */
+    MM_ERR_WORKSPACE = -3,      /* workspace missing or smaller than mm_query_workspace() */
+    MM_ERR_LAUNCH = -4,         /* hipLaunchKernel / hipMemsetAsync reported an error */
+    MM_ERR_UNSUPPORTED = -5     /* option outside what the kernels implement (e.g. knum > 64) */
+} MMStatus;
+
+/* --------------------------------------------------------------------------------------------------------------------
+ * Render: replaces DiffRender.render (networks.py:258-324), i.e. camera (smr_utils.py:257-311) -> prepare_vertices ->
+ * dibr_rasterization -> texture_mapping -> spherical_harmonic_lighting -> composite -> clamp -> cat(soft mask).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct MMRenderDesc {
+    /* sizes */
+    int32_t B, H, W;            /* batch, image rows (= round(ratio*image_size)), image cols (= image_size) */
+    int32_t V, F;               /* template vertices / faces */
+    int32_t Ht, Wt;             /* texture rows / cols */
+    int32_t no_mask;            /* 1: composite over bg then shade (trainer's --bg); 0: white background  (:307-313) */
+    int32_t knum;               /* dibr_rasterization knum (30) */
+    /* constants: cam_proj (networks.py:172-174) and the dibr_rasterization defaults */
+    float proj[3];              /* [1/(ratio'*tan(fovy/2)), 1/tan(fovy/2), -1] */
+    float sigmainv, boxlen, multiplier, eps; /* 7000, 0.02, 1000, 1e-8 */
+    /* static template data (device) */
+    const int32_t* faces;       /* (F,3) vertex ids */
+    const float* face_uvs;      /* (F,3,2) raw OBJ uv of every corner (networks.py:196-202) */
+    const int32_t* vc_offsets;  /* (V+1) CSR: vertex -> incident corners ...        (backward only; may be NULL forward) */
+    const int32_t* vc_items;    /* (3F)  ... each item = face*3 + corner, ascending (backward only) */
+    /* per-sample attributes (device), the 'attributes' dict of networks.py:259-270 */
+    const float* vertices;      /* (B,V,3) */
+    const float* textures;      /* (B,3,Ht,Wt) */
+    const float* lights;        /* (B,9) */
+    const float* bg;            /* (B,3,H,W); required iff no_mask */
+    const float* azimuths;      /* (B) degrees */
+    const float* elevations;    /* (B) degrees */
+    const float* distances;     /* (B) */
+    const float* biases;        /* (B,2) */
+    /* outputs (device) */
+    float* rgba;                /* (B,H,W,4): NHWC storage; the reference returns the (B,4,H,W) permute VIEW of it (:317) */
+    int32_t* face_idx;          /* (B,H,W): winning face per pixel, -1 = none (kaolin returns int64; int32 here) */
+    float* face_normals;        /* (B,F,3): unit face normals in camera space = attributes['face_normals'] (:319) */
+    float* imnormal;            /* (B,H,W,3) or NULL: attributes['imnormal'] (:320, "visualize only") */
+    /* scratch */
+    void* workspace;            /* >= mm_query_workspace(desc) bytes, 256-byte aligned */
+    size_t workspace_bytes;
+} MMRenderDesc;
+
+/* Gradients of one render call.  Every non-NULL output is OVERWRITTEN (the library zero-fills what it accumulates). */
+typedef struct MMRenderGrads {
+    const float* grad_rgba;          /* (B,H,W,4) NHWC, dL/d rgba; required */
+    const float* grad_face_normals;  /* (B,F,3) or NULL: dL/d attributes['face_normals'] (used by calc_reg_loss, :422-431) */
+    float* grad_vertices;            /* (B,V,3) */
+    float* grad_textures;            /* (B,3,Ht,Wt) */
+    float* grad_lights;              /* (B,9) */
+    float* grad_bg;                  /* (B,3,H,W); required iff no_mask */
+    float* grad_azimuths;            /* (B) per degree */
+    float* grad_elevations;          /* (B) per degree */
+    float* grad_distances;           /* (B) */
+    float* grad_biases;              /* (B,2) */
+} MMRenderGrads;
+
+size_t mm_query_workspace(const MMRenderDesc* desc);
+int mm_render_forward(const MMRenderDesc* desc, mm_stream_t stream);
+int mm_render_backward(const MMRenderDesc* desc, const MMRenderGrads* grads, mm_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------------------------------
+ * Reconstruction loss: replaces DiffRender.recon_data (networks.py:364-390) incl. kaolin mask_iou (:377) and the
+ * optional contour term (:379-387):  loss = image_weight * mean|pred*gm+(1-gm) - (gt*gm+(1-gm))| + (1 - mean_b IoU_b)
+ *                                           [+ contour * mean((c(pred_mask) - c(gt_mask))^2)].
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct MMReconDesc {
+    int32_t B, H, W;
+    const float* pred;           /* rgba prediction, element strides below (NHWC storage from mm_render_forward: {4HW,1,4W,4}) */
+    int64_t pred_strides[4];     /* strides of (b, channel, y, x) in elements */
+    const float* gt;             /* (B,4,H,W) dense: rgb + binary mask */
+    float image_weight;          /* DiffRender.image_weight */
+    float contour;               /* lambda_contour; <= 0 disables the term */
+    float* loss;                 /* (1) device scalar, overwritten */
+    /* backward only */
+    const float* grad_loss;      /* (1) device scalar dL/dloss, or NULL for 1 */
+    float* grad_pred;            /* same strides as pred; overwritten */
+    void* workspace;             /* >= mm_recon_query_workspace(desc) bytes; forward fills it, backward reads it */
+    size_t workspace_bytes;
+} MMReconDesc;
+
+size_t mm_recon_query_workspace(const MMReconDesc* desc);
+int mm_recon_data_forward(const MMReconDesc* desc, mm_stream_t stream);
+int mm_recon_data_backward(const MMReconDesc* desc, mm_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------------------------------
+ * Host helpers (no GPU involved)
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* Build the vertex -> corner CSR from HOST faces (F,3).  offsets: (V+1), items: (3F).  Returns MM_OK or an error. */
+int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces_host, int32_t* offsets_host, int32_t* items_host);
+const char* mm_status_string(int status);
+int mm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM_RENDER_H */

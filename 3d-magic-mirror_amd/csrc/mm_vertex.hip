@@ -196,7 +196,8 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.bbox = w.bbox; a.geo = w.geo; a.valid = w.valid; a.face_normals = d->face_normals;
     dim3 grid((d->F + 255) / 256, d->B);
-    hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a);
+    { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
+      hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 
@@ -209,7 +210,8 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.dfxy = w.dfxy; a.dfn = w.dfn; a.gfn = g->grad_face_normals;
     a.grad_vertices = g->grad_vertices;
     a.grad_azim = g->grad_azimuths; a.grad_elev = g->grad_elevations; a.grad_dist = g->grad_distances; a.grad_bias = g->grad_biases;
-    hipLaunchKernelGGL(vertex_bwd_kernel, dim3(d->B), dim3(MM_VB_THREADS), 0, s, a);
+    { ProfScope ps(d->prof_events, MM_PROF_VERTEX_BWD, s);
+      hipLaunchKernelGGL(vertex_bwd_kernel, dim3(d->B), dim3(MM_VB_THREADS), 0, s, a); }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 

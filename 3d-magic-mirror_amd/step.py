@@ -1,0 +1,121 @@
+"""Pre-planned render -> recon_data -> backward step over the C ABI, replayable as one HIP graph.
+
+The autograd wrappers in diff_render.py allocate per call and cross the Python/torch boundary four times per step;
+for a training loop (and for bench.py) the same four ABI calls are issued here against buffers allocated once, and
+captured into a HIP graph so that one step costs one graph launch on the host.  Work per step is exactly
+mm_render_forward + mm_recon_data_forward + mm_recon_data_backward + mm_render_backward (no skipped stage).
+"""
+import ctypes
+
+import torch
+
+from . import _native as N
+
+LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "distances", "biases")
+
+
+class HipEvents:
+    """Raw hipEvent_t pairs handed to the library's prof_events hook (timed on the stream the kernels run on)."""
+
+    def __init__(self, nslots):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.n = nslots
+        self.arr = (ctypes.c_void_p * (2 * nslots))()
+        for i in range(2 * nslots):
+            ev = ctypes.c_void_p()
+            rc = self.hip.hipEventCreate(ctypes.byref(ev))
+            if rc != 0:
+                raise RuntimeError("hipEventCreate failed (%d)" % rc)
+            self.arr[i] = ev
+
+    def ptr(self):
+        return ctypes.cast(self.arr, ctypes.c_void_p)
+
+    def elapsed_ms(self, slot):
+        ms = ctypes.c_float()
+        rc = self.hip.hipEventElapsedTime(ctypes.byref(ms), self.arr[2 * slot], self.arr[2 * slot + 1])
+        return ms.value if rc == 0 else float("nan")
+
+
+class RenderLossStep:
+    def __init__(self, dr, attributes, gt, no_mask=True, contour=0.0, emit_imnormal=False):
+        dev = attributes["azimuths"].device
+        N.require_device(*[attributes[k] for k in LEAVES if attributes.get(k) is not None], gt)
+        self.dr, self.dev, self.no_mask = dr, dev, bool(no_mask)
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        self.inp = {k: (f32(attributes[k]) if attributes.get(k) is not None else None) for k in LEAVES}
+        self.gt = f32(gt)
+        B = self.inp["azimuths"].shape[0]
+        H, W = dr.render_height, dr.image_size
+        self.B, self.H, self.W = B, H, W
+        st = dr._static(dev)
+        self.rgba = torch.empty((B, H, W, 4), device=dev)
+        self.face_idx = torch.empty((B, H, W), device=dev, dtype=torch.int32)
+        self.face_normals = torch.empty((B, dr.num_faces, 3), device=dev)
+        self.imnormal = torch.empty((B, H, W, 3), device=dev) if emit_imnormal else None
+        i = self.inp
+        self.d = dr._desc(st, B, no_mask, i["vertices"], i["textures"], i["lights"], i["bg"] if no_mask else None, i["azimuths"],
+                          i["elevations"], i["distances"], i["biases"], self.rgba, self.face_idx, self.face_normals, self.imnormal)
+        self.ws = torch.empty(N.lib().mm_query_workspace(ctypes.byref(self.d)), device=dev, dtype=torch.uint8)
+        self.d.workspace, self.d.workspace_bytes = N.ptr(self.ws), self.ws.numel()
+        self.grad_rgba = torch.empty_like(self.rgba)
+        self.grads = {k: (torch.empty_like(v) if v is not None and (k != "bg" or no_mask) else None) for k, v in self.inp.items()}
+        g = self.grads
+        self.g = N.MMRenderGrads(N.ptr(self.grad_rgba), None, N.ptr(g["vertices"]), N.ptr(g["textures"]), N.ptr(g["lights"]),
+                                 N.ptr(g["bg"]), N.ptr(g["azimuths"]), N.ptr(g["elevations"]), N.ptr(g["distances"]), N.ptr(g["biases"]))
+        self.loss = torch.zeros((), device=dev)
+        r = N.MMReconDesc()
+        r.B, r.H, r.W = B, H, W
+        r.pred, r.gt = N.ptr(self.rgba), N.ptr(self.gt)
+        for k, s in enumerate((H * W * 4, 1, W * 4, 4)):
+            r.pred_strides[k] = s
+        r.image_weight, r.contour = float(dr.image_weight), float(contour)
+        r.loss, r.grad_loss, r.grad_pred = N.ptr(self.loss), None, N.ptr(self.grad_rgba)
+        self.rws = torch.empty(N.lib().mm_recon_query_workspace(ctypes.byref(r)), device=dev, dtype=torch.uint8)
+        r.workspace, r.workspace_bytes = N.ptr(self.rws), self.rws.numel()
+        self.r = r
+        self.graph = None
+        self.ev_render = self.ev_recon = None
+
+    def run(self, stream=None):
+        """Enqueue one full step on ``stream`` (a torch.cuda.Stream; default: the current stream)."""
+        L = N.lib()
+        s = ctypes.c_void_p((stream or torch.cuda.current_stream(self.dev)).cuda_stream)
+        N.check(L.mm_render_forward(ctypes.byref(self.d), s), "mm_render_forward")
+        N.check(L.mm_recon_data_forward(ctypes.byref(self.r), s), "mm_recon_data_forward")
+        N.check(L.mm_recon_data_backward(ctypes.byref(self.r), s), "mm_recon_data_backward")
+        N.check(L.mm_render_backward(ctypes.byref(self.d), ctypes.byref(self.g), s), "mm_render_backward")
+
+    def capture(self):
+        """Capture run() into a HIP graph (torch.cuda.CUDAGraph is only the capture/replay plumbing)."""
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self.run(side)                      # warm-up outside capture (module load, first-touch)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.run(side)
+        return self.graph
+
+    def replay(self):
+        self.graph.replay()
+
+    # ---- per-kernel timing through the library's event hook (eager launches only) ------------------------------
+    def enable_profiling(self):
+        self.ev_render = HipEvents(len(N.PROF_RENDER))
+        self.ev_recon = HipEvents(len(N.PROF_RECON))
+        self.d.prof_events = self.ev_render.ptr()
+        self.r.prof_events = self.ev_recon.ptr()
+
+    def disable_profiling(self):
+        self.d.prof_events = None
+        self.r.prof_events = None
+
+    def kernel_times_ms(self):
+        """Call after run() + synchronize with profiling enabled."""
+        out = {name: self.ev_render.elapsed_ms(i) for i, name in enumerate(N.PROF_RENDER)}
+        out.update({name: self.ev_recon.elapsed_ms(i) for i, name in enumerate(N.PROF_RECON) if name != "recon_contour" or self.r.contour > 0})
+        return out

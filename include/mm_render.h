@@ -78,7 +78,15 @@ typedef struct MMRenderDesc {
     /* scratch */
     void* workspace;            /* >= mm_query_workspace(desc) bytes, 256-byte aligned */
     size_t workspace_bytes;
+    /* optional profiling: NULL, or an array of 2*MM_PROF_RENDER_SLOTS hipEvent_t created by the caller; the library
+     * records events [2*slot] / [2*slot+1] on the stream immediately before / after the kernel of that slot. */
+    void** prof_events;
 } MMRenderDesc;
+
+enum { MM_PROF_VERTEX_FWD = 0, MM_PROF_RASTER_FWD = 1, MM_PROF_ZERO = 2, MM_PROF_RASTER_BWD = 3, MM_PROF_VERTEX_BWD = 4,
+       MM_PROF_RENDER_SLOTS = 5 };
+enum { MM_PROF_RECON_PARTIAL = 0, MM_PROF_RECON_FINAL = 1, MM_PROF_RECON_BWD = 2, MM_PROF_RECON_CONTOUR = 3,
+       MM_PROF_RECON_SLOTS = 4 };
 
 /* Gradients of one render call.  Every non-NULL output is OVERWRITTEN (the library zero-fills what it accumulates). */
 typedef struct MMRenderGrads {
@@ -116,6 +124,7 @@ typedef struct MMReconDesc {
     float* grad_pred;            /* same strides as pred; overwritten */
     void* workspace;             /* >= mm_recon_query_workspace(desc) bytes; forward fills it, backward reads it */
     size_t workspace_bytes;
+    void** prof_events;          /* optional: 2*MM_PROF_RECON_SLOTS hipEvent_t, as in MMRenderDesc */
 } MMReconDesc;
 
 size_t mm_recon_query_workspace(const MMReconDesc* desc);

@@ -240,3 +240,20 @@ def recon_data(pred, gt, image_weight=0.1, contour=0.0, want_grad=False, gscale=
     loss = getattr(lib(), "mmo_recon_data_" + _sfx(dtype))(B, H, W, _p(pred), strides, _p(gt), r(image_weight), r(contour),
                                                            _p(dpred), r(gscale))
     return (float(loss), dpred) if want_grad else float(loss)
+
+
+def step(inp, gt, H, W, no_mask, proj, image_weight=0.1, dtype=np.float32, **kw):
+    """render -> recon_data -> backward in one call (the unit the CPU baseline times).  Returns (loss, grads dict)."""
+    a = _inputs(inp, dtype); c = _cfg(a, H, W, no_mask, proj, dtype, **kw)
+    B = c.B
+    g = {"vertices": np.zeros_like(a["vertices"]), "textures": np.zeros_like(a["textures"]), "lights": np.zeros((B, 9), dtype),
+         "bg": None if a["bg"] is None else np.zeros_like(a["bg"]), "azimuths": np.zeros(B, dtype), "elevations": np.zeros(B, dtype),
+         "distances": np.zeros(B, dtype), "biases": np.zeros((B, 2), dtype)}
+    fn = getattr(lib(), "mmo_step_" + _sfx(dtype))
+    fn.restype = _real(dtype)
+    r = _real(dtype)
+    loss = fn(ctypes.byref(c), _p(a["vertices"]), _p(a["faces"]), _p(a["face_uvs"]), _p(a["textures"]), _p(a["lights"]), _p(a["bg"]),
+              _p(a["azimuths"]), _p(a["elevations"]), _p(a["distances"]), _p(a["biases"]), _p(_c(gt, dtype)), r(image_weight),
+              _p(g["vertices"]), _p(g["textures"]), _p(g["lights"]), _p(g["bg"]), _p(g["azimuths"]), _p(g["elevations"]),
+              _p(g["distances"]), _p(g["biases"]))
+    return float(loss), g

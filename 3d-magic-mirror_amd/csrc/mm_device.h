@@ -12,37 +12,67 @@
 #include "../../include/mm_render.h"
 
 #define MM_WAVE 64
-#define MM_TILE_W 8           // pixels per wave tile, x
-#define MM_TILE_H 8           // pixels per wave tile, y
-#define MM_BLOCK_WAVES 4      // a 256-thread workgroup renders a 32x8 pixel strip: 4 wave tiles side by side
+#define MM_TILE 8             // a wave owns an 8x8 pixel tile, one lane per pixel
+#define MM_BLOCK_PX 16        // a 256-thread workgroup renders a 16x16 pixel block: 2x2 wave tiles
+#define MM_BLOCK_WAVES 4
+#define MM_GROUP_WORDS 16     // bin-mask words (of 64 faces) expanded per step: 1024 faces -> 2 KiB of uint16 ids per wave
 
 namespace mm {
 
 struct Float3 { float x, y, z; };
 
+// ---- screen bins ------------------------------------------------------------------------------------------------------
+// The vertex stage records, per screen bin, which faces' boxes (inflated by the soft-mask margin) may touch it, as one
+// bit per face: face order stays implicit in the bit order, which is what kaolin's tie rule and the soft mask's
+// "first knum faces" rule need.  Bin edge 8, 16 or 32 px, the smallest whose masks stay under 1/16 of the path's
+// algorithmic bytes per image (A = 140 F + 128 HW).
+__host__ __device__ inline int bin_shift_for(int H, int W, int F) {
+    const size_t words = (size_t)(F + 63) / 64;
+    const size_t A = (size_t)140 * F + (size_t)128 * H * W;
+    for (int s = 3; s < 5; ++s) {
+        const size_t nb = (size_t)((W + (1 << s) - 1) >> s) * ((H + (1 << s) - 1) >> s);
+        if (nb * words * 8 * 16 <= A) return s;
+    }
+    return 5;
+}
+
 // ---- workspace carving (all offsets multiples of 256 bytes) ---------------------------------------------------------
 struct Workspace {
-    float* T;              // (B,12)   camera transform [R;t], row-major (4,3)
-    float4* bbox;          // (B,F)    xmin,ymin,xmax,ymax of the projected face, in multiplier units
-    float4* geo;           // (B,F,3)  {ax,ay,bx,by} {cx,cy,az,bz} {cz, unit normal z, 0, 0}; xy in multiplier units
-    uint64_t* valid;       // (B,ceil(F/64)) bit f%64 of word f/64: face_normals_z >= 0 (front facing)
-    float* dfxy;           // (B,F,3,2) backward accumulator: dL/d face_vertices_image (unscaled NDC)
-    float* dfn;            // (B,F,3)   backward accumulator: dL/d unit face normal (from the rasterised normals)
+    float* T;              // (B,12)     camera transform [R;t], row-major (4,3)
+    float4* geo;           // (B,F,3)    {ax,ay,bx,by} {cx,cy,az,bz} {cz, unit normal z, 0, 0}; xy in multiplier units
+    uint64_t* binmask;     // (B,nbins,ceil(F/64)) bit f of bin: face f may touch the bin (zeroed every forward)
+    float* softq;          // (B,H,W)    soft-mask product state of uncovered pixels: +prod(1-p) if no factor is 0,
+                           //            -prod(non-zero factors) if exactly one factor is 0, 0 if two or more are
+    float* dfxy;           // (B,F,3,2)  backward accumulator: dL/d face_vertices_image (unscaled NDC)
+    float* dfn;            // (B,F,3)    backward accumulator: dL/d unit face normal (from the rasterised normals)
+    float* dTacc;          // (B,12)     backward accumulator: dL/d camera transform
+    unsigned* ticket;      // (B)        arrival counter of the vertex-backward workgroups of an image
+    size_t acc_floats;     // dfxy .. end of ticket, in floats (one contiguous zero-fill range)
+    int bin_shift, nbx, nby, words;
+    size_t binmask_bytes;
     size_t bytes;
 };
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-__host__ __device__ inline Workspace carve_workspace(void* base, int B, int F) {
+__host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, int H, int W) {
     Workspace w;
     char* p = (char*)base;
     size_t o = 0;
-    w.T = (float*)(p + o);        o += align256((size_t)B * 12 * sizeof(float));
-    w.bbox = (float4*)(p + o);    o += align256((size_t)B * F * sizeof(float4));
-    w.geo = (float4*)(p + o);     o += align256((size_t)B * F * 3 * sizeof(float4));
-    w.valid = (uint64_t*)(p + o); o += align256((size_t)B * ((F + 63) / 64) * sizeof(uint64_t));
-    w.dfxy = (float*)(p + o);     o += align256((size_t)B * F * 6 * sizeof(float));
-    w.dfn = (float*)(p + o);      o += align256((size_t)B * F * 3 * sizeof(float));
+    w.bin_shift = bin_shift_for(H, W, F);
+    w.nbx = (W + (1 << w.bin_shift) - 1) >> w.bin_shift;
+    w.nby = (H + (1 << w.bin_shift) - 1) >> w.bin_shift;
+    w.words = (F + 63) / 64;
+    w.binmask_bytes = (size_t)B * w.nbx * w.nby * w.words * sizeof(uint64_t);
+    w.T = (float*)(p + o);          o += align256((size_t)B * 12 * sizeof(float));
+    w.geo = (float4*)(p + o);       o += align256((size_t)B * F * 3 * sizeof(float4));
+    w.binmask = (uint64_t*)(p + o); o += align256(w.binmask_bytes);
+    w.softq = (float*)(p + o);      o += align256((size_t)B * H * W * sizeof(float));
+    w.dfxy = (float*)(p + o);       o += align256((size_t)B * F * 6 * sizeof(float));
+    w.dfn = (float*)(p + o);        o += align256((size_t)B * F * 3 * sizeof(float));
+    w.dTacc = (float*)(p + o);      o += align256((size_t)B * 12 * sizeof(float));
+    w.ticket = (unsigned*)(p + o);  o += align256((size_t)B * sizeof(unsigned));
+    w.acc_floats = (size_t)((p + o) - (char*)w.dfxy) / sizeof(float);
     w.bytes = o;
     return w;
 }

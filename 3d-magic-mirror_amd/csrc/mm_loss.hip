@@ -9,7 +9,7 @@
 
 namespace mm {
 
-#define MM_LOSS_CHUNKS 32
+#define MM_LOSS_CHUNKS 8
 
 struct LossArgs {
     int B, H, W;
@@ -67,24 +67,23 @@ __global__ __launch_bounds__(256) void recon_partial_kernel(LossArgs a) {
     if (tid < 4) a.partial[((size_t)b * MM_LOSS_CHUNKS + chunk) * 4 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
 }
 
-__global__ __launch_bounds__(256) void recon_final_kernel(LossArgs a) {
-    const int tid = threadIdx.x;
-    for (int b = tid; b < a.B; b += 256) {
+__global__ __launch_bounds__(64) void recon_final_kernel(LossArgs a) {
+    const int lane = threadIdx.x;
+    float l1 = 0.f, iou = 0.f, cs = 0.f;
+    for (int b = lane; b < a.B; b += 64) {
         float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int c = 0; c < MM_LOSS_CHUNKS; ++c)
 #pragma unroll
             for (int k = 0; k < 4; ++k) t[k] += a.partial[((size_t)b * MM_LOSS_CHUNKS + c) * 4 + k];
 #pragma unroll
         for (int k = 0; k < 4; ++k) a.totals[b * 4 + k] = t[k];
+        l1 += t[0];
+        iou += t[1] / (t[2] + 1e-10f);
+        cs += t[3];
     }
-    __syncthreads();
-    if (tid == 0) {
-        float l1 = 0.f, iou = 0.f, cs = 0.f;
-        for (int b = 0; b < a.B; ++b) {
-            l1 += a.totals[b * 4 + 0];
-            iou += a.totals[b * 4 + 1] / (a.totals[b * 4 + 2] + 1e-10f);
-            cs += a.totals[b * 4 + 3];
-        }
+    l1 = wave_sum(l1); iou = wave_sum(iou); cs = wave_sum(cs);
+    if (lane == 0) {
         const float cnt = (float)a.B * 3.f * (float)a.H * (float)a.W;
         float loss_mask = 1.f - iou / (float)a.B;
         if (a.contour > 0.f) loss_mask += (cs / ((float)a.B * (float)a.H * (float)a.W)) * a.contour;
@@ -156,7 +155,7 @@ int launch_recon_fwd(const MMReconDesc* d, hipStream_t s) {
     { ProfScope p(d->prof_events, MM_PROF_RECON_PARTIAL, s);
       hipLaunchKernelGGL(recon_partial_kernel, dim3(MM_LOSS_CHUNKS, d->B), dim3(256), 0, s, a); }
     { ProfScope p(d->prof_events, MM_PROF_RECON_FINAL, s);
-      hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(256), 0, s, a); }
+      hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(64), 0, s, a); }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 

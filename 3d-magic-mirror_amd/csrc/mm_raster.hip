@@ -7,27 +7,32 @@
 //   texture_mapping / grid_sample, spherical_harmonic_lighting, composite, clamp, cat
 // and their backward kernels (K2, K4, grid_sampler backward, SH backward).
 //
-// Design (not kaolin's pixel-major brute force):  one wave owns an 8x8 pixel tile, one lane per pixel.  The wave
-// streams the image's face bounding boxes 64 at a time (one coalesced float4 per lane), tests box-vs-tile,
-// compacts the survivors IN FACE ORDER with ballot + popcount-prefix into its LDS slot array, and only then do the
-// lanes run the per-pixel edge functions against the short list.  Face order is preserved end to end, which is
-// what kaolin's tie rule (lowest index wins) and the soft mask's "first knum faces" rule need.  A 256-thread
-// workgroup is four such waves side by side (a 32x8 strip: 128-byte output rows).
+// Design (not kaolin's pixel-major brute force over all faces):
+//   * a wave owns an 8x8 pixel tile, one lane per pixel; a 256-thread workgroup is 2x2 such tiles (16x16 px).
+//   * the vertex stage left, per screen bin, a bit-per-face mask of the faces whose (inflated) box may touch it.
+//     The wave loads its bin's mask words coalesced, turns the set bits into an ORDERED candidate list with
+//     popcount + wave prefix sum (face order = bit order, which kaolin's lowest-index tie rule and the soft mask's
+//     "first knum faces" rule need), and stages 64 candidates at a time in LDS (struct-of-arrays float4 rows).
+//   * phase A: every lane tests its pixel against the 64 staged boxes (broadcast LDS reads) and keeps a private
+//     64-bit hit mask.  phase B: every lane walks ONLY ITS OWN hits (ctz loop, per-lane LDS gathers) through the
+//     edge functions / segment distances.  The serial depth of a wave is therefore max-over-lanes of its own hit
+//     count (<= knum for the soft mask), not the number of faces that touch the tile.
 #include "mm_device.h"
 
 namespace mm {
 
 struct RasterArgs {
-    int B, H, W, F, Ht, Wt, knum, tiles_x, tiles_per_image;
+    int B, H, W, F, Ht, Wt, knum, blocks_x, blocks_per_image;
+    int bin_shift, nbx, nby, words;
     float mult, eps, sigmainv, infl;        // infl = boxlen * multiplier
-    const float4* bbox;
     const float4* geo;
-    const uint64_t* valid;
+    const uint64_t* binmask;
     const float* face_uvs;
     const float* fn;                        // (B,F,3) unit normals
     const float* textures;
     const float* lights;
     const float* bg;
+    float* softq;
     // forward outputs
     float* rgba;
     int32_t* face_idx;
@@ -41,90 +46,151 @@ struct RasterArgs {
     float* dfn;
 };
 
-// One staged face: everything a lane needs for the hard test and the soft distance (64 bytes, read as broadcasts).
-struct __attribute__((aligned(16))) Slot { float4 bb, p0, p1, p2; };   // p2 = {cz, nz, fidx(bits), 0}
+// per-wave LDS staging: 64 candidates as four float4 rows + the id list of one mask group
+struct __attribute__((aligned(16))) WaveStage {
+    float4 bb[64];      // xmin, ymin, xmax, ymax (multiplier units)
+    float4 p0[64];      // ax, ay, bx, by
+    float4 p1[64];      // cx, cy, az, bz
+    float4 p2[64];      // cz, unit normal z, face id (bits), 0
+    unsigned short ids[MM_GROUP_WORDS * 64];
+};
 
 struct TileCtx {
     int b, px, py, lane, wave;
     bool in_img;
     float x0, y0;
-    float txlo, txhi, tylo, tyhi;           // pixel-centre extent of this wave's tile (multiplier units)
+    const uint64_t* mask;                   // this wave's bin row: `words` 64-bit words
 };
 
 __device__ inline TileCtx make_tile(const RasterArgs& a) {
     TileCtx t;
-    int tile;
-    map_block(blockIdx.x, a.B, a.tiles_per_image, t.b, tile);
+    int blk;
+    map_block(blockIdx.x, a.B, a.blocks_per_image, t.b, blk);
     t.lane = threadIdx.x & 63; t.wave = threadIdx.x >> 6;
-    const int bx = tile % a.tiles_x, by = tile / a.tiles_x;
-    const int tx0 = bx * (MM_TILE_W * MM_BLOCK_WAVES) + t.wave * MM_TILE_W, ty0 = by * MM_TILE_H;
+    const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
+    const int tx0 = bx * MM_BLOCK_PX + (t.wave & 1) * MM_TILE, ty0 = by * MM_BLOCK_PX + (t.wave >> 1) * MM_TILE;
     t.px = tx0 + (t.lane & 7); t.py = ty0 + (t.lane >> 3);
     t.in_img = t.px < a.W && t.py < a.H;
     t.x0 = pixel_x(t.px, a.W, a.mult); t.y0 = pixel_y(t.py, a.H, a.mult);
-    // the same monotone formula bounds every pixel centre of the tile, so box-vs-tile rejection is exactly conservative
-    t.txlo = pixel_x(tx0, a.W, a.mult); t.txhi = pixel_x(tx0 + MM_TILE_W - 1, a.W, a.mult);
-    t.tyhi = pixel_y(ty0, a.H, a.mult); t.tylo = pixel_y(ty0 + MM_TILE_H - 1, a.H, a.mult);
+    // tiles never straddle bins (bin edge is 8, 16 or 32); a tile fully outside the image borrows the last bin
+    const int binx = min(tx0 >> a.bin_shift, a.nbx - 1), biny = min(ty0 >> a.bin_shift, a.nby - 1);
+    t.mask = a.binmask + ((size_t)t.b * a.nbx * a.nby + (size_t)biny * a.nbx + binx) * a.words;
     return t;
 }
 
-// Stream the face boxes of image b through the wave.  Survivors of chunk [base, base+64) are written, in face order,
-// to slots[0..n) and `body(n)` is invoked (wave-uniform).  kSoft selects the inflated, un-culled candidate set.
-template <bool kSoft, class Body>
-__device__ inline void scan_faces(const RasterArgs& a, const TileCtx& t, Slot* slots, Body&& body) {
-    const float4* bbox = a.bbox + (size_t)t.b * a.F;
+__device__ inline int wave_prefix_excl(int v, int lane, int& total) {
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+
+__device__ inline void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Walk the bin's candidates in face order, 64 at a time.  body(n) sees them staged in st->bb/p0/p1/p2[0..n) and returns
+// false to stop early (wave-uniform).
+template <class Body>
+__device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, Body&& body) {
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
-    const uint64_t* valid = a.valid + (size_t)t.b * ((a.F + 63) / 64);
-    const float pad = kSoft ? a.infl : 0.f;
-    for (int base = 0; base < a.F; base += 64) {
-        const int f = base + t.lane;
-        bool hit = false;
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < a.F) {
-            bb = bbox[f];
-            hit = !((bb.z + pad) < t.txlo || (bb.x - pad) > t.txhi || (bb.w + pad) < t.tylo || (bb.y - pad) > t.tyhi);
+    for (int wbase = 0; wbase < a.words; wbase += MM_GROUP_WORDS) {
+        uint64_t w = 0;
+        if (t.lane < MM_GROUP_WORDS && wbase + t.lane < a.words) w = t.mask[wbase + t.lane];
+        int total;
+        int pos = wave_prefix_excl(__popcll(w), t.lane, total);
+        if (total == 0) continue;
+        while (w) {                                              // <= MM_GROUP_WORDS lanes, <= 64 iterations
+            const int bit = __ffsll((unsigned long long)w) - 1;
+            w &= w - 1;
+            st->ids[pos++] = (unsigned short)(t.lane * 64 + bit);
         }
-        uint64_t m = __ballot(hit);
-        if (!kSoft) m &= valid[base >> 6];                       // back-face cull applies to colour only (a8)
-        if (m == 0) continue;
-        const bool keep = (m >> t.lane) & 1ull;
-        if (keep) {
-            const int pos = __popcll(m & ((1ull << t.lane) - 1ull));
-            const float4 g0 = geo[(size_t)f * 3 + 0], g1 = geo[(size_t)f * 3 + 1], g2 = geo[(size_t)f * 3 + 2];
-            Slot s;
-            s.bb = bb; s.p0 = g0; s.p1 = g1; s.p2 = make_float4(g2.x, g2.y, __int_as_float(f), 0.f);
-            slots[pos] = s;
+        wave_lds_sync();
+        for (int k0 = 0; k0 < total; k0 += 64) {
+            const int n = min(64, total - k0);
+            if (t.lane < n) {
+                const int f = wbase * 64 + st->ids[k0 + t.lane];
+                const float4 g0 = geo[(size_t)f * 3 + 0], g1 = geo[(size_t)f * 3 + 1], g2 = geo[(size_t)f * 3 + 2];
+                st->bb[t.lane] = make_float4(fminf(fminf(g0.x, g0.z), g1.x), fminf(fminf(g0.y, g0.w), g1.y),
+                                             fmaxf(fmaxf(g0.x, g0.z), g1.x), fmaxf(fmaxf(g0.y, g0.w), g1.y));
+                st->p0[t.lane] = g0; st->p1[t.lane] = g1;
+                st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), 0.f);
+            }
+            wave_lds_sync();
+            const bool go = body(n);
+            wave_lds_sync();
+            if (!go) return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (!body(__popcll(m))) return;
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
 struct Hit { float best; int f; float w0, w1, w2; };
 
-// K1 per pixel: faces arrive in index order; strict z > best keeps the lowest index on ties.
-__device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, Slot* slots, Hit& h) {
-    scan_faces<false>(a, t, slots, [&](int n) {
-        for (int j = 0; j < n; ++j) {
-            const float4 bb = slots[j].bb;
-            if (t.x0 < bb.x || t.x0 > bb.z || t.y0 < bb.y || t.y0 > bb.w) continue;
-            const float4 p0 = slots[j].p0, p1 = slots[j].p1, p2 = slots[j].p2;
-            float w0, w1, w2, nrm;
-            edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, t.x0, t.y0, a.eps, w0, w1, w2, nrm);
-            // cheap exact pre-reject: w/nrm < 0 whenever w and nrm have opposite signs and the quotient cannot
-            // underflow to -0; everything else takes the IEEE divisions the oracle takes.
-            const float sg = nrm < 0.f ? -1.f : 1.f;
-            if (fabsf(nrm) < 1e10f && fminf(fminf(w0 * sg, w1 * sg), w2 * sg) < -1e-30f) continue;
-            w0 /= nrm; w1 /= nrm; w2 /= nrm;
-            if (w0 < 0.f || w1 < 0.f || w2 < 0.f) continue;
-            const float z0 = (w0 * p1.z + w1 * p1.w) + w2 * p2.x;
-            if (!(z0 > h.best)) continue;
-            h.best = z0; h.f = __float_as_int(p2.z); h.w0 = w0; h.w1 = w1; h.w2 = w2;
+// K1: faces arrive in index order (batches ascending, bits ascending); strict z > best keeps the lowest index on ties.
+__device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h) {
+    for_each_batch(a, t, st, [&](int n) {
+        uint64_t hm = 0;
+        for (int j = 0; j < n; ++j) {                            // phase A: exact box test, front faces only (a8)
+            const float4 bb = st->bb[j];
+            const float nzj = st->p2[j].y;
+            const bool in = nzj >= 0.f && !(t.x0 < bb.x || t.x0 > bb.z || t.y0 < bb.y || t.y0 > bb.w);
+            hm |= (uint64_t)in << j;
+        }
+        while (__ballot(hm != 0)) {                              // phase B: lane-private walk
+            if (hm) {
+                const int j = __ffsll((unsigned long long)hm) - 1;
+                hm &= hm - 1;
+                const float4 p0 = st->p0[j], p1 = st->p1[j], p2 = st->p2[j];
+                float w0, w1, w2, nrm;
+                edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, t.x0, t.y0, a.eps, w0, w1, w2, nrm);
+                // exact pre-reject: w/nrm < 0 whenever w and nrm have opposite signs and the quotient cannot underflow
+                // to -0; everything else takes the IEEE divisions the oracle takes.
+                const float sg = nrm < 0.f ? -1.f : 1.f;
+                const bool out = fabsf(nrm) < 1e10f && fminf(fminf(w0 * sg, w1 * sg), w2 * sg) < -1e-30f;
+                if (!out) {
+                    w0 /= nrm; w1 /= nrm; w2 /= nrm;
+                    if (!(w0 < 0.f || w1 < 0.f || w2 < 0.f)) {
+                        const float z0 = (w0 * p1.z + w1 * p1.w) + w2 * p2.x;
+                        if (z0 > h.best) { h.best = z0; h.f = __float_as_int(p2.z); h.w0 = w0; h.w1 = w1; h.w2 = w2; }
+                    }
+                }
+            }
         }
         return true;
     });
+}
+
+// closest of the three edge segments: squared distance (multiplier units) and type = edge*3 + region
+__device__ inline float tri_dist2(float x0, float y0, const float4& p0, const float4& p1, int& ty) {
+    int r;
+    float d = seg_dist2(x0, y0, p0.x, p0.y, p0.z, p0.w, ty);
+    const float d1 = seg_dist2(x0, y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
+    const float d2 = seg_dist2(x0, y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
+    return d;
+}
+
+// soft-mask candidate mask of this lane for the staged batch: inflated box contains the pixel, all faces, in order;
+// truncated so that the lane never takes more than `room` further faces.
+__device__ inline uint64_t soft_hits(const RasterArgs& a, const TileCtx& t, const WaveStage* st, int n, bool open, int room) {
+    uint64_t sm = 0;
+    for (int j = 0; j < n; ++j) {
+        const float4 bb = st->bb[j];
+        const bool in = !(t.x0 < bb.x - a.infl || t.x0 > bb.z + a.infl || t.y0 < bb.y - a.infl || t.y0 > bb.w + a.infl);
+        sm |= (uint64_t)in << j;
+    }
+    if (!open || room <= 0) return 0;
+    if (__popcll(sm) > room) {                                   // keep the first `room` set bits (rare)
+        uint64_t kept = 0;
+        for (int i = 0; i < room; ++i) { const uint64_t low = sm & (~sm + 1); kept |= low; sm ^= low; }
+        sm = kept;
+    }
+    return sm;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -132,33 +198,32 @@ __device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, Slot
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool kNoMask>
 __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
-    __shared__ Slot s_slots[MM_BLOCK_WAVES][64];
+    __shared__ WaveStage s_stage[MM_BLOCK_WAVES];
     const TileCtx t = make_tile(a);
-    Slot* slots = s_slots[t.wave];
+    WaveStage* st = &s_stage[t.wave];
 
     Hit h; h.best = -INFINITY; h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
-    raster_pixels(a, t, slots, h);
+    raster_pixels(a, t, st, h);
 
-    // K3: soft silhouette for the lanes no front face covers
-    float keepprod = 1.f;
+    // K3: soft silhouette for the lanes no front face covers.  State = product of the non-zero (1-p) and #zero factors.
+    float qnz = 1.f;
+    int zeros = 0;
     const bool open = t.in_img && h.f < 0;
     if (__ballot(open)) {
         int cnt = 0;
         const float s2 = a.mult * a.mult;
-        scan_faces<true>(a, t, slots, [&](int n) {
-            for (int j = 0; j < n; ++j) {
-                const float4 bb = slots[j].bb;
-                const bool in = open && cnt < a.knum &&
-                                !(t.x0 < bb.x - a.infl || t.x0 > bb.z + a.infl || t.y0 < bb.y - a.infl || t.y0 > bb.w + a.infl);
-                if (!in) continue;
-                const float4 p0 = slots[j].p0, p1 = slots[j].p1;
-                int r;
-                float d = seg_dist2(t.x0, t.y0, p0.x, p0.y, p0.z, p0.w, r);
-                const float d1 = seg_dist2(t.x0, t.y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) d = d1;
-                const float d2 = seg_dist2(t.x0, t.y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) d = d2;
-                const float p = expf(-((d / s2) * a.sigmainv));
-                keepprod = keepprod * (1.f - p);
-                ++cnt;
+        for_each_batch(a, t, st, [&](int n) {
+            uint64_t sm = soft_hits(a, t, st, n, open, a.knum - cnt);
+            cnt += __popcll(sm);
+            while (__ballot(sm != 0)) {
+                if (sm) {
+                    const int j = __ffsll((unsigned long long)sm) - 1;
+                    sm &= sm - 1;
+                    int ty;
+                    const float d = tri_dist2(t.x0, t.y0, st->p0[j], st->p1[j], ty);
+                    const float q = 1.f - expf(-((d / s2) * a.sigmainv));
+                    if (q == 0.f) ++zeros; else qnz = qnz * q;
+                }
             }
             return __ballot(open && cnt < a.knum) != 0;          // every open lane already holds knum faces: stop
         });
@@ -207,9 +272,11 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
         }
         out[c] = val < 0.f ? 0.f : (val > 1.f ? 1.f : val);
     }
+    const float keepprod = zeros > 0 ? 0.f : qnz;
     out[3] = (h.f >= 0) ? 1.f : (1.f - keepprod);
     *(float4*)(a.rgba + pix * 4) = make_float4(out[0], out[1], out[2], out[3]);
     a.face_idx[pix] = h.f;
+    a.softq[pix] = (h.f >= 0 || zeros >= 2) ? 0.f : (zeros == 1 ? -qnz : qnz);
     if (a.imnormal) { a.imnormal[pix * 3] = nx; a.imnormal[pix * 3 + 1] = ny; a.imnormal[pix * 3 + 2] = nz; }
 }
 
@@ -218,10 +285,10 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool kNoMask>
 __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterArgs a) {
-    __shared__ Slot s_slots[MM_BLOCK_WAVES][64];
+    __shared__ WaveStage s_stage[MM_BLOCK_WAVES];
     __shared__ float s_dl[MM_BLOCK_WAVES][9];
     const TileCtx t = make_tile(a);
-    Slot* slots = s_slots[t.wave];
+    WaveStage* st = &s_stage[t.wave];
     const size_t hw = (size_t)a.H * a.W, pin = (size_t)t.py * a.W + t.px;
     const size_t pix = (size_t)t.b * hw + pin;
 
@@ -234,7 +301,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterArgs a) {
     for (int i = 0; i < 9; ++i) dl[i] = 0.f;
 
     if (t.in_img && (hf >= 0 || kNoMask)) {
-        // recompute the forward quantities of this pixel (nothing but face_idx was saved)
+        // recompute the forward quantities of this pixel (only face_idx and the soft-mask state were saved)
         float w0 = 0.f, w1 = 0.f, w2 = 0.f, nrm = 1.f, m = 0.f, u = 0.f, v = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
         float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
         float fu[6] = {0, 0, 0, 0, 0, 0}, n0 = 0.f, n1 = 0.f, n2 = 0.f;
@@ -351,86 +418,73 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterArgs a) {
         if (sum != 0.f) atomicAdd(a.grad_lights + t.b * 9 + threadIdx.x, sum);
     }
 
-    // K4 (Appendix A.2): soft-mask gradient of the uncovered lanes.  Two passes over the same ordered candidate walk
-    // as the forward: pass 1 rebuilds prod(1-p) (split into non-zero factors and a zero count), pass 2 scatters.
-    const bool open = t.in_img && hf < 0 && g4.w != 0.f;
+    // K4 (Appendix A.2): soft-mask gradient of the uncovered lanes; same ordered candidate walk as the forward, the
+    // product state of the forward (softq) gives every exclusive product prod_{j != k}(1 - p_j) without a second pass.
+    float sq = 0.f;
+    if (t.in_img && hf < 0 && g4.w != 0.f) sq = a.softq[pix];
+    const bool open = sq != 0.f && sq != 1.f;     // 1: no face in reach (every factor exactly 1) -> no gradient
     if (__ballot(open) == 0) return;
     const float s2 = a.mult * a.mult;
-    float qnz = 1.f;
-    int zeros = 0, cnt = 0;
-    auto candidate = [&](const Slot& sl, int c, float& p, int& ty) -> bool {
-        const float4 bb = sl.bb;
-        if (!(open && c < a.knum) || t.x0 < bb.x - a.infl || t.x0 > bb.z + a.infl || t.y0 < bb.y - a.infl || t.y0 > bb.w + a.infl) return false;
-        const float4 q0 = sl.p0, q1 = sl.p1;
-        int r, reg;
-        float d = seg_dist2(t.x0, t.y0, q0.x, q0.y, q0.z, q0.w, reg); ty = reg;
-        const float d1 = seg_dist2(t.x0, t.y0, q0.z, q0.w, q1.x, q1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
-        const float d2 = seg_dist2(t.x0, t.y0, q1.x, q1.y, q0.x, q0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
-        p = expf(-((d / s2) * a.sigmainv));
-        return true;
-    };
-    scan_faces<true>(a, t, slots, [&](int n) {
-        for (int j = 0; j < n; ++j) {
-            float p; int ty;
-            if (!candidate(slots[j], cnt, p, ty)) continue;
-            const float q = 1.f - p;
-            if (q == 0.f) ++zeros; else qnz = qnz * q;
-            ++cnt;
-        }
-        return __ballot(open && cnt < a.knum) != 0;
-    });
-    cnt = 0;
-    scan_faces<true>(a, t, slots, [&](int n) {
-        for (int j = 0; j < n; ++j) {
-            float p; int ty;
-            if (!candidate(slots[j], cnt, p, ty)) continue;
-            ++cnt;
-            const float q = 1.f - p;
-            const float excl = (q != 0.f) ? (zeros == 0 ? qnz / q : 0.f) : (zeros == 1 ? qnz : 0.f);
-            const float gd = g4.w * excl * (-(p * a.sigmainv) / s2);
-            if (gd == 0.f) continue;
-            const int e = ty / 3, reg = ty - e * 3;
-            const float4 q0 = slots[j].p0, q1 = slots[j].p1;
-            const float vx[3] = {q0.x, q0.z, q1.x}, vy[3] = {q0.y, q0.w, q1.y};
-            const int iu = e, iv = (e == 2) ? 0 : e + 1;
-            const float ux = vx[iu], uy = vy[iu], wx = vx[iv], wy = vy[iv];
-            float dux = 0.f, duy = 0.f, dvx = 0.f, dvy = 0.f;
-            if (reg == 0) { dux = -2.f * (t.x0 - ux); duy = -2.f * (t.y0 - uy); }
-            else if (reg == 2) { dvx = -2.f * (t.x0 - wx); dvy = -2.f * (t.y0 - wy); }
-            else {
-                const float ex = wx - ux, ey = wy - uy, rx = t.x0 - ux, ry = t.y0 - uy;
-                const float tt = (rx * ex + ry * ey) / (ex * ex + ey * ey);
-                const float qx = t.x0 - (ux + tt * ex), qy = t.y0 - (uy + tt * ey);
-                dux = -2.f * (1.f - tt) * qx; duy = -2.f * (1.f - tt) * qy;
-                dvx = -2.f * tt * qx; dvy = -2.f * tt * qy;
+    const float qnz = fabsf(sq);
+    const bool onezero = sq < 0.f;
+    int cnt = 0;
+    for_each_batch(a, t, st, [&](int n) {
+        uint64_t sm = soft_hits(a, t, st, n, open, a.knum - cnt);
+        cnt += __popcll(sm);
+        while (__ballot(sm != 0)) {
+            if (sm) {
+                const int j = __ffsll((unsigned long long)sm) - 1;
+                sm &= sm - 1;
+                const float4 q0 = st->p0[j], q1 = st->p1[j];
+                int ty;
+                const float d = tri_dist2(t.x0, t.y0, q0, q1, ty);
+                const float p = expf(-((d / s2) * a.sigmainv));
+                const float q = 1.f - p;
+                const float excl = (q != 0.f) ? (onezero ? 0.f : qnz / q) : (onezero ? qnz : 0.f);
+                const float gd = g4.w * excl * (-(p * a.sigmainv) / s2);
+                if (gd != 0.f) {
+                    const int e = ty / 3, reg = ty - e * 3;
+                    const int iu = e, iv = (e == 2) ? 0 : e + 1;
+                    const float ux = iu == 0 ? q0.x : (iu == 1 ? q0.z : q1.x), uy = iu == 0 ? q0.y : (iu == 1 ? q0.w : q1.y);
+                    const float wx = iv == 0 ? q0.x : (iv == 1 ? q0.z : q1.x), wy = iv == 0 ? q0.y : (iv == 1 ? q0.w : q1.y);
+                    float dux = 0.f, duy = 0.f, dvx = 0.f, dvy = 0.f;
+                    if (reg == 0) { dux = -2.f * (t.x0 - ux); duy = -2.f * (t.y0 - uy); }
+                    else if (reg == 2) { dvx = -2.f * (t.x0 - wx); dvy = -2.f * (t.y0 - wy); }
+                    else {
+                        const float ex = wx - ux, ey = wy - uy, rx = t.x0 - ux, ry = t.y0 - uy;
+                        const float tt = (rx * ex + ry * ey) / (ex * ex + ey * ey);
+                        const float qx = t.x0 - (ux + tt * ex), qy = t.y0 - (uy + tt * ey);
+                        dux = -2.f * (1.f - tt) * qx; duy = -2.f * (1.f - tt) * qy;
+                        dvx = -2.f * tt * qx; dvy = -2.f * tt * qy;
+                    }
+                    const int f = __float_as_int(st->p2[j].z);
+                    float* dq = a.dfxy + ((size_t)t.b * a.F + f) * 6;
+                    atomicAdd(dq + iu * 2, gd * dux * a.mult); atomicAdd(dq + iu * 2 + 1, gd * duy * a.mult);
+                    atomicAdd(dq + iv * 2, gd * dvx * a.mult); atomicAdd(dq + iv * 2 + 1, gd * dvy * a.mult);
+                }
             }
-            const int f = __float_as_int(slots[j].p2.z);
-            float* dq = a.dfxy + ((size_t)t.b * a.F + f) * 6;
-            atomicAdd(dq + iu * 2, gd * dux * a.mult); atomicAdd(dq + iu * 2 + 1, gd * duy * a.mult);
-            atomicAdd(dq + iv * 2, gd * dvx * a.mult); atomicAdd(dq + iv * 2 + 1, gd * dvy * a.mult);
         }
         return __ballot(open && cnt < a.knum) != 0;
     });
 }
 
-// Zero-fill of everything the backward accumulates into, in one launch (float4 grid-stride over three ranges).
-__global__ __launch_bounds__(256) void zero3_kernel(float4* p0, size_t n0, float4* p1, size_t n1, float4* p2, size_t n2,
-                                                    float* tail, size_t ntail) {
+// Zero-fill of everything the backward accumulates into, in one launch (float4 grid-stride over two ranges + a tail).
+__global__ __launch_bounds__(256) void zero_kernel(float4* p0, size_t n0, float4* p1, size_t n1, float* tail, size_t ntail) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += stride) p0[i] = z;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) p1[i] = z;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) p2[i] = z;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntail; i += stride) tail[i] = 0.f;
 }
 
 static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
     RasterArgs a;
     a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.Ht = d->Ht; a.Wt = d->Wt; a.knum = d->knum;
-    a.tiles_x = (d->W + MM_TILE_W * MM_BLOCK_WAVES - 1) / (MM_TILE_W * MM_BLOCK_WAVES);
-    a.tiles_per_image = a.tiles_x * ((d->H + MM_TILE_H - 1) / MM_TILE_H);
+    a.blocks_x = (d->W + MM_BLOCK_PX - 1) / MM_BLOCK_PX;
+    a.blocks_per_image = a.blocks_x * ((d->H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
+    a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
-    a.bbox = w.bbox; a.geo = w.geo; a.valid = w.valid;
+    a.geo = w.geo; a.binmask = w.binmask; a.softq = w.softq;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     a.grad_rgba = nullptr; a.grad_textures = nullptr; a.grad_lights = nullptr; a.grad_bg = nullptr;
@@ -440,7 +494,7 @@ static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
 
 int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     RasterArgs a = make_args(d, w);
-    dim3 grid(a.tiles_per_image * d->B);
+    dim3 grid(a.blocks_per_image * d->B);
     ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
     if (d->no_mask) hipLaunchKernelGGL(raster_fwd_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(raster_fwd_kernel<false>, grid, dim3(256), 0, s, a);
@@ -450,24 +504,22 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
 int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
     RasterArgs a = make_args(d, w);
     a.grad_rgba = g->grad_rgba; a.grad_textures = g->grad_textures; a.grad_lights = g->grad_lights; a.grad_bg = g->grad_bg;
-    // zero: grad_textures | dfxy+dfn (contiguous in the workspace up to alignment padding) | grad_lights
+    // zero: grad_textures | the workspace accumulators (adjacent, padding included) | grad_lights
     const size_t ntex = (size_t)d->B * 3 * d->Ht * d->Wt;
-    const size_t nacc = ((char*)w.dfn - (char*)w.dfxy) / sizeof(float) + (size_t)d->B * d->F * 3;
+    const size_t nacc = w.acc_floats;                        // dfxy | dfn | dTacc | ticket
     const size_t nl = (size_t)d->B * 9;
     {
-    ProfScope pz(d->prof_events, MM_PROF_ZERO, s);
-    if ((ntex % 4) != 0 || ((uintptr_t)g->grad_textures % 16) != 0) {
-        if (hipMemsetAsync(g->grad_textures, 0, ntex * sizeof(float), s) != hipSuccess) return MM_ERR_LAUNCH;
-        hipLaunchKernelGGL(zero3_kernel, dim3(256), dim3(256), 0, s, (float4*)w.dfxy, (nacc + 3) / 4, (float4*)nullptr, (size_t)0,
-                           (float4*)nullptr, (size_t)0, g->grad_lights, nl);
-    } else {
-        const int blocks = (int)((ntex / 4 + 255) / 256 < 2048 ? (ntex / 4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(zero3_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, (float4*)g->grad_textures, ntex / 4,
-                           (float4*)w.dfxy, (nacc + 3) / 4, (float4*)nullptr, (size_t)0, g->grad_lights, nl);
-    }
+        ProfScope pz(d->prof_events, MM_PROF_ZERO, s);
+        const bool vec = (ntex % 4) == 0 && ((uintptr_t)g->grad_textures % 16) == 0;
+        if (!vec && hipMemsetAsync(g->grad_textures, 0, ntex * sizeof(float), s) != hipSuccess) return MM_ERR_LAUNCH;
+        const size_t n0 = vec ? ntex / 4 : 0;
+        size_t blocks = (n0 + (nacc + 3) / 4 + 255) / 256;
+        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (float4*)g->grad_textures, n0, (float4*)w.dfxy,
+                           (nacc + 3) / 4, g->grad_lights, nl);
     }
     if (hipGetLastError() != hipSuccess) return MM_ERR_LAUNCH;
-    dim3 grid(a.tiles_per_image * d->B);
+    dim3 grid(a.blocks_per_image * d->B);
     ProfScope pb(d->prof_events, MM_PROF_RASTER_BWD, s);
     if (d->no_mask) hipLaunchKernelGGL(raster_bwd_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(raster_bwd_kernel<false>, grid, dim3(256), 0, s, a);

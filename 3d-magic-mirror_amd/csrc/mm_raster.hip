@@ -46,10 +46,9 @@ struct RasterArgs {
     float* dfn;
 };
 
-// per-wave LDS staging: 64 candidates as four float4 rows + the id list of one mask group
+// per-wave LDS staging: 64 candidates as three float4 rows + the id list of one mask group
 struct __attribute__((aligned(16))) WaveStage {
-    float4 bb[64];      // xmin, ymin, xmax, ymax (multiplier units)
-    float4 p0[64];      // ax, ay, bx, by
+    float4 p0[64];      // ax, ay, bx, by   (multiplier units)
     float4 p1[64];      // cx, cy, az, bz
     float4 p2[64];      // cz, unit normal z, face id (bits), 0
     unsigned short ids[MM_GROUP_WORDS * 64];
@@ -59,6 +58,7 @@ struct TileCtx {
     int b, px, py, lane, wave;
     bool in_img;
     float x0, y0;
+    float xs[MM_TILE], ys[MM_TILE];         // pixel-centre columns / rows of the tile (same in every lane)
     const uint64_t* mask;                   // this wave's bin row: `words` 64-bit words
 };
 
@@ -72,6 +72,8 @@ __device__ inline TileCtx make_tile(const RasterArgs& a) {
     t.px = tx0 + (t.lane & 7); t.py = ty0 + (t.lane >> 3);
     t.in_img = t.px < a.W && t.py < a.H;
     t.x0 = pixel_x(t.px, a.W, a.mult); t.y0 = pixel_y(t.py, a.H, a.mult);
+#pragma unroll
+    for (int i = 0; i < MM_TILE; ++i) { t.xs[i] = pixel_x(tx0 + i, a.W, a.mult); t.ys[i] = pixel_y(ty0 + i, a.H, a.mult); }
     // tiles never straddle bins (bin edge is 8, 16 or 32); a tile fully outside the image borrows the last bin
     const int binx = min(tx0 >> a.bin_shift, a.nbx - 1), biny = min(ty0 >> a.bin_shift, a.nby - 1);
     t.mask = a.binmask + ((size_t)t.b * a.nbx * a.nby + (size_t)biny * a.nbx + binx) * a.words;
@@ -95,9 +97,49 @@ __device__ inline void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Walk the bin's candidates in face order, 64 at a time.  body(n) sees them staged in st->bb/p0/p1/p2[0..n) and returns
-// false to stop early (wave-uniform).
-template <class Body>
+// 64x64 bit-matrix transpose across the wave: lane i holds row i on entry and column i on exit (6 butterfly stages).
+template <int S>
+__device__ inline uint64_t transpose_stage(uint64_t x, int lane) {
+    // m: bit positions whose index has bit S clear
+    constexpr uint64_t m = S == 32 ? 0x00000000FFFFFFFFull : S == 16 ? 0x0000FFFF0000FFFFull : S == 8 ? 0x00FF00FF00FF00FFull
+                         : S == 4 ? 0x0F0F0F0F0F0F0F0Full : S == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+    const unsigned lo = __shfl_xor((unsigned)x, S, 64), hi = __shfl_xor((unsigned)(x >> 32), S, 64);
+    const uint64_t y = ((uint64_t)hi << 32) | lo;
+    return (lane & S) ? (((y >> S) & m) | (x & ~m)) : ((x & m) | ((y & m) << S));
+}
+
+__device__ inline uint64_t wave_transpose64(uint64_t x, int lane) {
+    x = transpose_stage<32>(x, lane);
+    x = transpose_stage<16>(x, lane);
+    x = transpose_stage<8>(x, lane);
+    x = transpose_stage<4>(x, lane);
+    x = transpose_stage<2>(x, lane);
+    x = transpose_stage<1>(x, lane);
+    return x;
+}
+
+// box-vs-tile for ONE candidate (this lane's): bit (r*8+c) set iff pixel (row r, column c) of the tile passes the
+// separable closed-box test  !(x < lo || x > hi)  -- the same comparisons on the same floats as the per-pixel test.
+__device__ inline uint64_t box_pixels(const TileCtx& t, float xlo, float ylo, float xhi, float yhi) {
+    unsigned col = 0, row = 0;
+#pragma unroll
+    for (int i = 0; i < MM_TILE; ++i) {
+        col |= (unsigned)(!(t.xs[i] < xlo || t.xs[i] > xhi)) << i;
+        row |= (unsigned)(!(t.ys[i] < ylo || t.ys[i] > yhi)) << i;
+    }
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        lo |= ((row >> r) & 1u) ? (col << (8 * r)) : 0u;
+        hi |= ((row >> (r + 4)) & 1u) ? (col << (8 * r)) : 0u;
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Walk the bin's candidates in face order, 64 at a time.  For every batch the candidates are staged in st->p0/p1/p2[0..n)
+// and body(n, hm, sm) receives this LANE's (= this pixel's) hit masks over the batch: hm = front faces whose box contains
+// the pixel (kHard), sm = all faces whose inflated box contains it (kSoft).  body returns false to stop (wave-uniform).
+template <bool kHard, bool kSoft, class Body>
 __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, Body&& body) {
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
     for (int wbase = 0; wbase < a.words; wbase += MM_GROUP_WORDS) {
@@ -114,16 +156,21 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
         wave_lds_sync();
         for (int k0 = 0; k0 < total; k0 += 64) {
             const int n = min(64, total - k0);
+            uint64_t hmc = 0, smc = 0;                           // candidate-major: lane j = candidate j, bit p = pixel p
             if (t.lane < n) {
                 const int f = wbase * 64 + st->ids[k0 + t.lane];
                 const float4 g0 = geo[(size_t)f * 3 + 0], g1 = geo[(size_t)f * 3 + 1], g2 = geo[(size_t)f * 3 + 2];
-                st->bb[t.lane] = make_float4(fminf(fminf(g0.x, g0.z), g1.x), fminf(fminf(g0.y, g0.w), g1.y),
-                                             fmaxf(fmaxf(g0.x, g0.z), g1.x), fmaxf(fmaxf(g0.y, g0.w), g1.y));
                 st->p0[t.lane] = g0; st->p1[t.lane] = g1;
                 st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), 0.f);
+                const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
+                const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
+                if (kHard && g2.y >= 0.f) hmc = box_pixels(t, xmin, ymin, xmax, ymax);          // front faces only (a8)
+                if (kSoft) smc = box_pixels(t, xmin - a.infl, ymin - a.infl, xmax + a.infl, ymax + a.infl);
             }
+            const uint64_t hm = kHard ? wave_transpose64(hmc, t.lane) : 0;
+            const uint64_t sm = kSoft ? wave_transpose64(smc, t.lane) : 0;
             wave_lds_sync();
-            const bool go = body(n);
+            const bool go = body(n, hm, sm);
             wave_lds_sync();
             if (!go) return;
         }
@@ -134,15 +181,8 @@ struct Hit { float best; int f; float w0, w1, w2; };
 
 // K1: faces arrive in index order (batches ascending, bits ascending); strict z > best keeps the lowest index on ties.
 __device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h) {
-    for_each_batch(a, t, st, [&](int n) {
-        uint64_t hm = 0;
-        for (int j = 0; j < n; ++j) {                            // phase A: exact box test, front faces only (a8)
-            const float4 bb = st->bb[j];
-            const float nzj = st->p2[j].y;
-            const bool in = nzj >= 0.f && !(t.x0 < bb.x || t.x0 > bb.z || t.y0 < bb.y || t.y0 > bb.w);
-            hm |= (uint64_t)in << j;
-        }
-        while (__ballot(hm != 0)) {                              // phase B: lane-private walk
+    for_each_batch<true, false>(a, t, st, [&](int n, uint64_t hm, uint64_t) {
+        while (__ballot(hm != 0)) {                              // lane-private walk over this pixel's own hits
             if (hm) {
                 const int j = __ffsll((unsigned long long)hm) - 1;
                 hm &= hm - 1;
@@ -175,15 +215,9 @@ __device__ inline float tri_dist2(float x0, float y0, const float4& p0, const fl
     return d;
 }
 
-// soft-mask candidate mask of this lane for the staged batch: inflated box contains the pixel, all faces, in order;
-// truncated so that the lane never takes more than `room` further faces.
-__device__ inline uint64_t soft_hits(const RasterArgs& a, const TileCtx& t, const WaveStage* st, int n, bool open, int room) {
-    uint64_t sm = 0;
-    for (int j = 0; j < n; ++j) {
-        const float4 bb = st->bb[j];
-        const bool in = !(t.x0 < bb.x - a.infl || t.x0 > bb.z + a.infl || t.y0 < bb.y - a.infl || t.y0 > bb.w + a.infl);
-        sm |= (uint64_t)in << j;
-    }
+// soft-mask candidates of this lane in the staged batch: its inflated-box hits, in order, truncated so that the lane
+// never takes more than `room` further faces (kaolin keeps the first knum).
+__device__ inline uint64_t soft_take(uint64_t sm, bool open, int room) {
     if (!open || room <= 0) return 0;
     if (__popcll(sm) > room) {                                   // keep the first `room` set bits (rare)
         uint64_t kept = 0;
@@ -212,8 +246,8 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
     if (__ballot(open)) {
         int cnt = 0;
         const float s2 = a.mult * a.mult;
-        for_each_batch(a, t, st, [&](int n) {
-            uint64_t sm = soft_hits(a, t, st, n, open, a.knum - cnt);
+        for_each_batch<false, true>(a, t, st, [&](int n, uint64_t, uint64_t sm) {
+            sm = soft_take(sm, open, a.knum - cnt);
             cnt += __popcll(sm);
             while (__ballot(sm != 0)) {
                 if (sm) {
@@ -428,8 +462,8 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterArgs a) {
     const float qnz = fabsf(sq);
     const bool onezero = sq < 0.f;
     int cnt = 0;
-    for_each_batch(a, t, st, [&](int n) {
-        uint64_t sm = soft_hits(a, t, st, n, open, a.knum - cnt);
+    for_each_batch<false, true>(a, t, st, [&](int n, uint64_t, uint64_t sm) {
+        sm = soft_take(sm, open, a.knum - cnt);
         cnt += __popcll(sm);
         while (__ballot(sm != 0)) {
             if (sm) {

@@ -38,7 +38,7 @@ class MMReconDesc(ctypes.Structure):
                 ("image_weight", c_f), ("contour", c_f), ("loss", c_p), ("grad_loss", c_p), ("grad_pred", c_p),
                 ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p)]
 
-PROF_RENDER = ("vertex_fwd", "raster_fwd", "zero", "raster_bwd", "vertex_bwd")
+PROF_RENDER = ("vertex_fwd", "raster_fwd", "zero", "raster_bwd", "vertex_bwd", "bin")
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",

@@ -5,6 +5,7 @@
 namespace mm {
 int launch_vertex_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_vertex_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
+int launch_bin(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_raster_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_raster_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
 size_t recon_workspace_bytes(const MMReconDesc*);
@@ -37,8 +38,9 @@ int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
     if (st != MM_OK) return st;
     const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->F, d->H, d->W);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(w.binmask, 0, w.binmask_bytes, s) != hipSuccess) return MM_ERR_LAUNCH;
     st = mm::launch_vertex_fwd(d, w, s);
+    if (st != MM_OK) return st;
+    st = mm::launch_bin(d, w, s);
     if (st != MM_OK) return st;
     return mm::launch_raster_fwd(d, w, s);
 }

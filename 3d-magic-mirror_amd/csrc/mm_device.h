@@ -40,7 +40,8 @@ __host__ __device__ inline int bin_shift_for(int H, int W, int F) {
 struct Workspace {
     float* T;              // (B,12)     camera transform [R;t], row-major (4,3)
     float4* geo;           // (B,F,3)    {ax,ay,bx,by} {cx,cy,az,bz} {cz, unit normal z, 0, 0}; xy in multiplier units
-    uint64_t* binmask;     // (B,nbins,ceil(F/64)) bit f of bin: face f may touch the bin (zeroed every forward)
+    uint64_t* binmask;     // (B,nbins,ceil(F/64)) bit f: the box of face f, inflated by the soft-mask margin, may touch the bin
+    uint64_t* binmask_hard;// (B,nbins,ceil(F/64)) bit f: face f is front facing and its box may touch the bin
     float* softq;          // (B,H,W)    soft-mask product state of uncovered pixels: +prod(1-p) if no factor is 0,
                            //            -prod(non-zero factors) if exactly one factor is 0, 0 if two or more are
     float* dfxy;           // (B,F,3,2)  backward accumulator: dL/d face_vertices_image (unscaled NDC)
@@ -67,6 +68,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.T = (float*)(p + o);          o += align256((size_t)B * 12 * sizeof(float));
     w.geo = (float4*)(p + o);       o += align256((size_t)B * F * 3 * sizeof(float4));
     w.binmask = (uint64_t*)(p + o); o += align256(w.binmask_bytes);
+    w.binmask_hard = (uint64_t*)(p + o); o += align256(w.binmask_bytes);
     w.softq = (float*)(p + o);      o += align256((size_t)B * H * W * sizeof(float));
     w.dfxy = (float*)(p + o);       o += align256((size_t)B * F * 6 * sizeof(float));
     w.dfn = (float*)(p + o);        o += align256((size_t)B * F * 3 * sizeof(float));

@@ -26,7 +26,8 @@ struct RasterArgs {
     int bin_shift, nbx, nby, words;
     float mult, eps, sigmainv, infl;        // infl = boxlen * multiplier
     const float4* geo;
-    const uint64_t* binmask;
+    const uint64_t* binmask;                // soft candidates (inflated boxes, all faces)
+    const uint64_t* binmask_hard;           // colour candidates (front faces)
     const float* face_uvs;
     const float* fn;                        // (B,F,3) unit normals
     const float* textures;
@@ -46,20 +47,25 @@ struct RasterArgs {
     float* dfn;
 };
 
+#define MM_PAIR_ROUND 256
+
 // per-wave LDS staging: 64 candidates as three float4 rows + the id list of one mask group
 struct __attribute__((aligned(16))) WaveStage {
     float4 p0[64];      // ax, ay, bx, by   (multiplier units)
     float4 p1[64];      // cx, cy, az, bz
     float4 p2[64];      // cz, unit normal z, face id (bits), 0
     unsigned short ids[MM_GROUP_WORDS * 64];
+    unsigned short pairs[MM_PAIR_ROUND];    // (owner lane << 8) | staged candidate
+    float res[MM_PAIR_ROUND];               // one result per pair
 };
 
 struct TileCtx {
-    int b, px, py, lane, wave;
+    int b, px, py, tx0, ty0, lane, wave;
     bool in_img;
     float x0, y0;
     float xs[MM_TILE], ys[MM_TILE];         // pixel-centre columns / rows of the tile (same in every lane)
-    const uint64_t* mask;                   // this wave's bin row: `words` 64-bit words
+    const uint64_t* mask;                   // this wave's bin row (soft candidates): `words` 64-bit words
+    const uint64_t* mask_hard;              // same bin, colour candidates
 };
 
 __device__ inline TileCtx make_tile(const RasterArgs& a) {
@@ -69,6 +75,7 @@ __device__ inline TileCtx make_tile(const RasterArgs& a) {
     t.lane = threadIdx.x & 63; t.wave = threadIdx.x >> 6;
     const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
     const int tx0 = bx * MM_BLOCK_PX + (t.wave & 1) * MM_TILE, ty0 = by * MM_BLOCK_PX + (t.wave >> 1) * MM_TILE;
+    t.tx0 = tx0; t.ty0 = ty0;
     t.px = tx0 + (t.lane & 7); t.py = ty0 + (t.lane >> 3);
     t.in_img = t.px < a.W && t.py < a.H;
     t.x0 = pixel_x(t.px, a.W, a.mult); t.y0 = pixel_y(t.py, a.H, a.mult);
@@ -76,7 +83,8 @@ __device__ inline TileCtx make_tile(const RasterArgs& a) {
     for (int i = 0; i < MM_TILE; ++i) { t.xs[i] = pixel_x(tx0 + i, a.W, a.mult); t.ys[i] = pixel_y(ty0 + i, a.H, a.mult); }
     // tiles never straddle bins (bin edge is 8, 16 or 32); a tile fully outside the image borrows the last bin
     const int binx = min(tx0 >> a.bin_shift, a.nbx - 1), biny = min(ty0 >> a.bin_shift, a.nby - 1);
-    t.mask = a.binmask + ((size_t)t.b * a.nbx * a.nby + (size_t)biny * a.nbx + binx) * a.words;
+    const size_t mrow = ((size_t)t.b * a.nbx * a.nby + (size_t)biny * a.nbx + binx) * a.words;
+    t.mask = a.binmask + mrow; t.mask_hard = a.binmask_hard + mrow;
     return t;
 }
 
@@ -137,14 +145,16 @@ __device__ inline uint64_t box_pixels(const TileCtx& t, float xlo, float ylo, fl
 }
 
 // Walk the bin's candidates in face order, 64 at a time.  For every batch the candidates are staged in st->p0/p1/p2[0..n)
-// and body(n, hm, sm) receives this LANE's (= this pixel's) hit masks over the batch: hm = front faces whose box contains
-// the pixel (kHard), sm = all faces whose inflated box contains it (kSoft).  body returns false to stop (wave-uniform).
-template <bool kHard, bool kSoft, class Body>
+// and body(n, m) receives this LANE's (= this pixel's) hit mask over the batch: kHard: front faces whose box contains the
+// pixel; else: all faces whose inflated box contains it.  body returns false to stop (wave-uniform).
+template <bool kHard, class Body>
 __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, Body&& body) {
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
+    const uint64_t* mask = kHard ? t.mask_hard : t.mask;
+    const float pad = kHard ? 0.f : a.infl;
     for (int wbase = 0; wbase < a.words; wbase += MM_GROUP_WORDS) {
         uint64_t w = 0;
-        if (t.lane < MM_GROUP_WORDS && wbase + t.lane < a.words) w = t.mask[wbase + t.lane];
+        if (t.lane < MM_GROUP_WORDS && wbase + t.lane < a.words) w = mask[wbase + t.lane];
         int total;
         int pos = wave_prefix_excl(__popcll(w), t.lane, total);
         if (total == 0) continue;
@@ -156,7 +166,7 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
         wave_lds_sync();
         for (int k0 = 0; k0 < total; k0 += 64) {
             const int n = min(64, total - k0);
-            uint64_t hmc = 0, smc = 0;                           // candidate-major: lane j = candidate j, bit p = pixel p
+            uint64_t mc = 0;                                     // candidate-major: lane j = candidate j, bit p = pixel p
             if (t.lane < n) {
                 const int f = wbase * 64 + st->ids[k0 + t.lane];
                 const float4 g0 = geo[(size_t)f * 3 + 0], g1 = geo[(size_t)f * 3 + 1], g2 = geo[(size_t)f * 3 + 2];
@@ -164,16 +174,52 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
                 st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), 0.f);
                 const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
                 const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
-                if (kHard && g2.y >= 0.f) hmc = box_pixels(t, xmin, ymin, xmax, ymax);          // front faces only (a8)
-                if (kSoft) smc = box_pixels(t, xmin - a.infl, ymin - a.infl, xmax + a.infl, ymax + a.infl);
+                if (!kHard || g2.y >= 0.f) mc = box_pixels(t, xmin - pad, ymin - pad, xmax + pad, ymax + pad);
             }
-            const uint64_t hm = kHard ? wave_transpose64(hmc, t.lane) : 0;
-            const uint64_t sm = kSoft ? wave_transpose64(smc, t.lane) : 0;
+            const uint64_t m = wave_transpose64(mc, t.lane);
             wave_lds_sync();
-            const bool go = body(n, hm, sm);
+            const bool go = body(n, m);
             wave_lds_sync();
             if (!go) return;
         }
+    }
+}
+
+// Balanced evaluation of this batch's (pixel, candidate) pairs.  `m` = this lane's hits.  The pairs of all lanes are laid
+// out lane-major in LDS, evaluated 64 at a time by WHICHEVER lane (eval(owner_lane, candidate) -> float), and each owner
+// lane then consumes its own results in candidate order (consume(candidate, value)): the expensive part is spread evenly
+// over the wave, the ordered part stays with the pixel.  Deterministic: no atomics, fixed orders.
+template <class Eval, class Consume>
+__device__ inline void pair_parallel(const TileCtx& t, WaveStage* st, uint64_t m, Eval&& eval, Consume&& consume) {
+    int total;
+    const int off = wave_prefix_excl(__popcll(m), t.lane, total);
+    for (int base = 0; base < total; base += MM_PAIR_ROUND) {
+        const int lim = min(MM_PAIR_ROUND, total - base);
+        {
+            uint64_t mm_ = m; int k = off - base;
+            while (mm_) {
+                const int j = __ffsll((unsigned long long)mm_) - 1;
+                mm_ &= mm_ - 1;
+                if (k >= 0 && k < lim) st->pairs[k] = (unsigned short)((t.lane << 8) | j);
+                ++k;
+            }
+        }
+        wave_lds_sync();
+        for (int p = t.lane; p < lim; p += 64) {
+            const unsigned pr = st->pairs[p];
+            st->res[p] = eval((int)(pr >> 8), (int)(pr & 255u));
+        }
+        wave_lds_sync();
+        {
+            uint64_t mm_ = m; int k = off - base;
+            while (mm_) {
+                const int j = __ffsll((unsigned long long)mm_) - 1;
+                mm_ &= mm_ - 1;
+                if (k >= 0 && k < lim) consume(j, st->res[k]);
+                ++k;
+            }
+        }
+        wave_lds_sync();
     }
 }
 
@@ -181,29 +227,31 @@ struct Hit { float best; int f; float w0, w1, w2; };
 
 // K1: faces arrive in index order (batches ascending, bits ascending); strict z > best keeps the lowest index on ties.
 __device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h) {
-    for_each_batch<true, false>(a, t, st, [&](int n, uint64_t hm, uint64_t) {
-        while (__ballot(hm != 0)) {                              // lane-private walk over this pixel's own hits
-            if (hm) {
-                const int j = __ffsll((unsigned long long)hm) - 1;
-                hm &= hm - 1;
-                const float4 p0 = st->p0[j], p1 = st->p1[j], p2 = st->p2[j];
+    for_each_batch<true>(a, t, st, [&](int n, uint64_t hm) {
+        pair_parallel(t, st, hm,
+            [&](int l, int j) -> float {                       // interpolated z if the pixel of lane l is inside face j
+                const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
+                const float4 p0 = st->p0[j], p1 = st->p1[j];
                 float w0, w1, w2, nrm;
-                edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, t.x0, t.y0, a.eps, w0, w1, w2, nrm);
+                edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
                 // exact pre-reject: w/nrm < 0 whenever w and nrm have opposite signs and the quotient cannot underflow
                 // to -0; everything else takes the IEEE divisions the oracle takes.
                 const float sg = nrm < 0.f ? -1.f : 1.f;
-                const bool out = fabsf(nrm) < 1e10f && fminf(fminf(w0 * sg, w1 * sg), w2 * sg) < -1e-30f;
-                if (!out) {
-                    w0 /= nrm; w1 /= nrm; w2 /= nrm;
-                    if (!(w0 < 0.f || w1 < 0.f || w2 < 0.f)) {
-                        const float z0 = (w0 * p1.z + w1 * p1.w) + w2 * p2.x;
-                        if (z0 > h.best) { h.best = z0; h.f = __float_as_int(p2.z); h.w0 = w0; h.w1 = w1; h.w2 = w2; }
-                    }
-                }
-            }
-        }
+                if (fabsf(nrm) < 1e10f && fminf(fminf(w0 * sg, w1 * sg), w2 * sg) < -1e-30f) return -INFINITY;
+                w0 /= nrm; w1 /= nrm; w2 /= nrm;
+                if (w0 < 0.f || w1 < 0.f || w2 < 0.f) return -INFINITY;
+                return (w0 * p1.z + w1 * p1.w) + w2 * st->p2[j].x;
+            },
+            [&](int j, float z0) { if (z0 > h.best) { h.best = z0; h.f = __float_as_int(st->p2[j].z); } });
         return true;
     });
+    if (h.f >= 0) {                                              // barycentrics of the winner (same expressions, same values)
+        const float4* geo = a.geo + ((size_t)t.b * a.F + h.f) * 3;
+        const float4 p0 = geo[0], p1 = geo[1];
+        float nrm;
+        edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, t.x0, t.y0, a.eps, h.w0, h.w1, h.w2, nrm);
+        h.w0 /= nrm; h.w1 /= nrm; h.w2 /= nrm;
+    }
 }
 
 // closest of the three edge segments: squared distance (multiplier units) and type = edge*3 + region
@@ -246,19 +294,17 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
     if (__ballot(open)) {
         int cnt = 0;
         const float s2 = a.mult * a.mult;
-        for_each_batch<false, true>(a, t, st, [&](int n, uint64_t, uint64_t sm) {
+        for_each_batch<false>(a, t, st, [&](int n, uint64_t sm) {
             sm = soft_take(sm, open, a.knum - cnt);
             cnt += __popcll(sm);
-            while (__ballot(sm != 0)) {
-                if (sm) {
-                    const int j = __ffsll((unsigned long long)sm) - 1;
-                    sm &= sm - 1;
+            pair_parallel(t, st, sm,
+                [&](int l, int j) -> float {
+                    const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
                     int ty;
-                    const float d = tri_dist2(t.x0, t.y0, st->p0[j], st->p1[j], ty);
-                    const float q = 1.f - expf(-((d / s2) * a.sigmainv));
-                    if (q == 0.f) ++zeros; else qnz = qnz * q;
-                }
-            }
+                    const float d = tri_dist2(x0, y0, st->p0[j], st->p1[j], ty);
+                    return 1.f - expf(-((d / s2) * a.sigmainv));
+                },
+                [&](int, float q) { if (q == 0.f) ++zeros; else qnz = qnz * q; });
             return __ballot(open && cnt < a.knum) != 0;          // every open lane already holds knum faces: stop
         });
     }
@@ -462,7 +508,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterArgs a) {
     const float qnz = fabsf(sq);
     const bool onezero = sq < 0.f;
     int cnt = 0;
-    for_each_batch<false, true>(a, t, st, [&](int n, uint64_t, uint64_t sm) {
+    for_each_batch<false>(a, t, st, [&](int n, uint64_t sm) {
         sm = soft_take(sm, open, a.knum - cnt);
         cnt += __popcll(sm);
         while (__ballot(sm != 0)) {
@@ -518,7 +564,7 @@ static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
     a.blocks_per_image = a.blocks_x * ((d->H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
-    a.geo = w.geo; a.binmask = w.binmask; a.softq = w.softq;
+    a.geo = w.geo; a.binmask = w.binmask; a.binmask_hard = w.binmask_hard; a.softq = w.softq;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     a.grad_rgba = nullptr; a.grad_textures = nullptr; a.grad_lights = nullptr; a.grad_bg = nullptr;

@@ -12,14 +12,12 @@ namespace mm {
 
 struct VertexFwdArgs {
     int B, V, F, H, W;
-    int bin_shift, nbx, nby, words;
-    float proj0, proj1, proj2, mult, infl;
+    float proj0, proj1, proj2, mult;
     const int32_t* faces;
     const float* vertices;
     const float *azim, *elev, *dist, *bias;
     float* T;
     float4* geo;
-    uint64_t* binmask;
     float* face_normals;
 };
 
@@ -34,18 +32,6 @@ __device__ inline void block_camera(const float* azim, const float* elev, const 
     __syncthreads();
     if (tid == 0) camera_build(dist[b], s_trig[0], s_trig[1], s_trig[2], s_trig[3], bias[2 * b], bias[2 * b + 1], *s_cam);
     __syncthreads();
-}
-
-// conservative pixel range [lo, hi] whose centres can satisfy  lo_v <= centre <= hi_v  (one pixel of slack either side
-// covers the rounding of this closed form; the raster stage re-tests every pixel exactly)
-__device__ inline void pixel_range(float lo_v, float hi_v, float mult, int n, bool flip, int& lo, int& hi) {
-    float a = (lo_v / mult) * (float)n, c = (hi_v / mult) * (float)n;
-    float flo, fhi;
-    if (!flip) { flo = (a + (float)(n - 1)) * 0.5f; fhi = (c + (float)(n - 1)) * 0.5f; }      // x: centre grows with px
-    else { flo = ((float)(n - 1) - c) * 0.5f; fhi = ((float)(n - 1) - a) * 0.5f; }            // y: centre falls with py
-    if (!(fabsf(flo) < 1e9f) || !(fabsf(fhi) < 1e9f)) { lo = 0; hi = n - 1; return; }         // inf / NaN: every pixel
-    lo = (int)floorf(flo) - 1; hi = (int)ceilf(fhi) + 1;
-    lo = lo < 0 ? 0 : lo; hi = hi > n - 1 ? n - 1 : hi;
 }
 
 __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
@@ -83,18 +69,72 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     a.geo[o * 3 + 2] = make_float4(C.z, nz, 0.f, 0.f);
     a.face_normals[o * 3 + 0] = nx; a.face_normals[o * 3 + 1] = ny; a.face_normals[o * 3 + 2] = nz;
 
-    // screen binning of the soft-mask box (the hard box is inside it)
-    const float xmin = fminf(fminf(ax, bx), cx) - a.infl, xmax = fmaxf(fmaxf(ax, bx), cx) + a.infl;
-    const float ymin = fminf(fminf(ay, by), cy) - a.infl, ymax = fmaxf(fmaxf(ay, by), cy) + a.infl;
-    int px0, px1, py0, py1;
-    pixel_range(xmin, xmax, a.mult, a.W, false, px0, px1);
-    pixel_range(ymin, ymax, a.mult, a.H, true, py0, py1);
-    if (px0 > px1 || py0 > py1) return;                      // entirely off screen
-    const int bx0 = px0 >> a.bin_shift, bx1 = px1 >> a.bin_shift, by0 = py0 >> a.bin_shift, by1 = py1 >> a.bin_shift;
-    const unsigned long long bit = 1ull << (f & 63);
-    unsigned long long* base = (unsigned long long*)a.binmask + (size_t)b * a.nbx * a.nby * a.words + (f >> 6);
-    for (int yy = by0; yy <= by1; ++yy)
-        for (int xx = bx0; xx <= bx1; ++xx) atomicOr(base + (size_t)(yy * a.nbx + xx) * a.words, bit);
+}
+
+// ---- screen binning ---------------------------------------------------------------------------------------------------
+// One wave per REGION of 4x4 bins walks the image's faces 64 at a time; every lane tests its face's box against the
+// region's 4 bin columns and 4 bin rows (closed-box test on the pixel-centre extent of each bin, computed with the same
+// monotone formula as the pixel centres, so it is exactly conservative), and 16 ballots per kind turn the lanes'
+// 4x4 coverage into the 16 bins' mask words.  Plain stores, every word written: no atomics and no zero-fill.
+struct BinArgs {
+    int B, F, H, W, bin_shift, nbx, nby, words;
+    float mult, infl;
+    const float4* geo;
+    uint64_t* soft;
+    uint64_t* hard;
+};
+
+__global__ __launch_bounds__(256) void bin_kernel(BinArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int rx = (a.nbx + 3) >> 2, ry = (a.nby + 3) >> 2;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= a.B * rx * ry) return;
+    const int b = gw / (rx * ry), r = gw - b * (rx * ry);
+    const int bx0 = (r % rx) * 4, by0 = (r / rx) * 4;
+    float xlo[4], xhi[4], ylo[4], yhi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px0 = (bx0 + i) << a.bin_shift, px1 = min(((bx0 + i + 1) << a.bin_shift) - 1, a.W - 1);
+        const int py0 = (by0 + i) << a.bin_shift, py1 = min(((by0 + i + 1) << a.bin_shift) - 1, a.H - 1);
+        xlo[i] = pixel_x(px0, a.W, a.mult); xhi[i] = pixel_x(px1, a.W, a.mult);
+        yhi[i] = pixel_y(py0, a.H, a.mult); ylo[i] = pixel_y(py1, a.H, a.mult);
+    }
+    const float4* geo = a.geo + (size_t)b * a.F * 3;
+    const size_t nbins = (size_t)a.nbx * a.nby;
+    const int i4 = lane & 3, k4 = (lane >> 2) & 3;
+    const bool writer = lane < 16 && (bx0 + i4) < a.nbx && (by0 + k4) < a.nby;
+    const size_t row = ((size_t)b * nbins + (size_t)(by0 + k4) * a.nbx + (bx0 + i4)) * a.words;
+    for (int c = 0; c < a.words; ++c) {
+        const int f = c * 64 + lane;
+        unsigned cs = 0, ch = 0;
+        if (f < a.F) {
+            const float4 g0 = geo[(size_t)f * 3 + 0], g1 = geo[(size_t)f * 3 + 1];
+            const float nz = geo[(size_t)f * 3 + 2].y;
+            const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
+            const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
+            unsigned cols = 0, rows = 0, colh = 0, rowh = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                cols |= (unsigned)(!(xmax + a.infl < xlo[i] || xmin - a.infl > xhi[i])) << i;
+                rows |= (unsigned)(!(ymax + a.infl < ylo[i] || ymin - a.infl > yhi[i])) << i;
+                colh |= (unsigned)(!(xmax < xlo[i] || xmin > xhi[i])) << i;
+                rowh |= (unsigned)(!(ymax < ylo[i] || ymin > yhi[i])) << i;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cs |= ((rows >> k) & 1u) ? (cols << (4 * k)) : 0u;
+                ch |= ((rowh >> k) & 1u) ? (colh << (4 * k)) : 0u;
+            }
+            if (!(nz >= 0.f)) ch = 0;                            // colour only sees front faces (a8)
+        }
+        uint64_t ms = 0, mh = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint64_t s1 = __ballot((cs >> j) & 1u), h1 = __ballot((ch >> j) & 1u);
+            if (lane == j) { ms = s1; mh = h1; }
+        }
+        if (writer) { a.soft[row + c] = ms; a.hard[row + c] = mh; }
+    }
 }
 
 struct VertexBwdArgs {
@@ -224,15 +264,24 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
 int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     VertexFwdArgs a;
     a.B = d->B; a.V = d->V; a.F = d->F; a.H = d->H; a.W = d->W;
-    a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2]; a.mult = d->multiplier;
-    a.infl = d->boxlen * d->multiplier;
     a.faces = d->faces; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
-    a.T = w.T; a.geo = w.geo; a.binmask = w.binmask; a.face_normals = d->face_normals;
+    a.T = w.T; a.geo = w.geo; a.face_normals = d->face_normals;
     dim3 grid((d->F + 255) / 256, d->B);
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
       hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }
+    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+}
+
+int launch_bin(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
+    BinArgs a;
+    a.B = d->B; a.F = d->F; a.H = d->H; a.W = d->W; a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
+    a.mult = d->multiplier; a.infl = d->boxlen * d->multiplier;
+    a.geo = w.geo; a.soft = w.binmask; a.hard = w.binmask_hard;
+    const int waves = d->B * ((w.nbx + 3) / 4) * ((w.nby + 3) / 4);
+    { ProfScope ps(d->prof_events, MM_PROF_BIN, s);
+      hipLaunchKernelGGL(bin_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, a); }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 

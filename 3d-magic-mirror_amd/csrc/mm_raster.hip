@@ -55,8 +55,10 @@ struct __attribute__((aligned(16))) WaveStage {
     float4 p1[64];      // cx, cy, az, bz
     float4 p2[64];      // cz, unit normal z, face id (bits), 0
     unsigned short ids[MM_GROUP_WORDS * 64];
-    unsigned short pairs[MM_PAIR_ROUND];    // (owner lane << 8) | staged candidate
-    float res[MM_PAIR_ROUND];               // one result per pair
+    unsigned short pairs[MM_PAIR_ROUND];    // (candidate << 8) | pixel, or (owner lane << 8) | candidate
+    unsigned long long key[64];             // per pixel: best (orderable z << 32 | ~face) so far; 0 = none
+    long long logsum[64];                   // per pixel: sum of log2(1-p) in 2^-32 fixed point (integer adds commute)
+    int zeros[64];                          // per pixel: number of factors (1-p) that are exactly 0
 };
 
 struct TileCtx {
@@ -145,9 +147,10 @@ __device__ inline uint64_t box_pixels(const TileCtx& t, float xlo, float ylo, fl
 }
 
 // Walk the bin's candidates in face order, 64 at a time.  For every batch the candidates are staged in st->p0/p1/p2[0..n)
-// and body(n, m) receives this LANE's (= this pixel's) hit mask over the batch: kHard: front faces whose box contains the
-// pixel; else: all faces whose inflated box contains it.  body returns false to stop (wave-uniform).
-template <bool kHard, class Body>
+// and body(n, m) receives the hit masks of the batch -- kHard: front faces whose box contains the pixel; else: all faces whose
+// inflated box contains it -- either candidate-major (lane j = candidate j, bit p = pixel p) or, with kTranspose,
+// pixel-major (this lane's pixel, bit j = candidate j).  body returns false to stop (wave-uniform).
+template <bool kHard, bool kTranspose, class Body>
 __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, Body&& body) {
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
     const uint64_t* mask = kHard ? t.mask_hard : t.mask;
@@ -176,7 +179,7 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
                 const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
                 if (!kHard || g2.y >= 0.f) mc = box_pixels(t, xmin - pad, ymin - pad, xmax + pad, ymax + pad);
             }
-            const uint64_t m = wave_transpose64(mc, t.lane);
+            const uint64_t m = kTranspose ? wave_transpose64(mc, t.lane) : mc;
             wave_lds_sync();
             const bool go = body(n, m);
             wave_lds_sync();
@@ -185,67 +188,71 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
     }
 }
 
-// Balanced evaluation of this batch's (pixel, candidate) pairs.  `m` = this lane's hits.  The pairs of all lanes are laid
-// out lane-major in LDS, evaluated 64 at a time by WHICHEVER lane (eval(owner_lane, candidate) -> float), and each owner
-// lane then consumes its own results in candidate order (consume(candidate, value)): the expensive part is spread evenly
-// over the wave, the ordered part stays with the pixel.  Deterministic: no atomics, fixed orders.
-template <class Eval, class Consume>
-__device__ inline void pair_parallel(const TileCtx& t, WaveStage* st, uint64_t m, Eval&& eval, Consume&& consume) {
+// Balanced evaluation of a batch's (row, column) pairs: every lane owns one ROW of the bit matrix `m` (a candidate, or a
+// pixel) and the set bits are its columns.  The pairs of all lanes are laid out row-major in LDS and evaluated 64 at a
+// time by WHICHEVER lane, eval(row, col); results are combined by the caller through commutative, exact LDS atomics
+// (64-bit max / integer add), so the wave's critical path is pairs/64 evaluations, not its busiest lane, and the outcome
+// does not depend on evaluation order.
+template <class Eval>
+__device__ inline void pair_parallel(const TileCtx& t, WaveStage* st, uint64_t m, Eval&& eval) {
     int total;
     const int off = wave_prefix_excl(__popcll(m), t.lane, total);
     for (int base = 0; base < total; base += MM_PAIR_ROUND) {
         const int lim = min(MM_PAIR_ROUND, total - base);
         {
             uint64_t mm_ = m; int k = off - base;
-            while (mm_) {
+            while (mm_ && k < lim) {
                 const int j = __ffsll((unsigned long long)mm_) - 1;
                 mm_ &= mm_ - 1;
-                if (k >= 0 && k < lim) st->pairs[k] = (unsigned short)((t.lane << 8) | j);
+                if (k >= 0) st->pairs[k] = (unsigned short)((t.lane << 8) | j);
                 ++k;
             }
         }
         wave_lds_sync();
         for (int p = t.lane; p < lim; p += 64) {
             const unsigned pr = st->pairs[p];
-            st->res[p] = eval((int)(pr >> 8), (int)(pr & 255u));
-        }
-        wave_lds_sync();
-        {
-            uint64_t mm_ = m; int k = off - base;
-            while (mm_) {
-                const int j = __ffsll((unsigned long long)mm_) - 1;
-                mm_ &= mm_ - 1;
-                if (k >= 0 && k < lim) consume(j, st->res[k]);
-                ++k;
-            }
+            eval((int)(pr >> 8), (int)(pr & 255u));
         }
         wave_lds_sync();
     }
 }
 
-struct Hit { float best; int f; float w0, w1, w2; };
+__device__ inline unsigned long long depth_key(float z, int f) {
+    const unsigned bits = __float_as_uint(z + 0.f);              // -0 -> +0: equal depths must tie
+    const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    return ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)f);
+}
 
-// K1: faces arrive in index order (batches ascending, bits ascending); strict z > best keeps the lowest index on ties.
+struct Hit { int f; float w0, w1, w2; };
+
+// K1: nearest front face per pixel.  kaolin walks faces in index order and keeps strict z > best, i.e. the winner is
+// argmax over (z, -index); that maximum is taken here with a 64-bit LDS atomic max per (pixel, face) pair, which is
+// exact and order-free.  NaN and -inf depths never win, as in the reference.
 __device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h) {
-    for_each_batch<true>(a, t, st, [&](int n, uint64_t hm) {
-        pair_parallel(t, st, hm,
-            [&](int l, int j) -> float {                       // interpolated z if the pixel of lane l is inside face j
-                const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
-                const float4 p0 = st->p0[j], p1 = st->p1[j];
-                float w0, w1, w2, nrm;
-                edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
-                // exact pre-reject: w/nrm < 0 whenever w and nrm have opposite signs and the quotient cannot underflow
-                // to -0; everything else takes the IEEE divisions the oracle takes.
-                const float sg = nrm < 0.f ? -1.f : 1.f;
-                if (fabsf(nrm) < 1e10f && fminf(fminf(w0 * sg, w1 * sg), w2 * sg) < -1e-30f) return -INFINITY;
-                w0 /= nrm; w1 /= nrm; w2 /= nrm;
-                if (w0 < 0.f || w1 < 0.f || w2 < 0.f) return -INFINITY;
-                return (w0 * p1.z + w1 * p1.w) + w2 * st->p2[j].x;
-            },
-            [&](int j, float z0) { if (z0 > h.best) { h.best = z0; h.f = __float_as_int(st->p2[j].z); } });
+    st->key[t.lane] = 0ull;
+    wave_lds_sync();
+    for_each_batch<true, false>(a, t, st, [&](int n, uint64_t mc) {
+        pair_parallel(t, st, mc, [&](int j, int l) {             // candidate j of the batch, pixel l of the tile
+            const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
+            const float4 p0 = st->p0[j], p1 = st->p1[j], p2 = st->p2[j];
+            float w0, w1, w2, nrm;
+            edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
+            // exact pre-reject: w/nrm < 0 whenever w and nrm have opposite signs and the quotient cannot underflow to
+            // -0; everything else takes the IEEE divisions the oracle takes.
+            const float sg = nrm < 0.f ? -1.f : 1.f;
+            if (fabsf(nrm) < 1e10f && fminf(fminf(w0 * sg, w1 * sg), w2 * sg) < -1e-30f) return;
+            w0 /= nrm; w1 /= nrm; w2 /= nrm;
+            if (w0 < 0.f || w1 < 0.f || w2 < 0.f) return;
+            const float z0 = (w0 * p1.z + w1 * p1.w) + w2 * p2.x;
+            if (z0 > -INFINITY) atomicMax(&st->key[l], depth_key(z0, __float_as_int(p2.z)));
+        });
         return true;
     });
-    if (h.f >= 0) {                                              // barycentrics of the winner (same expressions, same values)
+    wave_lds_sync();
+    const unsigned long long k = st->key[t.lane];
+    h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
+    if (k != 0ull) {                                             // barycentrics of the winner (same expressions, same values)
+        h.f = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
         const float4* geo = a.geo + ((size_t)t.b * a.F + h.f) * 3;
         const float4 p0 = geo[0], p1 = geo[1];
         float nrm;
@@ -284,29 +291,35 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
     const TileCtx t = make_tile(a);
     WaveStage* st = &s_stage[t.wave];
 
-    Hit h; h.best = -INFINITY; h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
+    Hit h;
     raster_pixels(a, t, st, h);
 
-    // K3: soft silhouette for the lanes no front face covers.  State = product of the non-zero (1-p) and #zero factors.
+    // K3: soft silhouette for the lanes no front face covers.  prod(1-p) is order-free, so it is accumulated per pixel
+    // as an integer sum of log2(1-p) in 2^-32 fixed point (exact, commutative LDS adds) plus a count of exact zeros.
     float qnz = 1.f;
     int zeros = 0;
     const bool open = t.in_img && h.f < 0;
     if (__ballot(open)) {
         int cnt = 0;
         const float s2 = a.mult * a.mult;
-        for_each_batch<false>(a, t, st, [&](int n, uint64_t sm) {
-            sm = soft_take(sm, open, a.knum - cnt);
+        st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0;
+        wave_lds_sync();
+        for_each_batch<false, true>(a, t, st, [&](int n, uint64_t sm) {
+            sm = soft_take(sm, open, a.knum - cnt);              // pixel-major: the first knum hits of this pixel, in order
             cnt += __popcll(sm);
-            pair_parallel(t, st, sm,
-                [&](int l, int j) -> float {
-                    const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
-                    int ty;
-                    const float d = tri_dist2(x0, y0, st->p0[j], st->p1[j], ty);
-                    return 1.f - expf(-((d / s2) * a.sigmainv));
-                },
-                [&](int, float q) { if (q == 0.f) ++zeros; else qnz = qnz * q; });
+            pair_parallel(t, st, sm, [&](int l, int j) {         // pixel l of the tile, candidate j of the batch
+                const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
+                int ty;
+                const float d = tri_dist2(x0, y0, st->p0[j], st->p1[j], ty);
+                const float q = 1.f - expf(-((d / s2) * a.sigmainv));
+                if (q == 0.f) atomicAdd(&st->zeros[l], 1);
+                else atomicAdd((unsigned long long*)&st->logsum[l], (unsigned long long)(long long)((double)log2f(q) * 4294967296.0));
+            });
             return __ballot(open && cnt < a.knum) != 0;          // every open lane already holds knum faces: stop
         });
+        wave_lds_sync();
+        zeros = st->zeros[t.lane];
+        qnz = exp2f((float)((double)st->logsum[t.lane] * (1.0 / 4294967296.0)));
     }
     if (!t.in_img) return;
 
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterArgs a) {
     const float qnz = fabsf(sq);
     const bool onezero = sq < 0.f;
     int cnt = 0;
-    for_each_batch<false>(a, t, st, [&](int n, uint64_t sm) {
+    for_each_batch<false, true>(a, t, st, [&](int n, uint64_t sm) {
         sm = soft_take(sm, open, a.knum - cnt);
         cnt += __popcll(sm);
         while (__ballot(sm != 0)) {

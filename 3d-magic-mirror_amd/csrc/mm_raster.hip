@@ -47,7 +47,7 @@ struct RasterArgs {
     float* dfn;
 };
 
-#define MM_PAIR_ROUND 256
+#define MM_PAIR_ROUND 512
 
 // per-wave LDS staging: 64 candidates as three float4 rows + the id list of one mask group
 struct __attribute__((aligned(16))) WaveStage {
@@ -196,22 +196,23 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
 template <class Eval>
 __device__ inline void pair_parallel(const TileCtx& t, WaveStage* st, uint64_t m, Eval&& eval) {
     int total;
-    const int off = wave_prefix_excl(__popcll(m), t.lane, total);
+    int k = wave_prefix_excl(__popcll(m), t.lane, total);       // index of this lane's next unwritten pair
+    uint64_t rem = m;
     for (int base = 0; base < total; base += MM_PAIR_ROUND) {
         const int lim = min(MM_PAIR_ROUND, total - base);
-        {
-            uint64_t mm_ = m; int k = off - base;
-            while (mm_ && k < lim) {
-                const int j = __ffsll((unsigned long long)mm_) - 1;
-                mm_ &= mm_ - 1;
-                if (k >= 0) st->pairs[k] = (unsigned short)((t.lane << 8) | j);
-                ++k;
-            }
+        while (rem && k < base + lim) {                          // every set bit is visited exactly once overall
+            const int j = __ffsll((unsigned long long)rem) - 1;
+            rem &= rem - 1;
+            st->pairs[k - base] = (unsigned short)((t.lane << 8) | j);
+            ++k;
         }
         wave_lds_sync();
-        for (int p = t.lane; p < lim; p += 64) {
-            const unsigned pr = st->pairs[p];
-            eval((int)(pr >> 8), (int)(pr & 255u));
+        for (int p = t.lane; p < lim; p += 128) {                // two independent pairs per trip: ILP for a lone wave
+            const unsigned pr0 = st->pairs[p];
+            const bool two = p + 64 < lim;
+            const unsigned pr1 = two ? st->pairs[p + 64] : pr0;
+            eval((int)(pr0 >> 8), (int)(pr0 & 255u), true);
+            eval((int)(pr1 >> 8), (int)(pr1 & 255u), two);
         }
         wave_lds_sync();
     }
@@ -232,19 +233,16 @@ __device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, Wave
     st->key[t.lane] = 0ull;
     wave_lds_sync();
     for_each_batch<true, false>(a, t, st, [&](int n, uint64_t mc) {
-        pair_parallel(t, st, mc, [&](int j, int l) {             // candidate j of the batch, pixel l of the tile
+        pair_parallel(t, st, mc, [&](int j, int l, bool live) {  // candidate j of the batch, pixel l of the tile
             const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
             const float4 p0 = st->p0[j], p1 = st->p1[j], p2 = st->p2[j];
             float w0, w1, w2, nrm;
             edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
-            // exact pre-reject: w/nrm < 0 whenever w and nrm have opposite signs and the quotient cannot underflow to
-            // -0; everything else takes the IEEE divisions the oracle takes.
-            const float sg = nrm < 0.f ? -1.f : 1.f;
-            if (fabsf(nrm) < 1e10f && fminf(fminf(w0 * sg, w1 * sg), w2 * sg) < -1e-30f) return;
+            // straight-line on purpose (two of these are interleaved per trip): the IEEE divisions the oracle takes
             w0 /= nrm; w1 /= nrm; w2 /= nrm;
-            if (w0 < 0.f || w1 < 0.f || w2 < 0.f) return;
             const float z0 = (w0 * p1.z + w1 * p1.w) + w2 * p2.x;
-            if (z0 > -INFINITY) atomicMax(&st->key[l], depth_key(z0, __float_as_int(p2.z)));
+            if (live && !(w0 < 0.f || w1 < 0.f || w2 < 0.f) && z0 > -INFINITY)
+                atomicMax(&st->key[l], depth_key(z0, __float_as_int(p2.z)));
         });
         return true;
     });
@@ -307,13 +305,15 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
         for_each_batch<false, true>(a, t, st, [&](int n, uint64_t sm) {
             sm = soft_take(sm, open, a.knum - cnt);              // pixel-major: the first knum hits of this pixel, in order
             cnt += __popcll(sm);
-            pair_parallel(t, st, sm, [&](int l, int j) {         // pixel l of the tile, candidate j of the batch
+            pair_parallel(t, st, sm, [&](int l, int j, bool live) {   // pixel l of the tile, candidate j of the batch
                 const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
                 int ty;
                 const float d = tri_dist2(x0, y0, st->p0[j], st->p1[j], ty);
                 const float q = 1.f - expf(-((d / s2) * a.sigmainv));
-                if (q == 0.f) atomicAdd(&st->zeros[l], 1);
-                else atomicAdd((unsigned long long*)&st->logsum[l], (unsigned long long)(long long)((double)log2f(q) * 4294967296.0));
+                if (live) {
+                    if (q == 0.f) atomicAdd(&st->zeros[l], 1);
+                    else atomicAdd((unsigned long long*)&st->logsum[l], (unsigned long long)(long long)((double)log2f(q) * 4294967296.0));
+                }
             });
             return __ballot(open && cnt < a.knum) != 0;          // every open lane already holds knum faces: stop
         });

@@ -104,12 +104,15 @@ __global__ __launch_bounds__(256) void bin_kernel(BinArgs a) {
     const int i4 = lane & 3, k4 = (lane >> 2) & 3;
     const bool writer = lane < 16 && (bx0 + i4) < a.nbx && (by0 + k4) < a.nby;
     const size_t row = ((size_t)b * nbins + (size_t)(by0 + k4) * a.nbx + (bx0 + i4)) * a.words;
+    // software prefetch: the next 64 faces are in flight while the ballots of the current 64 run
+    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0; float nz = -1.f;
+    if (lane < a.F) { g0 = geo[(size_t)lane * 3 + 0]; g1 = geo[(size_t)lane * 3 + 1]; nz = geo[(size_t)lane * 3 + 2].y; }
     for (int c = 0; c < a.words; ++c) {
-        const int f = c * 64 + lane;
+        const int f = c * 64 + lane, fn_ = f + 64;
+        float4 ng0 = make_float4(0, 0, 0, 0), ng1 = ng0; float nnz = -1.f;
+        if (c + 1 < a.words && fn_ < a.F) { ng0 = geo[(size_t)fn_ * 3 + 0]; ng1 = geo[(size_t)fn_ * 3 + 1]; nnz = geo[(size_t)fn_ * 3 + 2].y; }
         unsigned cs = 0, ch = 0;
         if (f < a.F) {
-            const float4 g0 = geo[(size_t)f * 3 + 0], g1 = geo[(size_t)f * 3 + 1];
-            const float nz = geo[(size_t)f * 3 + 2].y;
             const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
             const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
             unsigned cols = 0, rows = 0, colh = 0, rowh = 0;
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(256) void bin_kernel(BinArgs a) {
             if (lane == j) { ms = s1; mh = h1; }
         }
         if (writer) { a.soft[row + c] = ms; a.hard[row + c] = mh; }
+        g0 = ng0; g1 = ng1; nz = nnz;
     }
 }
 

@@ -20,7 +20,8 @@ c_p = ctypes.c_void_p
 class MMRenderDesc(ctypes.Structure):
     _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("V", c_i), ("F", c_i), ("Ht", c_i), ("Wt", c_i), ("no_mask", c_i),
                 ("knum", c_i), ("proj", c_f * 3), ("sigmainv", c_f), ("boxlen", c_f), ("multiplier", c_f), ("eps", c_f),
-                ("faces", c_p), ("face_uvs", c_p), ("vc_offsets", c_p), ("vc_items", c_p),
+                ("faces", c_p), ("face_uvs", c_p), ("vc_offsets", c_p), ("vc_items", c_p), ("uvt_offsets", c_p), ("uvt_faces", c_p),
+                ("uvt_size", c_i),
                 ("vertices", c_p), ("textures", c_p), ("lights", c_p), ("bg", c_p), ("azimuths", c_p), ("elevations", c_p),
                 ("distances", c_p), ("biases", c_p),
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
@@ -38,11 +39,12 @@ class MMReconDesc(ctypes.Structure):
                 ("image_weight", c_f), ("contour", c_f), ("loss", c_p), ("grad_loss", c_p), ("grad_pred", c_p),
                 ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p)]
 
-PROF_RENDER = ("vertex_fwd", "raster_fwd", "zero", "raster_bwd", "vertex_bwd", "bin")
+PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "bin")
+UV_TILE = 32
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",
-           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_status_string",
+           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_uv_tiles", "mm_status_string",
            "mm_abi_version")
 
 
@@ -73,6 +75,7 @@ def lib():
     L.mm_recon_data_forward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
     L.mm_recon_data_backward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
     L.mm_build_vertex_corner_csr.argtypes = [c_i, c_i, c_p, c_p, c_p]
+    L.mm_build_uv_tiles.argtypes = [c_i, c_p, c_i, c_i, c_p, c_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.mm_status_string.restype = ctypes.c_char_p
     L.mm_status_string.argtypes = [ctypes.c_int]
     _LIB = L

@@ -21,7 +21,8 @@ static int check_render(const MMRenderDesc* d, bool backward) {
         !d->distances || !d->biases || !d->rgba || !d->face_idx || !d->face_normals)
         return MM_ERR_NULL_POINTER;
     if (d->no_mask && !d->bg) return MM_ERR_NULL_POINTER;
-    if (backward && (!d->vc_offsets || !d->vc_items)) return MM_ERR_NULL_POINTER;
+    if (backward && (!d->vc_offsets || !d->vc_items || !d->uvt_offsets || !d->uvt_faces)) return MM_ERR_NULL_POINTER;
+    if (backward && d->uvt_size != MM_UV_TILE) return MM_ERR_UNSUPPORTED;
     if (!d->workspace || d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_WORKSPACE;
     return MM_OK;
 }
@@ -85,6 +86,46 @@ int mm_recon_data_backward(const MMReconDesc* d, mm_stream_t stream) {
     int st = check_recon(d, true);
     if (st != MM_OK) return st;
     return mm::launch_recon_bwd(d, (hipStream_t)stream);
+}
+
+int mm_build_uv_tiles(int32_t F, const float* fuv, int32_t Ht, int32_t Wt, int32_t* offsets, int32_t* items, int64_t capacity,
+                      int64_t* needed) {
+    if (!fuv || !offsets || !needed) return MM_ERR_NULL_POINTER;
+    if (F <= 0 || Ht <= 0 || Wt <= 0) return MM_ERR_BAD_SHAPE;
+    const int TS = MM_UV_TILE, ntx = (Wt + TS - 1) / TS, nty = (Ht + TS - 1) / TS, nt = ntx * nty;
+    // texel-space box of every face's samples: ix = u*Wt - 0.5, iy = (1-v)*Ht - 0.5 (texture_mapping, a9), clipped to the
+    // texture like grid_sample's border mode, widened by the bilinear footprint and one texel of slack
+    auto range = [&](int f, int& x0, int& x1, int& y0, int& y1) {
+        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+        for (int k = 0; k < 3; ++k) {
+            const float u = fuv[(f * 3 + k) * 2], v = fuv[(f * 3 + k) * 2 + 1];
+            const float ix = (((u * 2.f - 1.f) + 1.f) * (float)Wt - 1.f) / 2.f, iy = (((-(v * 2.f - 1.f)) + 1.f) * (float)Ht - 1.f) / 2.f;
+            xmin = ix < xmin ? ix : xmin; xmax = ix > xmax ? ix : xmax; ymin = iy < ymin ? iy : ymin; ymax = iy > ymax ? iy : ymax;
+        }
+        auto clampi = [](float v, int hi) { if (!(v > 0.f)) return 0; if (v > (float)hi) return hi; return (int)v; };
+        x0 = clampi(floorf(xmin) - 1.f, Wt - 1); x1 = clampi(floorf(xmax) + 2.f, Wt - 1);
+        y0 = clampi(floorf(ymin) - 1.f, Ht - 1); y1 = clampi(floorf(ymax) + 2.f, Ht - 1);
+    };
+    for (int t = 0; t <= nt; ++t) offsets[t] = 0;
+    int64_t total = 0;
+    for (int f = 0; f < F; ++f) {
+        int x0, x1, y0, y1; range(f, x0, x1, y0, y1);
+        for (int ty = y0 / TS; ty <= y1 / TS; ++ty) for (int tx = x0 / TS; tx <= x1 / TS; ++tx) { ++offsets[ty * ntx + tx + 1]; ++total; }
+    }
+    *needed = total;
+    for (int t = 0; t < nt; ++t) offsets[t + 1] += offsets[t];
+    if (!items || capacity < total) return items ? MM_ERR_WORKSPACE : MM_OK;
+    for (int f = 0; f < F; ++f) {                                // ascending face id within a tile; offsets doubles as cursor
+        int x0, x1, y0, y1; range(f, x0, x1, y0, y1);
+        bool first = true;
+        for (int ty = y0 / TS; ty <= y1 / TS; ++ty) for (int tx = x0 / TS; tx <= x1 / TS; ++tx) {
+            items[offsets[ty * ntx + tx]++] = first ? (int32_t)((uint32_t)f | 0x80000000u) : f;
+            first = false;
+        }
+    }
+    for (int t = nt; t > 0; --t) offsets[t] = offsets[t - 1];
+    offsets[0] = 0;
+    return MM_OK;
 }
 
 int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces, int32_t* offsets, int32_t* items) {

@@ -46,9 +46,14 @@ struct Workspace {
                            //            -prod(non-zero factors) if exactly one factor is 0, 0 if two or more are
     float* dfxy;           // (B,F,3,2)  backward accumulator: dL/d face_vertices_image (unscaled NDC)
     float* dfn;            // (B,F,3)    backward accumulator: dL/d unit face normal (from the rasterised normals)
-    float* dTacc;          // (B,12)     backward accumulator: dL/d camera transform
-    unsigned* ticket;      // (B)        arrival counter of the vertex-backward workgroups of an image
-    size_t acc_floats;     // dfxy .. end of ticket, in floats (one contiguous zero-fill range)
+    float* dTacc;          // (B,12)     backward accumulator: dL/d camera transform (zeroed by the pixel backward)
+    unsigned* ticket;      // (B)        arrival counter of the vertex-backward workgroups of an image (same)
+    int* lastf;            // (B,H,W)    uncovered pixels: id of the knum-th soft-mask face taken, INT_MAX if fewer were
+    float4* gp0;           // (B,H,W)    covered pixels, written by the pixel backward for the gather: {dtex rgb, dmask}
+    float4* gp1;           // (B,H,W)    {du, dv, dnx, dny}
+    float* gp2;            // (B,H,W)    {dnz}
+    float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
+    int blocks_per_image;
     int bin_shift, nbx, nby, words;
     size_t binmask_bytes;
     size_t bytes;
@@ -74,7 +79,12 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.dfn = (float*)(p + o);        o += align256((size_t)B * F * 3 * sizeof(float));
     w.dTacc = (float*)(p + o);      o += align256((size_t)B * 12 * sizeof(float));
     w.ticket = (unsigned*)(p + o);  o += align256((size_t)B * sizeof(unsigned));
-    w.acc_floats = (size_t)((p + o) - (char*)w.dfxy) / sizeof(float);
+    w.lastf = (int*)(p + o);        o += align256((size_t)B * H * W * sizeof(int));
+    w.gp0 = (float4*)(p + o);       o += align256((size_t)B * H * W * sizeof(float4));
+    w.gp1 = (float4*)(p + o);       o += align256((size_t)B * H * W * sizeof(float4));
+    w.gp2 = (float*)(p + o);        o += align256((size_t)B * H * W * sizeof(float));
+    w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
+    w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
     w.bytes = o;
     return w;
 }
@@ -152,6 +162,18 @@ __device__ inline Float3 to_camera(const float* __restrict__ v, const float* T) 
 // ---- pixel centre convention of kaolin's rasteriser -----------------------------------------------
 __device__ inline float pixel_x(int px, int W, float mult) { return (mult / (float)W) * (float)(2 * px + 1 - W); }
 __device__ inline float pixel_y(int py, int H, float mult) { return (mult / (float)H) * (float)(H - 2 * py - 1); }
+
+// conservative pixel range [lo, hi] whose centres can satisfy  lo_v <= centre <= hi_v  (one pixel of slack either side
+// covers the rounding of this closed form; callers re-test every pixel exactly).  flip: centres fall with the index (y).
+__device__ inline void pixel_range(float lo_v, float hi_v, float mult, int n, bool flip, int& lo, int& hi) {
+    const float a = (lo_v / mult) * (float)n, c = (hi_v / mult) * (float)n;
+    float flo, fhi;
+    if (!flip) { flo = (a + (float)(n - 1)) * 0.5f; fhi = (c + (float)(n - 1)) * 0.5f; }
+    else { flo = ((float)(n - 1) - c) * 0.5f; fhi = ((float)(n - 1) - a) * 0.5f; }
+    if (!(fabsf(flo) < 1e9f) || !(fabsf(fhi) < 1e9f)) { lo = 0; hi = n - 1; return; }         // inf / NaN: every pixel
+    lo = (int)floorf(flo) - 1; hi = (int)ceilf(fhi) + 1;
+    lo = lo < 0 ? 0 : lo; hi = hi > n - 1 ? n - 1 : hi;
+}
 
 // barycentric weights exactly as packed_rasterize_forward (edge functions, copysign(eps) normalisation)
 __device__ inline void edge_weights(float ax, float ay, float bx, float by, float cx, float cy, float x0, float y0, float eps,

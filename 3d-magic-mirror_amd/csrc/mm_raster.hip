@@ -9,14 +9,17 @@
 //
 // Design (not kaolin's pixel-major brute force over all faces):
 //   * a wave owns an 8x8 pixel tile, one lane per pixel; a 256-thread workgroup is 2x2 such tiles (16x16 px).
-//   * the vertex stage left, per screen bin, a bit-per-face mask of the faces whose (inflated) box may touch it.
-//     The wave loads its bin's mask words coalesced, turns the set bits into an ORDERED candidate list with
-//     popcount + wave prefix sum (face order = bit order, which kaolin's lowest-index tie rule and the soft mask's
-//     "first knum faces" rule need), and stages 64 candidates at a time in LDS (struct-of-arrays float4 rows).
-//   * phase A: every lane tests its pixel against the 64 staged boxes (broadcast LDS reads) and keeps a private
-//     64-bit hit mask.  phase B: every lane walks ONLY ITS OWN hits (ctz loop, per-lane LDS gathers) through the
-//     edge functions / segment distances.  The serial depth of a wave is therefore max-over-lanes of its own hit
-//     count (<= knum for the soft mask), not the number of faces that touch the tile.
+//   * the bin kernel left, per screen bin, bit-per-face masks of the faces whose box may touch it (front faces for
+//     colour, inflated boxes of all faces for the silhouette).  The wave loads its bin's mask words coalesced, turns the
+//     set bits into an ORDERED candidate list with popcount + wave prefix sum (face order = bit order, which the soft
+//     mask's "first knum faces" rule needs) and stages 64 candidates at a time in LDS (struct-of-arrays float4 rows).
+//   * per batch, lane j tests candidate j's box against the tile's 8 pixel columns and 8 rows (separable closed-box
+//     test, the same float comparisons as a per-pixel test) -> a 64-bit pixel mask per candidate; a 6-stage wave
+//     butterfly transposes that 64x64 bit matrix when the per-pixel view is needed.
+//   * the (pixel, candidate) pairs of the batch are then evaluated 64 at a time by whichever lane and combined with
+//     exact, commutative LDS atomics: 64-bit max of (orderable z, ~face id) for colour -- argmax over (z, -index) is
+//     exactly kaolin's "strict z > best in index order" -- and an integer sum of log2(1-p) for the silhouette.  A wave's
+//     critical path is pairs/64 evaluations, not its busiest pixel, and results do not depend on evaluation order.
 #include "mm_device.h"
 
 namespace mm {
@@ -34,17 +37,11 @@ struct RasterArgs {
     const float* lights;
     const float* bg;
     float* softq;
-    // forward outputs
+    int* lastf;
+    // outputs
     float* rgba;
     int32_t* face_idx;
     float* imnormal;
-    // backward
-    const float* grad_rgba;
-    float* grad_textures;
-    float* grad_lights;
-    float* grad_bg;
-    float* dfxy;
-    float* dfn;
 };
 
 #define MM_PAIR_ROUND 512
@@ -295,7 +292,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
     // K3: soft silhouette for the lanes no front face covers.  prod(1-p) is order-free, so it is accumulated per pixel
     // as an integer sum of log2(1-p) in 2^-32 fixed point (exact, commutative LDS adds) plus a count of exact zeros.
     float qnz = 1.f;
-    int zeros = 0;
+    int zeros = 0, lastf = 0x7FFFFFFF;
     const bool open = t.in_img && h.f < 0;
     if (__ballot(open)) {
         int cnt = 0;
@@ -305,6 +302,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
         for_each_batch<false, true>(a, t, st, [&](int n, uint64_t sm) {
             sm = soft_take(sm, open, a.knum - cnt);              // pixel-major: the first knum hits of this pixel, in order
             cnt += __popcll(sm);
+            if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);   // knum-th face taken
             pair_parallel(t, st, sm, [&](int l, int j, bool live) {   // pixel l of the tile, candidate j of the batch
                 const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
                 int ty;
@@ -370,218 +368,20 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(RasterArgs a) {
     *(float4*)(a.rgba + pix * 4) = make_float4(out[0], out[1], out[2], out[3]);
     a.face_idx[pix] = h.f;
     a.softq[pix] = (h.f >= 0 || zeros >= 2) ? 0.f : (zeros == 1 ? -qnz : qnz);
+    if (h.f < 0) a.lastf[pix] = lastf;
     if (a.imnormal) { a.imnormal[pix * 3] = nx; a.imnormal[pix * 3 + 1] = ny; a.imnormal[pix * 3 + 2] = nz; }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// backward
-// ---------------------------------------------------------------------------------------------------------------------
-template <bool kNoMask>
-__global__ __launch_bounds__(256) void raster_bwd_kernel(RasterArgs a) {
-    __shared__ WaveStage s_stage[MM_BLOCK_WAVES];
-    __shared__ float s_dl[MM_BLOCK_WAVES][9];
-    const TileCtx t = make_tile(a);
-    WaveStage* st = &s_stage[t.wave];
-    const size_t hw = (size_t)a.H * a.W, pin = (size_t)t.py * a.W + t.px;
-    const size_t pix = (size_t)t.b * hw + pin;
-
-    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    int hf = -1;
-    if (t.in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
-    const float gin[3] = {g4.x, g4.y, g4.z};
-    float dl[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) dl[i] = 0.f;
-
-    if (t.in_img && (hf >= 0 || kNoMask)) {
-        // recompute the forward quantities of this pixel (only face_idx and the soft-mask state were saved)
-        float w0 = 0.f, w1 = 0.f, w2 = 0.f, nrm = 1.f, m = 0.f, u = 0.f, v = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
-        float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
-        float fu[6] = {0, 0, 0, 0, 0, 0}, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-        if (hf >= 0) {
-            const float4* geo = a.geo + ((size_t)t.b * a.F + hf) * 3;
-            p0 = geo[0]; p1 = geo[1];
-            edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, t.x0, t.y0, a.eps, w0, w1, w2, nrm);
-            w0 /= nrm; w1 /= nrm; w2 /= nrm;
-            const float* fuv = a.face_uvs + (size_t)hf * 6;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) fu[i] = fuv[i];
-            const float* nn = a.fn + ((size_t)t.b * a.F + hf) * 3;
-            n0 = nn[0]; n1 = nn[1]; n2 = nn[2];
-            m = (w0 + w1) + w2;
-            u = (w0 * fu[0] + w1 * fu[2]) + w2 * fu[4];
-            v = (w0 * fu[1] + w1 * fu[3]) + w2 * fu[5];
-            nx = (w0 * n0 + w1 * n0) + w2 * n0;
-            ny = (w0 * n1 + w1 * n1) + w2 * n1;
-            nz = (w0 * n2 + w1 * n2) + w2 * n2;
-        }
-        const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
-        const bool inw = s.x0 < a.Wt && s.y0 < a.Ht, ine = s.x1 < a.Wt && s.y0 < a.Ht;
-        const bool isw = s.x0 < a.Wt && s.y1 < a.Ht, ise = s.x1 < a.Wt && s.y1 < a.Ht;
-        float bnd[9];
-        sh_bands(nx, ny, nz, bnd);
-        const float* L = a.lights + t.b * 9;
-        float coef = 0.f;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) coef += bnd[i] * L[i];
-
-        float dm = 0.f, dc = 0.f, gix = 0.f, giy = 0.f;
-        const float ex = 1.f - s.tx, ey = 1.f - s.ty;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const size_t tb = ((size_t)t.b * 3 + c) * a.Ht * a.Wt;
-            const float* tex = a.textures + tb;
-            const float tnw = inw ? tex[(size_t)s.y0 * a.Wt + s.x0] : 0.f, tne = ine ? tex[(size_t)s.y0 * a.Wt + s.x1] : 0.f;
-            const float tsw = isw ? tex[(size_t)s.y1 * a.Wt + s.x0] : 0.f, tse = ise ? tex[(size_t)s.y1 * a.Wt + s.x1] : 0.f;
-            float tc = 0.f;
-            if (inw) tc += tnw * s.wnw;
-            if (ine) tc += tne * s.wne;
-            if (isw) tc += tsw * s.wsw;
-            if (ise) tc += tse * s.wse;
-            float pre, dtc;
-            if (kNoMask) {
-                const float bgv = a.bg[((size_t)t.b * 3 + c) * hw + pin];
-                const float base = tc * m + bgv * (1.f - m);
-                pre = base * coef;
-                const float g = (pre >= 0.f && pre <= 1.f) ? gin[c] : 0.f;      // torch.clamp backward mask
-                dc += g * base;
-                const float dbase = g * coef;
-                dtc = dbase * m;
-                a.grad_bg[((size_t)t.b * 3 + c) * hw + pin] = dbase * (1.f - m);
-                dm += dbase * (tc - bgv);
-            } else {
-                pre = (tc * m) * coef + 1.f * (1.f - m);
-                const float g = (pre >= 0.f && pre <= 1.f) ? gin[c] : 0.f;
-                dc += g * (tc * m);
-                dtc = (g * coef) * m;
-                dm += g * (tc * coef - 1.f);
-            }
-            if (hf >= 0 && dtc != 0.f) {
-                float* gt = a.grad_textures + tb;
-                if (inw) atomicAdd(gt + (size_t)s.y0 * a.Wt + s.x0, dtc * s.wnw);
-                if (ine) atomicAdd(gt + (size_t)s.y0 * a.Wt + s.x1, dtc * s.wne);
-                if (isw) atomicAdd(gt + (size_t)s.y1 * a.Wt + s.x0, dtc * s.wsw);
-                if (ise) atomicAdd(gt + (size_t)s.y1 * a.Wt + s.x1, dtc * s.wse);
-                gix += dtc * ((tne - tnw) * ey + (tse - tsw) * s.ty);
-                giy += dtc * ((tsw - tnw) * ex + (tse - tne) * s.tx);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) dl[i] = dc * bnd[i];
-        if (hf >= 0) {
-            const float du = gix * s.mx * ((float)a.Wt / 2.f) * 2.f;
-            const float dv = giy * s.my * ((float)a.Ht / 2.f) * -2.f;
-            const float dnx = dc * (((MM_SH_C1 * L[1] + MM_SH_C4 * ny * L[4]) + MM_SH_C7 * nz * L[7]) + 2.f * MM_SH_C8 * nx * L[8]);
-            const float dny = dc * (((MM_SH_C1 * L[3] + MM_SH_C4 * nx * L[4]) + MM_SH_C4 * nz * L[5]) - 2.f * MM_SH_C8 * ny * L[8]);
-            const float dnz = dc * (((MM_SH_C1 * L[2] + MM_SH_C4 * ny * L[5]) + 2.f * MM_SH_C6 * nz * L[6]) + MM_SH_C7 * nx * L[7]);
-            // K2 (Appendix A.1): features per corner k = (1, u_k, v_k, n)
-            const float gn = (dnx * n0 + dny * n1) + dnz * n2;
-            const float G0 = ((dm + du * fu[0]) + dv * fu[1]) + gn;
-            const float G1 = ((dm + du * fu[2]) + dv * fu[3]) + gn;
-            const float G2 = ((dm + du * fu[4]) + dv * fu[5]) + gn;
-            const float Gm = (w0 * G0 + w1 * G1) + w2 * G2;
-            const float dw0 = (G0 - Gm) / nrm, dw1 = (G1 - Gm) / nrm, dw2 = (G2 - Gm) / nrm;
-            const float aex = p0.x - t.x0, aey = p0.y - t.y0, bex = p0.z - t.x0, bey = p0.w - t.y0, cex = p1.x - t.x0, cey = p1.y - t.y0;
-            float* dq = a.dfxy + ((size_t)t.b * a.F + hf) * 6;
-            atomicAdd(dq + 0, (dw1 * (-cey) + dw2 * bey) * a.mult);
-            atomicAdd(dq + 1, (dw1 * cex + dw2 * (-bex)) * a.mult);
-            atomicAdd(dq + 2, (dw0 * cey + dw2 * (-aey)) * a.mult);
-            atomicAdd(dq + 3, (dw0 * (-cex) + dw2 * aex) * a.mult);
-            atomicAdd(dq + 4, (dw0 * (-bey) + dw1 * aey) * a.mult);
-            atomicAdd(dq + 5, (dw0 * bex + dw1 * (-aex)) * a.mult);
-            float* dn = a.dfn + ((size_t)t.b * a.F + hf) * 3;
-            atomicAdd(dn + 0, (w0 * dnx + w1 * dnx) + w2 * dnx);
-            atomicAdd(dn + 1, (w0 * dny + w1 * dny) + w2 * dny);
-            atomicAdd(dn + 2, (w0 * dnz + w1 * dnz) + w2 * dnz);
-        }
-    }
-
-    // d lights: wave butterfly -> one LDS row per wave -> 9 atomics per workgroup
-#pragma unroll
-    for (int i = 0; i < 9; ++i) dl[i] = wave_sum(dl[i]);
-    if (t.lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) s_dl[t.wave][i] = dl[i];
-    }
-    __syncthreads();
-    if (threadIdx.x < 9) {
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < MM_BLOCK_WAVES; ++w) sum += s_dl[w][threadIdx.x];
-        if (sum != 0.f) atomicAdd(a.grad_lights + t.b * 9 + threadIdx.x, sum);
-    }
-
-    // K4 (Appendix A.2): soft-mask gradient of the uncovered lanes; same ordered candidate walk as the forward, the
-    // product state of the forward (softq) gives every exclusive product prod_{j != k}(1 - p_j) without a second pass.
-    float sq = 0.f;
-    if (t.in_img && hf < 0 && g4.w != 0.f) sq = a.softq[pix];
-    const bool open = sq != 0.f && sq != 1.f;     // 1: no face in reach (every factor exactly 1) -> no gradient
-    if (__ballot(open) == 0) return;
-    const float s2 = a.mult * a.mult;
-    const float qnz = fabsf(sq);
-    const bool onezero = sq < 0.f;
-    int cnt = 0;
-    for_each_batch<false, true>(a, t, st, [&](int n, uint64_t sm) {
-        sm = soft_take(sm, open, a.knum - cnt);
-        cnt += __popcll(sm);
-        while (__ballot(sm != 0)) {
-            if (sm) {
-                const int j = __ffsll((unsigned long long)sm) - 1;
-                sm &= sm - 1;
-                const float4 q0 = st->p0[j], q1 = st->p1[j];
-                int ty;
-                const float d = tri_dist2(t.x0, t.y0, q0, q1, ty);
-                const float p = expf(-((d / s2) * a.sigmainv));
-                const float q = 1.f - p;
-                const float excl = (q != 0.f) ? (onezero ? 0.f : qnz / q) : (onezero ? qnz : 0.f);
-                const float gd = g4.w * excl * (-(p * a.sigmainv) / s2);
-                if (gd != 0.f) {
-                    const int e = ty / 3, reg = ty - e * 3;
-                    const int iu = e, iv = (e == 2) ? 0 : e + 1;
-                    const float ux = iu == 0 ? q0.x : (iu == 1 ? q0.z : q1.x), uy = iu == 0 ? q0.y : (iu == 1 ? q0.w : q1.y);
-                    const float wx = iv == 0 ? q0.x : (iv == 1 ? q0.z : q1.x), wy = iv == 0 ? q0.y : (iv == 1 ? q0.w : q1.y);
-                    float dux = 0.f, duy = 0.f, dvx = 0.f, dvy = 0.f;
-                    if (reg == 0) { dux = -2.f * (t.x0 - ux); duy = -2.f * (t.y0 - uy); }
-                    else if (reg == 2) { dvx = -2.f * (t.x0 - wx); dvy = -2.f * (t.y0 - wy); }
-                    else {
-                        const float ex = wx - ux, ey = wy - uy, rx = t.x0 - ux, ry = t.y0 - uy;
-                        const float tt = (rx * ex + ry * ey) / (ex * ex + ey * ey);
-                        const float qx = t.x0 - (ux + tt * ex), qy = t.y0 - (uy + tt * ey);
-                        dux = -2.f * (1.f - tt) * qx; duy = -2.f * (1.f - tt) * qy;
-                        dvx = -2.f * tt * qx; dvy = -2.f * tt * qy;
-                    }
-                    const int f = __float_as_int(st->p2[j].z);
-                    float* dq = a.dfxy + ((size_t)t.b * a.F + f) * 6;
-                    atomicAdd(dq + iu * 2, gd * dux * a.mult); atomicAdd(dq + iu * 2 + 1, gd * duy * a.mult);
-                    atomicAdd(dq + iv * 2, gd * dvx * a.mult); atomicAdd(dq + iv * 2 + 1, gd * dvy * a.mult);
-                }
-            }
-        }
-        return __ballot(open && cnt < a.knum) != 0;
-    });
-}
-
-// Zero-fill of everything the backward accumulates into, in one launch (float4 grid-stride over two ranges + a tail).
-__global__ __launch_bounds__(256) void zero_kernel(float4* p0, size_t n0, float4* p1, size_t n1, float* tail, size_t ntail) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += stride) p0[i] = z;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) p1[i] = z;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntail; i += stride) tail[i] = 0.f;
 }
 
 static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
     RasterArgs a;
     a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.Ht = d->Ht; a.Wt = d->Wt; a.knum = d->knum;
     a.blocks_x = (d->W + MM_BLOCK_PX - 1) / MM_BLOCK_PX;
-    a.blocks_per_image = a.blocks_x * ((d->H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
+    a.blocks_per_image = w.blocks_per_image;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
-    a.geo = w.geo; a.binmask = w.binmask; a.binmask_hard = w.binmask_hard; a.softq = w.softq;
+    a.geo = w.geo; a.binmask = w.binmask; a.binmask_hard = w.binmask_hard; a.softq = w.softq; a.lastf = w.lastf;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
-    a.grad_rgba = nullptr; a.grad_textures = nullptr; a.grad_lights = nullptr; a.grad_bg = nullptr;
-    a.dfxy = w.dfxy; a.dfn = w.dfn;
     return a;
 }
 
@@ -591,31 +391,6 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
     if (d->no_mask) hipLaunchKernelGGL(raster_fwd_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(raster_fwd_kernel<false>, grid, dim3(256), 0, s, a);
-    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
-}
-
-int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
-    RasterArgs a = make_args(d, w);
-    a.grad_rgba = g->grad_rgba; a.grad_textures = g->grad_textures; a.grad_lights = g->grad_lights; a.grad_bg = g->grad_bg;
-    // zero: grad_textures | the workspace accumulators (adjacent, padding included) | grad_lights
-    const size_t ntex = (size_t)d->B * 3 * d->Ht * d->Wt;
-    const size_t nacc = w.acc_floats;                        // dfxy | dfn | dTacc | ticket
-    const size_t nl = (size_t)d->B * 9;
-    {
-        ProfScope pz(d->prof_events, MM_PROF_ZERO, s);
-        const bool vec = (ntex % 4) == 0 && ((uintptr_t)g->grad_textures % 16) == 0;
-        if (!vec && hipMemsetAsync(g->grad_textures, 0, ntex * sizeof(float), s) != hipSuccess) return MM_ERR_LAUNCH;
-        const size_t n0 = vec ? ntex / 4 : 0;
-        size_t blocks = (n0 + (nacc + 3) / 4 + 255) / 256;
-        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (float4*)g->grad_textures, n0, (float4*)w.dfxy,
-                           (nacc + 3) / 4, g->grad_lights, nl);
-    }
-    if (hipGetLastError() != hipSuccess) return MM_ERR_LAUNCH;
-    dim3 grid(a.blocks_per_image * d->B);
-    ProfScope pb(d->prof_events, MM_PROF_RASTER_BWD, s);
-    if (d->no_mask) hipLaunchKernelGGL(raster_bwd_kernel<true>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(raster_bwd_kernel<false>, grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 

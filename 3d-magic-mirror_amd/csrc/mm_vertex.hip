@@ -155,6 +155,9 @@ struct VertexBwdArgs {
     const float* gfn;       // (B,F,3) external gradient of attributes['face_normals'] or NULL
     float* dTacc;           // (B,12) zeroed accumulator
     unsigned* ticket;       // (B) zeroed arrival counter
+    const float* dl_part;   // (B,blocks,12) partial dL/dlights of the pixel backward
+    int blocks_per_image;
+    float* grad_lights;
     float* grad_vertices;
     float *grad_azim, *grad_elev, *grad_dist, *grad_bias;
 };
@@ -253,6 +256,11 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
     }
     __syncthreads();
     if (!s_last) return;
+    if (tid >= 64 && tid < 73) {                                 // dL/dlights: fixed-order sum of the workgroup partials
+        float sum = 0.f;
+        for (int k = 0; k < a.blocks_per_image; ++k) sum += a.dl_part[((size_t)b * a.blocks_per_image + k) * 12 + (tid - 64)];
+        a.grad_lights[b * 9 + (tid - 64)] = sum;
+    }
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -297,6 +305,7 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.dfxy = w.dfxy; a.dfn = w.dfn; a.gfn = g->grad_face_normals;
     a.dTacc = w.dTacc; a.ticket = w.ticket;
+    a.dl_part = w.dl_part; a.blocks_per_image = w.blocks_per_image; a.grad_lights = g->grad_lights;
     a.grad_vertices = g->grad_vertices;
     a.grad_azim = g->grad_azimuths; a.grad_elev = g->grad_elevations; a.grad_dist = g->grad_distances; a.grad_bias = g->grad_biases;
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_BWD, s);

@@ -173,6 +173,26 @@ class DiffRender(object):
             print("Unique Edge Number: %d" % self.edges.shape[0])
 
     # ---- device-resident static template data (the reference re-uploads faces/face_uvs on every call, :272-273) ----
+    def _uv_tiles(self, device, Ht, Wt):
+        """Static texture-space tiling for the backward gather (mm_build_uv_tiles), cached per texture size and device."""
+        key = (str(device), Ht, Wt)
+        hit = self._static_cache.get(key)
+        if hit is None:
+            L = N.lib()
+            fuv = self.face_uvs.to(torch.float32).reshape(-1, 3, 2).contiguous().numpy()
+            nt = ((Wt + N.UV_TILE - 1) // N.UV_TILE) * ((Ht + N.UV_TILE - 1) // N.UV_TILE)
+            offsets = np.zeros(nt + 1, dtype=np.int32)
+            need = ctypes.c_int64(0)
+            N.check(L.mm_build_uv_tiles(self.num_faces, fuv.ctypes.data_as(ctypes.c_void_p), Ht, Wt,
+                                        offsets.ctypes.data_as(ctypes.c_void_p), None, 0, ctypes.byref(need)), "mm_build_uv_tiles")
+            items = np.zeros(max(1, need.value), dtype=np.int32)
+            N.check(L.mm_build_uv_tiles(self.num_faces, fuv.ctypes.data_as(ctypes.c_void_p), Ht, Wt,
+                                        offsets.ctypes.data_as(ctypes.c_void_p), items.ctypes.data_as(ctypes.c_void_p),
+                                        items.size, ctypes.byref(need)), "mm_build_uv_tiles")
+            hit = (torch.from_numpy(offsets).to(device), torch.from_numpy(items).to(device))
+            self._static_cache[key] = hit
+        return hit
+
     def _static(self, device):
         key = str(device)
         st = self._static_cache.get(key)
@@ -196,6 +216,8 @@ class DiffRender(object):
         d.vertices, d.textures, d.lights, d.bg = N.ptr(vertices), N.ptr(textures), N.ptr(lights), N.ptr(bg)
         d.azimuths, d.elevations, d.distances, d.biases = N.ptr(azimuths), N.ptr(elevations), N.ptr(distances), N.ptr(biases)
         d.rgba, d.face_idx, d.face_normals, d.imnormal = N.ptr(rgba), N.ptr(face_idx), N.ptr(fn), N.ptr(imn)
+        uo, uf = self._uv_tiles(vertices.device, d.Ht, d.Wt)
+        d.uvt_offsets, d.uvt_faces, d.uvt_size = N.ptr(uo), N.ptr(uf), N.UV_TILE
         return d
 
     # ---- networks.py:258-324 -------------------------------------------------------------------------------------

@@ -61,6 +61,9 @@ typedef struct MMRenderDesc {
     const float* face_uvs;      /* (F,3,2) raw OBJ uv of every corner (networks.py:196-202) */
     const int32_t* vc_offsets;  /* (V+1) CSR: vertex -> incident corners ...        (backward only; may be NULL forward) */
     const int32_t* vc_items;    /* (3F)  ... each item = face*3 + corner, ascending (backward only) */
+    const int32_t* uvt_offsets; /* (ntiles+1) CSR: texture tile -> faces that may sample it   (backward only; mm_build_uv_tiles) */
+    const int32_t* uvt_faces;   /* face id, bit 31 set on the face's primary tile              (backward only) */
+    int32_t uvt_size;           /* texture tile edge in texels (MM_UV_TILE)                    (backward only) */
     /* per-sample attributes (device), the 'attributes' dict of networks.py:259-270 */
     const float* vertices;      /* (B,V,3) */
     const float* textures;      /* (B,3,Ht,Wt) */
@@ -83,7 +86,7 @@ typedef struct MMRenderDesc {
     void** prof_events;
 } MMRenderDesc;
 
-enum { MM_PROF_VERTEX_FWD = 0, MM_PROF_RASTER_FWD = 1, MM_PROF_ZERO = 2, MM_PROF_RASTER_BWD = 3, MM_PROF_VERTEX_BWD = 4,
+enum { MM_PROF_VERTEX_FWD = 0, MM_PROF_RASTER_FWD = 1, MM_PROF_PIXEL_BWD = 2, MM_PROF_GATHER_BWD = 3, MM_PROF_VERTEX_BWD = 4,
        MM_PROF_BIN = 5, MM_PROF_RENDER_SLOTS = 6 };
 enum { MM_PROF_RECON_PARTIAL = 0, MM_PROF_RECON_FINAL = 1, MM_PROF_RECON_BWD = 2, MM_PROF_RECON_CONTOUR = 3,
        MM_PROF_RECON_SLOTS = 4 };
@@ -134,6 +137,13 @@ int mm_recon_data_backward(const MMReconDesc* desc, mm_stream_t stream);
 /* --------------------------------------------------------------------------------------------------------------------
  * Host helpers (no GPU involved)
  * ------------------------------------------------------------------------------------------------------------------ */
+/* Texture-space tiling used by the backward (static per template and texture size).  A face is listed in every tile
+ * its uv triangle (+1 texel) can touch; exactly one of those entries carries bit 31 (the face's primary tile).
+ * Query: items == NULL -> *needed receives the number of entries.  offsets: (ntiles+1) with
+ * ntiles = ceil(Wt/MM_UV_TILE) * ceil(Ht/MM_UV_TILE). */
+#define MM_UV_TILE 32
+int mm_build_uv_tiles(int32_t F, const float* face_uvs_host, int32_t Ht, int32_t Wt, int32_t* offsets_host,
+                      int32_t* items_host, int64_t capacity, int64_t* needed);
 /* Build the vertex -> corner CSR from HOST faces (F,3).  offsets: (V+1), items: (3F).  Returns MM_OK or an error. */
 int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces_host, int32_t* offsets_host, int32_t* items_host);
 const char* mm_status_string(int status);

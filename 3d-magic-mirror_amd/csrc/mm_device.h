@@ -163,15 +163,15 @@ __device__ inline Float3 to_camera(const float* __restrict__ v, const float* T) 
 __device__ inline float pixel_x(int px, int W, float mult) { return (mult / (float)W) * (float)(2 * px + 1 - W); }
 __device__ inline float pixel_y(int py, int H, float mult) { return (mult / (float)H) * (float)(H - 2 * py - 1); }
 
-// conservative pixel range [lo, hi] whose centres can satisfy  lo_v <= centre <= hi_v  (one pixel of slack either side
-// covers the rounding of this closed form; callers re-test every pixel exactly).  flip: centres fall with the index (y).
+// conservative pixel range [lo, hi] whose centres can satisfy  lo_v <= centre <= hi_v  (a 0.02 px slack covers the
+// rounding of this closed form by orders of magnitude; callers re-test every pixel exactly).  flip: centres fall with the index (y).
 __device__ inline void pixel_range(float lo_v, float hi_v, float mult, int n, bool flip, int& lo, int& hi) {
     const float a = (lo_v / mult) * (float)n, c = (hi_v / mult) * (float)n;
     float flo, fhi;
     if (!flip) { flo = (a + (float)(n - 1)) * 0.5f; fhi = (c + (float)(n - 1)) * 0.5f; }
     else { flo = ((float)(n - 1) - c) * 0.5f; fhi = ((float)(n - 1) - a) * 0.5f; }
     if (!(fabsf(flo) < 1e9f) || !(fabsf(fhi) < 1e9f)) { lo = 0; hi = n - 1; return; }         // inf / NaN: every pixel
-    lo = (int)floorf(flo) - 1; hi = (int)ceilf(fhi) + 1;
+    lo = (int)ceilf(flo - 0.02f); hi = (int)floorf(fhi + 0.02f);                                // 0.02 px >> rounding of flo/fhi
     lo = lo < 0 ? 0 : lo; hi = hi > n - 1 ? n - 1 : hi;
 }
 

@@ -40,8 +40,9 @@ def algorithmic_bytes(kernel, B, F, V, HW, T):
         "raster_fwd": 52 * F + 12 * T + 20 * HW,
         "recon_partial": 32 * HW,
         "recon_bwd": 48 * HW,
-        "zero": 12 * T + 36 * F,
-        "raster_bwd": 88 * F + 24 * T + 20 * HW,
+        "bin": 48 * F,
+        "pixel_bwd": 52 * F + 12 * T + 20 * HW,
+        "gather_bwd": 36 * F + 12 * T,
         "vertex_bwd": 36 * F + 24 * V,
     }.get(kernel)
     return None if per_image is None else per_image * B

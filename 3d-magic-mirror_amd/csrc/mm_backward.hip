@@ -177,7 +177,7 @@ __device__ inline float group16_sum(float v) {
     return v;
 }
 
-struct FaceBox { float4 p0, p1; float xmin, ymin, xmax, ymax; int px0, py0, bw, npx; };
+struct FaceBox { float4 p0, p1; float xmin, ymin, xmax, ymax; int px0, py0, bw, npx; float inv_bw; };
 
 __device__ inline FaceBox face_box(const BwdArgs& a, size_t o, float pad) {
     FaceBox fb;
@@ -190,54 +190,125 @@ __device__ inline FaceBox face_box(const BwdArgs& a, size_t o, float pad) {
     fb.bw = px1 - fb.px0 + 1;
     const int bh = py1 - fb.py0 + 1;
     fb.npx = (fb.bw > 0 && bh > 0) ? fb.bw * bh : 0;
+    fb.inv_bw = 1.f / (float)(fb.bw > 0 ? fb.bw : 1);
     return fb;
 }
 
+// pixel #idx of a box swept row-major (idx < 2^22: the float quotient is exact enough to be fixed up by one compare)
+__device__ inline void box_pixel(int idx, int px0, int py0, int bw, float inv_bw, int& px, int& py) {
+    int yy = (int)(((float)idx + 0.5f) * inv_bw);
+    if (yy * bw > idx) --yy;
+    if ((yy + 1) * bw <= idx) ++yy;
+    px = px0 + (idx - yy * bw); py = py0 + yy;
+}
+
+// What a wave keeps in LDS about the (up to) four faces its four 16-lane groups sweep, so that ANY lane can finish a
+// compacted work item of any of them.
+struct __attribute__((aligned(16))) FaceSlot {
+    float4 p0, p1;                   // ax,ay,bx,by | cx,cy,az,bz  (multiplier units)
+    float box[4];                    // xmin, ymin, xmax, ymax
+    float fu[6];                     // corner uvs
+    float n[3];                      // unit normal
+    int px0, py0, bw, f;
+    float inv_bw;
+    float acc[9];                    // dL/d(ax,ay,bx,by,cx,cy), dL/d(n)
+};
+
+struct __attribute__((aligned(16))) SweepStage {
+    FaceSlot slot[4];
+    unsigned char items[4 * 64];     // (sweep slot << 6) | lane
+};
+
+// ballot-compaction of four per-lane flags into an ordered LDS item list; returns the item count (wave-uniform)
+__device__ inline int compact4(const bool (&flag)[MM_SWEEP], int lane, unsigned char* items) {
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < MM_SWEEP; ++i) {
+        const unsigned long long m = __ballot(flag[i]);
+        if (flag[i]) items[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)((i << 6) | lane);
+        base += __popcll(m);
+    }
+    return base;
+}
+
+__device__ inline void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// pixel index of item `it` of the current trip: the item names the sweeping lane (hence its 16-lane group = face slot and
+// its position in the box walk)
+__device__ inline void item_pixel(const SweepStage* st, unsigned it, int base, int& g, int& px, int& py) {
+    const int l = it & 63, i = it >> 6;
+    g = l >> 4;
+    const FaceSlot& fs = st->slot[g];
+    box_pixel(base + i * 16 + (l & 15), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
+}
+
 // 2a. texture gradient: one workgroup per (image, 32x32-texel tile), accumulators in LDS, every texel written once.
+//     Each wave sweeps four faces at a time (16 lanes each, 4 pixels per lane per trip, loads issued together); the owned
+//     pixels found in a trip are ballot-compacted and finished by all 64 lanes.
 __global__ __launch_bounds__(256) void texture_gather_kernel(BwdArgs a) {
     __shared__ float s_acc[3][MM_TS * MM_TS];
+    __shared__ SweepStage s_stage[4];
     const int ntiles = a.ntx * a.nty;
     int b, T;
     map_block(blockIdx.x, a.B, ntiles, b, T);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SweepStage* st = &s_stage[wave];
     for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) (&s_acc[0][0])[i] = 0.f;
     __syncthreads();
     const int tx0 = (T % a.ntx) * MM_TS, ty0 = (T / a.ntx) * MM_TS;
     const int beg = a.uvt_offsets[T], end = a.uvt_offsets[T + 1];
-    const int grp = tid >> 4, sl = tid & 15;
+    const int grp = lane >> 4, sl = lane & 15;
     const size_t hw = (size_t)a.H * a.W;
 
-    for (int k = beg + grp; k < end; k += 16) {
-        const int f = a.uvt_faces[k] & 0x7FFFFFFF;
-        const size_t o = (size_t)b * a.F + f;
-        const FaceBox fb = face_box(a, o, 0.f);                  // owned pixels lie inside the face's own box
-        const float* fu = a.face_uvs + (size_t)f * 6;
-        for (int base = 0; base < fb.npx; base += 16 * MM_SWEEP) {
-            size_t pixv[MM_SWEEP]; int fiv[MM_SWEEP]; float4 q0v[MM_SWEEP]; int pxv[MM_SWEEP], pyv[MM_SWEEP];
+    for (int k0 = beg + wave * 4; k0 < end; k0 += 16) {          // wave-uniform: four list entries per step
+        const int k = k0 + grp;
+        int f = -1; FaceBox fb; fb.npx = 0; fb.bw = 1; fb.px0 = fb.py0 = 0; fb.inv_bw = 1.f;
+        if (k < end) {
+            f = a.uvt_faces[k] & 0x7FFFFFFF;
+            fb = face_box(a, (size_t)b * a.F + f, 0.f);          // owned pixels lie inside the face's own box
+            if (sl == 0) {
+                FaceSlot& fs = st->slot[grp];
+                fs.p0 = fb.p0; fs.p1 = fb.p1; fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f;
+                const float* fu = a.face_uvs + (size_t)f * 6;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) fs.fu[i] = fu[i];
+            }
+        }
+        int nmax = fb.npx;
+        nmax = max(nmax, __shfl_xor(nmax, 16, 64)); nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+        wave_sync_lds();
+        for (int base = 0; base < nmax; base += 16 * MM_SWEEP) {
+            bool own[MM_SWEEP];
 #pragma unroll
             for (int i = 0; i < MM_SWEEP; ++i) {
                 const int idx = base + i * 16 + sl;
-                const int yy = idx / fb.bw;
-                pxv[i] = fb.px0 + (idx - yy * fb.bw); pyv[i] = fb.py0 + yy;
-                pixv[i] = (size_t)b * hw + (size_t)pyv[i] * a.W + pxv[i];
-                fiv[i] = idx < fb.npx ? a.face_idx[pixv[i]] : -2;
+                int px, py;
+                box_pixel(idx, fb.px0, fb.py0, fb.bw, fb.inv_bw, px, py);
+                own[i] = idx < fb.npx && a.face_idx[(size_t)b * hw + (size_t)py * a.W + px] == f;
             }
-#pragma unroll
-            for (int i = 0; i < MM_SWEEP; ++i) q0v[i] = fiv[i] == f ? a.gp0[pixv[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < MM_SWEEP; ++i) {
-                if (fiv[i] != f) continue;
-                const float x0 = pixel_x(pxv[i], a.W, a.mult), y0 = pixel_y(pyv[i], a.H, a.mult);
+            const int n = compact4(own, lane, st->items);
+            wave_sync_lds();
+            for (int j = lane; j < n; j += 64) {
+                int g, px, py;
+                item_pixel(st, st->items[j], base, g, px, py);
+                const FaceSlot& fs = st->slot[g];
+                const size_t pix = (size_t)b * hw + (size_t)py * a.W + px;
+                const float4 q0 = a.gp0[pix];
+                const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
                 float w0, w1, w2, nrm;
-                edge_weights(fb.p0.x, fb.p0.y, fb.p0.z, fb.p0.w, fb.p1.x, fb.p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
+                edge_weights(fs.p0.x, fs.p0.y, fs.p0.z, fs.p0.w, fs.p1.x, fs.p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
                 w0 /= nrm; w1 /= nrm; w2 /= nrm;
-                const float u = (w0 * fu[0] + w1 * fu[2]) + w2 * fu[4];
-                const float v = (w0 * fu[1] + w1 * fu[3]) + w2 * fu[5];
+                const float u = (w0 * fs.fu[0] + w1 * fs.fu[2]) + w2 * fs.fu[4];
+                const float v = (w0 * fs.fu[1] + w1 * fs.fu[3]) + w2 * fs.fu[5];
                 const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
                 const int lx0 = s.x0 - tx0, lx1 = s.x1 - tx0, ly0 = s.y0 - ty0, ly1 = s.y1 - ty0;
                 const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && s.x1 < a.Wt;
                 const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && s.y1 < a.Ht;
-                const float dt[3] = {q0v[i].x, q0v[i].y, q0v[i].z};
+                const float dt[3] = {q0.x, q0.y, q0.z};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     if (dt[c] != 0.f) {
@@ -248,6 +319,7 @@ __global__ __launch_bounds__(256) void texture_gather_kernel(BwdArgs a) {
                     }
                 }
             }
+            wave_sync_lds();
         }
     }
     __syncthreads();
@@ -261,115 +333,132 @@ __global__ __launch_bounds__(256) void texture_gather_kernel(BwdArgs a) {
 }
 
 // 2b. per-face gradients: 16 lanes per (image, face) sweep the face's inflated box; pixels it owns give the K2 barycentric
-//     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  One plain store per face.
+//     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The two kinds of hits are
+//     ballot-compacted per wave (four faces) and finished by all 64 lanes into per-face LDS accumulators; one plain store
+//     per face at the end.
 __global__ __launch_bounds__(256) void face_gather_kernel(BwdArgs a) {
-    const int sl = threadIdx.x & 15;
+    __shared__ SweepStage s_stage[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4, sl = lane & 15;
+    SweepStage* st = &s_stage[wave];
     const long long gid = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (gid >= (long long)a.B * a.F) return;
-    const int b = (int)(gid / a.F), f = (int)(gid - (long long)b * a.F);
-    const size_t o = (size_t)gid, hw = (size_t)a.H * a.W;
+    const bool live = gid < (long long)a.B * a.F;
+    const int b = live ? (int)(gid / a.F) : 0, f = live ? (int)(gid - (long long)b * a.F) : 0;
+    const size_t o = (size_t)b * a.F + f, hw = (size_t)a.H * a.W;
     const float s2 = a.mult * a.mult;
-    const FaceBox fb = face_box(a, o, a.infl);
-    const float* fu = a.face_uvs + (size_t)f * 6;
-    const float* nn = a.fn + o * 3;
-    const float n0 = nn[0], n1 = nn[1], n2 = nn[2];
-    const float4 p0 = fb.p0, p1 = fb.p1;
-    float gxy[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
+    FaceBox fb = face_box(a, o, a.infl);
+    if (!live) fb.npx = 0;
+    if (sl == 0) {
+        FaceSlot& fs = st->slot[grp];
+        fs.p0 = fb.p0; fs.p1 = fb.p1; fs.box[0] = fb.xmin; fs.box[1] = fb.ymin; fs.box[2] = fb.xmax; fs.box[3] = fb.ymax;
+        fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f;
+        const float* fu = a.face_uvs + (size_t)f * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) fs.fu[i] = fu[i];
+        const float* nn = a.fn + o * 3;
+        fs.n[0] = nn[0]; fs.n[1] = nn[1]; fs.n[2] = nn[2];
+    }
+    if (sl < 9) st->slot[grp].acc[sl] = 0.f;
+    int nmax = fb.npx;
+    nmax = max(nmax, __shfl_xor(nmax, 16, 64)); nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+    wave_sync_lds();
 
-    for (int base = 0; base < fb.npx; base += 16 * MM_SWEEP) {
-        size_t pixv[MM_SWEEP]; int fiv[MM_SWEEP], pxv[MM_SWEEP], pyv[MM_SWEEP];
-        float4 q0v[MM_SWEEP], q1v[MM_SWEEP]; float q2v[MM_SWEEP], sqv[MM_SWEEP], gav[MM_SWEEP]; int lfv[MM_SWEEP];
+    for (int base = 0; base < nmax; base += 16 * MM_SWEEP) {
+        bool own[MM_SWEEP], opn[MM_SWEEP];
 #pragma unroll
         for (int i = 0; i < MM_SWEEP; ++i) {
             const int idx = base + i * 16 + sl;
-            const int yy = idx / fb.bw;
-            pxv[i] = fb.px0 + (idx - yy * fb.bw); pyv[i] = fb.py0 + yy;
-            pixv[i] = (size_t)b * hw + (size_t)pyv[i] * a.W + pxv[i];
-            fiv[i] = idx < fb.npx ? a.face_idx[pixv[i]] : -2;
+            int px, py;
+            box_pixel(idx, fb.px0, fb.py0, fb.bw, fb.inv_bw, px, py);
+            const int fi = idx < fb.npx ? a.face_idx[(size_t)b * hw + (size_t)py * a.W + px] : -2;
+            own[i] = fi == f; opn[i] = fi == -1;
         }
-#pragma unroll
-        for (int i = 0; i < MM_SWEEP; ++i) {
-            const bool own = fiv[i] == f, opn = fiv[i] == -1;
-            q0v[i] = own ? a.gp0[pixv[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
-            q1v[i] = own ? a.gp1[pixv[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
-            q2v[i] = own ? a.gp2[pixv[i]] : 0.f;
-            sqv[i] = opn ? a.softq[pixv[i]] : 0.f;
-            lfv[i] = opn ? a.lastf[pixv[i]] : -1;
-            gav[i] = opn ? a.grad_rgba[pixv[i] * 4 + 3] : 0.f;
+        // ---- K2 (Appendix A.1) for the pixels these faces own: features per corner k = (1, u_k, v_k, n)
+        int n = compact4(own, lane, st->items);
+        wave_sync_lds();
+        for (int j = lane; j < n; j += 64) {
+            int g, px, py;
+            item_pixel(st, st->items[j], base, g, px, py);
+            FaceSlot& fs = st->slot[g];
+            const int bb = (int)(((long long)blockIdx.x * 16 + wave * 4 + g) / a.F);
+            const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
+            const float4 q0 = a.gp0[pix], q1 = a.gp1[pix];
+            const float dnz = a.gp2[pix];
+            const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
+            const float4 p0 = fs.p0, p1 = fs.p1;
+            float w0, w1, w2, nrm;
+            edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
+            w0 /= nrm; w1 /= nrm; w2 /= nrm;
+            const float dm = q0.w, du = q1.x, dv = q1.y, dnx = q1.z, dny = q1.w;
+            const float gnn = (dnx * fs.n[0] + dny * fs.n[1]) + dnz * fs.n[2];
+            const float G0 = ((dm + du * fs.fu[0]) + dv * fs.fu[1]) + gnn;
+            const float G1 = ((dm + du * fs.fu[2]) + dv * fs.fu[3]) + gnn;
+            const float G2 = ((dm + du * fs.fu[4]) + dv * fs.fu[5]) + gnn;
+            const float Gm = (w0 * G0 + w1 * G1) + w2 * G2;
+            const float dw0 = (G0 - Gm) / nrm, dw1 = (G1 - Gm) / nrm, dw2 = (G2 - Gm) / nrm;
+            const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
+            atomicAdd(&fs.acc[0], (dw1 * (-cey) + dw2 * bey) * a.mult);
+            atomicAdd(&fs.acc[1], (dw1 * cex + dw2 * (-bex)) * a.mult);
+            atomicAdd(&fs.acc[2], (dw0 * cey + dw2 * (-aey)) * a.mult);
+            atomicAdd(&fs.acc[3], (dw0 * (-cex) + dw2 * aex) * a.mult);
+            atomicAdd(&fs.acc[4], (dw0 * (-bey) + dw1 * aey) * a.mult);
+            atomicAdd(&fs.acc[5], (dw0 * bex + dw1 * (-aex)) * a.mult);
+            atomicAdd(&fs.acc[6], (w0 * dnx + w1 * dnx) + w2 * dnx);
+            atomicAdd(&fs.acc[7], (w0 * dny + w1 * dny) + w2 * dny);
+            atomicAdd(&fs.acc[8], (w0 * dnz + w1 * dnz) + w2 * dnz);
         }
-#pragma unroll
-        for (int i = 0; i < MM_SWEEP; ++i) {
-            const float x0 = pixel_x(pxv[i], a.W, a.mult), y0 = pixel_y(pyv[i], a.H, a.mult);
-            if (fiv[i] == f) {
-                // ---- K2 (Appendix A.1): features per corner k = (1, u_k, v_k, n)
-                float w0, w1, w2, nrm;
-                edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
-                w0 /= nrm; w1 /= nrm; w2 /= nrm;
-                const float dm = q0v[i].w, du = q1v[i].x, dv = q1v[i].y, dnx = q1v[i].z, dny = q1v[i].w, dnz = q2v[i];
-                const float gnn = (dnx * n0 + dny * n1) + dnz * n2;
-                const float G0 = ((dm + du * fu[0]) + dv * fu[1]) + gnn;
-                const float G1 = ((dm + du * fu[2]) + dv * fu[3]) + gnn;
-                const float G2 = ((dm + du * fu[4]) + dv * fu[5]) + gnn;
-                const float Gm = (w0 * G0 + w1 * G1) + w2 * G2;
-                const float dw0 = (G0 - Gm) / nrm, dw1 = (G1 - Gm) / nrm, dw2 = (G2 - Gm) / nrm;
-                const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
-                gxy[0] += (dw1 * (-cey) + dw2 * bey) * a.mult;
-                gxy[1] += (dw1 * cex + dw2 * (-bex)) * a.mult;
-                gxy[2] += (dw0 * cey + dw2 * (-aey)) * a.mult;
-                gxy[3] += (dw0 * (-cex) + dw2 * aex) * a.mult;
-                gxy[4] += (dw0 * (-bey) + dw1 * aey) * a.mult;
-                gxy[5] += (dw0 * bex + dw1 * (-aex)) * a.mult;
-                gn[0] += (w0 * dnx + w1 * dnx) + w2 * dnx;
-                gn[1] += (w0 * dny + w1 * dny) + w2 * dny;
-                gn[2] += (w0 * dnz + w1 * dnz) + w2 * dnz;
-            } else if (fiv[i] == -1) {
-                // ---- K4 (Appendix A.2): an uncovered pixel that may hold this face among its first knum soft-mask faces
-                const float sq = sqv[i], ga = gav[i];
-                if (sq != 0.f && sq != 1.f && ga != 0.f && f <= lfv[i] &&
-                    !(x0 < fb.xmin - a.infl || x0 > fb.xmax + a.infl || y0 < fb.ymin - a.infl || y0 > fb.ymax + a.infl)) {
-                    int r, ty;
-                    float d = seg_dist2(x0, y0, p0.x, p0.y, p0.z, p0.w, ty);
-                    const float d1 = seg_dist2(x0, y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
-                    const float d2 = seg_dist2(x0, y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
-                    const float p = expf(-((d / s2) * a.sigmainv));
-                    const float q = 1.f - p;
-                    const float qnz = fabsf(sq);
-                    const bool onezero = sq < 0.f;
-                    const float excl = (q != 0.f) ? (onezero ? 0.f : qnz / q) : (onezero ? qnz : 0.f);
-                    const float gd = ga * excl * (-(p * a.sigmainv) / s2);
-                    if (gd != 0.f) {
-                        const int e = ty / 3, reg = ty - e * 3;
-                        const float ux = e == 0 ? p0.x : (e == 1 ? p0.z : p1.x), uy = e == 0 ? p0.y : (e == 1 ? p0.w : p1.y);
-                        const float wx = e == 0 ? p0.z : (e == 1 ? p1.x : p0.x), wy = e == 0 ? p0.w : (e == 1 ? p1.y : p0.y);
-                        float dux = 0.f, duy = 0.f, dvx = 0.f, dvy = 0.f;
-                        if (reg == 0) { dux = -2.f * (x0 - ux); duy = -2.f * (y0 - uy); }
-                        else if (reg == 2) { dvx = -2.f * (x0 - wx); dvy = -2.f * (y0 - wy); }
-                        else {
-                            const float ex = wx - ux, ey = wy - uy, rx = x0 - ux, ry = y0 - uy;
-                            const float tt = (rx * ex + ry * ey) / (ex * ex + ey * ey);
-                            const float qx = x0 - (ux + tt * ex), qy = y0 - (uy + tt * ey);
-                            dux = -2.f * (1.f - tt) * qx; duy = -2.f * (1.f - tt) * qy;
-                            dvx = -2.f * tt * qx; dvy = -2.f * tt * qy;
-                        }
-                        const float sux = gd * dux * a.mult, suy = gd * duy * a.mult, svx = gd * dvx * a.mult, svy = gd * dvy * a.mult;
-                        // edge e runs from corner e to corner (e+1)%3
-                        if (e == 0) { gxy[0] += sux; gxy[1] += suy; gxy[2] += svx; gxy[3] += svy; }
-                        else if (e == 1) { gxy[2] += sux; gxy[3] += suy; gxy[4] += svx; gxy[5] += svy; }
-                        else { gxy[4] += sux; gxy[5] += suy; gxy[0] += svx; gxy[1] += svy; }
+        wave_sync_lds();
+        // ---- K4 (Appendix A.2) for uncovered pixels that may hold one of these faces among their first knum faces
+        n = compact4(opn, lane, st->items);
+        wave_sync_lds();
+        for (int j = lane; j < n; j += 64) {
+            int g, px, py;
+            item_pixel(st, st->items[j], base, g, px, py);
+            FaceSlot& fs = st->slot[g];
+            const int bb = (int)(((long long)blockIdx.x * 16 + wave * 4 + g) / a.F);
+            const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
+            const float sq = a.softq[pix];
+            const int lf = a.lastf[pix];
+            const float ga = a.grad_rgba[pix * 4 + 3];
+            const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
+            if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= lf &&
+                !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl)) {
+                const float4 p0 = fs.p0, p1 = fs.p1;
+                int r, ty;
+                float d = seg_dist2(x0, y0, p0.x, p0.y, p0.z, p0.w, ty);
+                const float d1 = seg_dist2(x0, y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
+                const float d2 = seg_dist2(x0, y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
+                const float p = expf(-((d / s2) * a.sigmainv));
+                const float q = 1.f - p;
+                const float qnz = fabsf(sq);
+                const bool onezero = sq < 0.f;
+                const float excl = (q != 0.f) ? (onezero ? 0.f : qnz / q) : (onezero ? qnz : 0.f);
+                const float gd = ga * excl * (-(p * a.sigmainv) / s2);
+                if (gd != 0.f) {
+                    const int e = ty / 3, reg = ty - e * 3;
+                    const float ux = e == 0 ? p0.x : (e == 1 ? p0.z : p1.x), uy = e == 0 ? p0.y : (e == 1 ? p0.w : p1.y);
+                    const float wx = e == 0 ? p0.z : (e == 1 ? p1.x : p0.x), wy = e == 0 ? p0.w : (e == 1 ? p1.y : p0.y);
+                    float dux = 0.f, duy = 0.f, dvx = 0.f, dvy = 0.f;
+                    if (reg == 0) { dux = -2.f * (x0 - ux); duy = -2.f * (y0 - uy); }
+                    else if (reg == 2) { dvx = -2.f * (x0 - wx); dvy = -2.f * (y0 - wy); }
+                    else {
+                        const float ex = wx - ux, ey = wy - uy, rx = x0 - ux, ry = y0 - uy;
+                        const float tt = (rx * ex + ry * ey) / (ex * ex + ey * ey);
+                        const float qx = x0 - (ux + tt * ex), qy = y0 - (uy + tt * ey);
+                        dux = -2.f * (1.f - tt) * qx; duy = -2.f * (1.f - tt) * qy;
+                        dvx = -2.f * tt * qx; dvy = -2.f * tt * qy;
                     }
+                    // edge e runs from corner e to corner (e+1)%3
+                    const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;
+                    atomicAdd(&fs.acc[iu], gd * dux * a.mult); atomicAdd(&fs.acc[iu + 1], gd * duy * a.mult);
+                    atomicAdd(&fs.acc[iv], gd * dvx * a.mult); atomicAdd(&fs.acc[iv + 1], gd * dvy * a.mult);
                 }
             }
         }
+        wave_sync_lds();
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gxy[i] = group16_sum(gxy[i]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) gn[i] = group16_sum(gn[i]);
-    if (sl == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) a.dfxy[o * 6 + i] = gxy[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) a.dfn[o * 3 + i] = gn[i];
+    if (live && sl < 9) {
+        const float v = st->slot[grp].acc[sl];
+        if (sl < 6) a.dfxy[o * 6 + sl] = v; else a.dfn[o * 3 + (sl - 6)] = v;
     }
 }
 

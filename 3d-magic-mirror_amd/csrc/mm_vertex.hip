@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
 }
 
 // ---- screen binning ---------------------------------------------------------------------------------------------------
-// One wave per REGION of 4x4 bins walks the image's faces 64 at a time; every lane tests its face's box against the
+// One wave per (image, REGION of 4x4 bins, mask word = 64 faces): every lane tests its face's box against the
 // region's 4 bin columns and 4 bin rows (closed-box test on the pixel-centre extent of each bin, computed with the same
 // monotone formula as the pixel centres, so it is exactly conservative), and 16 ballots per kind turn the lanes'
 // 4x4 coverage into the 16 bins' mask words.  Plain stores, every word written: no atomics and no zero-fill.
@@ -87,57 +87,50 @@ struct BinArgs {
 __global__ __launch_bounds__(256) void bin_kernel(BinArgs a) {
     const int lane = threadIdx.x & 63;
     const int rx = (a.nbx + 3) >> 2, ry = (a.nby + 3) >> 2;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gw >= a.B * rx * ry) return;
-    const int b = gw / (rx * ry), r = gw - b * (rx * ry);
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per (image, region, mask word)
+    if (gw >= (long long)a.B * rx * ry * a.words) return;
+    const int c = (int)(gw % a.words);
+    const int br = (int)(gw / a.words);
+    const int b = br / (rx * ry), r = br - b * (rx * ry);
     const int bx0 = (r % rx) * 4, by0 = (r / rx) * 4;
-    float xlo[4], xhi[4], ylo[4], yhi[4];
+    const int f = c * 64 + lane;
+    unsigned cs = 0, ch = 0;
+    if (f < a.F) {
+        const float4* geo = a.geo + ((size_t)b * a.F + f) * 3;
+        const float4 g0 = geo[0], g1 = geo[1];
+        const float nz = geo[2].y;
+        const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
+        const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
+        unsigned cols = 0, rows = 0, colh = 0, rowh = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int px0 = (bx0 + i) << a.bin_shift, px1 = min(((bx0 + i + 1) << a.bin_shift) - 1, a.W - 1);
-        const int py0 = (by0 + i) << a.bin_shift, py1 = min(((by0 + i + 1) << a.bin_shift) - 1, a.H - 1);
-        xlo[i] = pixel_x(px0, a.W, a.mult); xhi[i] = pixel_x(px1, a.W, a.mult);
-        yhi[i] = pixel_y(py0, a.H, a.mult); ylo[i] = pixel_y(py1, a.H, a.mult);
+        for (int i = 0; i < 4; ++i) {
+            // pixel-centre extent of bin column / row i of this region
+            const int px0 = (bx0 + i) << a.bin_shift, px1 = min(((bx0 + i + 1) << a.bin_shift) - 1, a.W - 1);
+            const int py0 = (by0 + i) << a.bin_shift, py1 = min(((by0 + i + 1) << a.bin_shift) - 1, a.H - 1);
+            const float xlo = pixel_x(px0, a.W, a.mult), xhi = pixel_x(px1, a.W, a.mult);
+            const float yhi = pixel_y(py0, a.H, a.mult), ylo = pixel_y(py1, a.H, a.mult);
+            cols |= (unsigned)(!(xmax + a.infl < xlo || xmin - a.infl > xhi)) << i;
+            rows |= (unsigned)(!(ymax + a.infl < ylo || ymin - a.infl > yhi)) << i;
+            colh |= (unsigned)(!(xmax < xlo || xmin > xhi)) << i;
+            rowh |= (unsigned)(!(ymax < ylo || ymin > yhi)) << i;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cs |= ((rows >> k) & 1u) ? (cols << (4 * k)) : 0u;
+            ch |= ((rowh >> k) & 1u) ? (colh << (4 * k)) : 0u;
+        }
+        if (!(nz >= 0.f)) ch = 0;                                // colour only sees front faces (a8)
     }
-    const float4* geo = a.geo + (size_t)b * a.F * 3;
-    const size_t nbins = (size_t)a.nbx * a.nby;
+    uint64_t ms = 0, mh = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint64_t s1 = __ballot((cs >> j) & 1u), h1 = __ballot((ch >> j) & 1u);
+        if (lane == j) { ms = s1; mh = h1; }
+    }
     const int i4 = lane & 3, k4 = (lane >> 2) & 3;
-    const bool writer = lane < 16 && (bx0 + i4) < a.nbx && (by0 + k4) < a.nby;
-    const size_t row = ((size_t)b * nbins + (size_t)(by0 + k4) * a.nbx + (bx0 + i4)) * a.words;
-    // software prefetch: the next 64 faces are in flight while the ballots of the current 64 run
-    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0; float nz = -1.f;
-    if (lane < a.F) { g0 = geo[(size_t)lane * 3 + 0]; g1 = geo[(size_t)lane * 3 + 1]; nz = geo[(size_t)lane * 3 + 2].y; }
-    for (int c = 0; c < a.words; ++c) {
-        const int f = c * 64 + lane, fn_ = f + 64;
-        float4 ng0 = make_float4(0, 0, 0, 0), ng1 = ng0; float nnz = -1.f;
-        if (c + 1 < a.words && fn_ < a.F) { ng0 = geo[(size_t)fn_ * 3 + 0]; ng1 = geo[(size_t)fn_ * 3 + 1]; nnz = geo[(size_t)fn_ * 3 + 2].y; }
-        unsigned cs = 0, ch = 0;
-        if (f < a.F) {
-            const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
-            const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
-            unsigned cols = 0, rows = 0, colh = 0, rowh = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                cols |= (unsigned)(!(xmax + a.infl < xlo[i] || xmin - a.infl > xhi[i])) << i;
-                rows |= (unsigned)(!(ymax + a.infl < ylo[i] || ymin - a.infl > yhi[i])) << i;
-                colh |= (unsigned)(!(xmax < xlo[i] || xmin > xhi[i])) << i;
-                rowh |= (unsigned)(!(ymax < ylo[i] || ymin > yhi[i])) << i;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                cs |= ((rows >> k) & 1u) ? (cols << (4 * k)) : 0u;
-                ch |= ((rowh >> k) & 1u) ? (colh << (4 * k)) : 0u;
-            }
-            if (!(nz >= 0.f)) ch = 0;                            // colour only sees front faces (a8)
-        }
-        uint64_t ms = 0, mh = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint64_t s1 = __ballot((cs >> j) & 1u), h1 = __ballot((ch >> j) & 1u);
-            if (lane == j) { ms = s1; mh = h1; }
-        }
-        if (writer) { a.soft[row + c] = ms; a.hard[row + c] = mh; }
-        g0 = ng0; g1 = ng1; nz = nnz;
+    if (lane < 16 && (bx0 + i4) < a.nbx && (by0 + k4) < a.nby) {
+        const size_t row = ((size_t)b * a.nbx * a.nby + (size_t)(by0 + k4) * a.nbx + (bx0 + i4)) * a.words;
+        a.soft[row + c] = ms; a.hard[row + c] = mh;
     }
 }
 
@@ -162,8 +155,8 @@ struct VertexBwdArgs {
     float *grad_azim, *grad_elev, *grad_dist, *grad_bias;
 };
 
-// One thread per vertex, grid (ceil(V/256), B).  Per-vertex gradients are gathered through the static vertex->corner
-// CSR in a fixed order (no atomics); dT is reduced per workgroup and added to the image's accumulator; the LAST
+// Eight lanes per vertex, grid (ceil(V/32), B).  Per-vertex gradients are gathered through the static vertex->corner
+// CSR (no atomics); dT is reduced per workgroup and added to the image's accumulator; the LAST
 // workgroup of an image to arrive (agent-scope release / ticket / acquire, cdna_hip_programming.md G16) runs the
 // camera chain.
 __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
@@ -180,7 +173,9 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.f;
 
-    const int v = blockIdx.x * 256 + tid;
+    // 8 lanes per vertex: lane c of the group takes corners c, c+8, ... of the vertex (valence is ~6), then a 3-step
+    // butterfly inside the group; 32 vertices per workgroup
+    const int v = blockIdx.x * 32 + (tid >> 3), cl = tid & 7;
     if (v < a.V) {
         const float p[3] = {vb[v * 3], vb[v * 3 + 1], vb[v * 3 + 2]};
         const Float3 me = to_camera(p, T);
@@ -188,7 +183,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         const float xi = (me.x * a.proj0) / pz, yi = (me.y * a.proj1) / pz;
         float d[3] = {0.f, 0.f, 0.f};
         const int beg = a.vc_offsets[v], end = a.vc_offsets[v + 1];
-        for (int it = beg; it < end; ++it) {
+        for (int it = beg + cl; it < end; it += 8) {
             const int item = a.vc_items[it];
             const int f = item / 3, k = item - f * 3;
             const size_t o = (size_t)b * a.F + f;
@@ -227,15 +222,21 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
                 }
             }
         }
-        float* gv = a.grad_vertices + ((size_t)b * a.V + v) * 3;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            gv[i] = (T[i * 3 + 0] * d[0] + T[i * 3 + 1] * d[1]) + T[i * 3 + 2] * d[2];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[i * 3 + j] = p[i] * d[j];
+        for (int j = 0; j < 3; ++j) {
+            d[j] += __shfl_xor(d[j], 4, 8); d[j] += __shfl_xor(d[j], 2, 8); d[j] += __shfl_xor(d[j], 1, 8);
         }
+        if (cl == 0) {
+            float* gv = a.grad_vertices + ((size_t)b * a.V + v) * 3;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[9 + j] = d[j];
+            for (int i = 0; i < 3; ++i) {
+                gv[i] = (T[i * 3 + 0] * d[0] + T[i * 3 + 1] * d[1]) + T[i * 3 + 2] * d[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i * 3 + j] = p[i] * d[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[9 + j] = d[j];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = wave_sum(acc[i]);
@@ -291,9 +292,9 @@ int launch_bin(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     a.B = d->B; a.F = d->F; a.H = d->H; a.W = d->W; a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.infl = d->boxlen * d->multiplier;
     a.geo = w.geo; a.soft = w.binmask; a.hard = w.binmask_hard;
-    const int waves = d->B * ((w.nbx + 3) / 4) * ((w.nby + 3) / 4);
+    const long long waves = (long long)d->B * ((w.nbx + 3) / 4) * ((w.nby + 3) / 4) * w.words;
     { ProfScope ps(d->prof_events, MM_PROF_BIN, s);
-      hipLaunchKernelGGL(bin_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, a); }
+      hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 
@@ -309,7 +310,7 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.grad_vertices = g->grad_vertices;
     a.grad_azim = g->grad_azimuths; a.grad_elev = g->grad_elevations; a.grad_dist = g->grad_distances; a.grad_bias = g->grad_biases;
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_BWD, s);
-      hipLaunchKernelGGL(vertex_bwd_kernel, dim3((d->V + 255) / 256, d->B), dim3(256), 0, s, a); }
+      hipLaunchKernelGGL(vertex_bwd_kernel, dim3((d->V + 31) / 32, d->B), dim3(256), 0, s, a); }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }
 

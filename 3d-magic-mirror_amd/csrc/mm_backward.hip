@@ -249,12 +249,10 @@ __device__ inline void item_pixel(const SweepStage* st, unsigned it, int base, i
 // 2a. texture gradient: one workgroup per (image, 32x32-texel tile), accumulators in LDS, every texel written once.
 //     Each wave sweeps four faces at a time (16 lanes each, 4 pixels per lane per trip, loads issued together); the owned
 //     pixels found in a trip are ballot-compacted and finished by all 64 lanes.
-__global__ __launch_bounds__(256) void texture_gather_kernel(BwdArgs a) {
-    __shared__ float s_acc[3][MM_TS * MM_TS];
-    __shared__ SweepStage s_stage[4];
+__device__ inline void texture_gather_block(const BwdArgs& a, int block, float (*s_acc)[MM_TS * MM_TS], SweepStage* s_stage) {
     const int ntiles = a.ntx * a.nty;
     int b, T;
-    map_block(blockIdx.x, a.B, ntiles, b, T);
+    map_block(block, a.B, ntiles, b, T);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SweepStage* st = &s_stage[wave];
     for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) (&s_acc[0][0])[i] = 0.f;
@@ -336,11 +334,10 @@ __global__ __launch_bounds__(256) void texture_gather_kernel(BwdArgs a) {
 //     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The two kinds of hits are
 //     ballot-compacted per wave (four faces) and finished by all 64 lanes into per-face LDS accumulators; one plain store
 //     per face at the end.
-__global__ __launch_bounds__(256) void face_gather_kernel(BwdArgs a) {
-    __shared__ SweepStage s_stage[4];
+__device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage* s_stage) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4, sl = lane & 15;
     SweepStage* st = &s_stage[wave];
-    const long long gid = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long gid = (long long)block * 16 + (threadIdx.x >> 4);
     const bool live = gid < (long long)a.B * a.F;
     const int b = live ? (int)(gid / a.F) : 0, f = live ? (int)(gid - (long long)b * a.F) : 0;
     const size_t o = (size_t)b * a.F + f, hw = (size_t)a.H * a.W;
@@ -379,7 +376,7 @@ __global__ __launch_bounds__(256) void face_gather_kernel(BwdArgs a) {
             int g, px, py;
             item_pixel(st, st->items[j], base, g, px, py);
             FaceSlot& fs = st->slot[g];
-            const int bb = (int)(((long long)blockIdx.x * 16 + wave * 4 + g) / a.F);
+            const int bb = (int)(((long long)block * 16 + wave * 4 + g) / a.F);
             const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
             const float4 q0 = a.gp0[pix], q1 = a.gp1[pix];
             const float dnz = a.gp2[pix];
@@ -414,7 +411,7 @@ __global__ __launch_bounds__(256) void face_gather_kernel(BwdArgs a) {
             int g, px, py;
             item_pixel(st, st->items[j], base, g, px, py);
             FaceSlot& fs = st->slot[g];
-            const int bb = (int)(((long long)blockIdx.x * 16 + wave * 4 + g) / a.F);
+            const int bb = (int)(((long long)block * 16 + wave * 4 + g) / a.F);
             const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
             const float sq = a.softq[pix];
             const int lf = a.lastf[pix];
@@ -462,6 +459,15 @@ __global__ __launch_bounds__(256) void face_gather_kernel(BwdArgs a) {
     }
 }
 
+// One launch for both gathers: they only depend on the pixel pass, and each is latency-bound with a long tail, so their
+// workgroups are interleaved in a single grid (texture tiles first: they are the heavier ones).
+__global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
+    __shared__ float s_acc[3][MM_TS * MM_TS];
+    __shared__ SweepStage s_stage[4];
+    if ((int)blockIdx.x < ntex) texture_gather_block(a, blockIdx.x, s_acc, s_stage);
+    else face_gather_block(a, blockIdx.x - ntex, s_stage);
+}
+
 int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
     BwdArgs a;
     a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.Ht = d->Ht; a.Wt = d->Wt; a.knum = d->knum;
@@ -484,8 +490,9 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     if (hipGetLastError() != hipSuccess) return MM_ERR_LAUNCH;
     {
         ProfScope p(d->prof_events, MM_PROF_GATHER_BWD, s);
-        hipLaunchKernelGGL(texture_gather_kernel, dim3(a.ntx * a.nty * d->B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(face_gather_kernel, dim3((unsigned)(((long long)d->B * d->F + 15) / 16)), dim3(256), 0, s, a);
+        const int ntex = a.ntx * a.nty * d->B;
+        const unsigned nface = (unsigned)(((long long)d->B * d->F + 15) / 16);
+        hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex);
     }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }

@@ -257,10 +257,17 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
     }
     __syncthreads();
     if (!s_last) return;
-    if (tid >= 64 && tid < 73) {                                 // dL/dlights: fixed-order sum of the workgroup partials
-        float sum = 0.f;
-        for (int k = 0; k < a.blocks_per_image; ++k) sum += a.dl_part[((size_t)b * a.blocks_per_image + k) * 12 + (tid - 64)];
-        a.grad_lights[b * 9 + (tid - 64)] = sum;
+    {   // dL/dlights: sum of the pixel-backward workgroup partials; waves 1..3 take 3 components each, lanes stride over
+        // the partials (independent loads), fixed butterfly order
+        const int wv = tid >> 6, ln = tid & 63;
+        if (wv >= 1) {
+            for (int i = (wv - 1) * 3; i < (wv - 1) * 3 + 3; ++i) {
+                float sum = 0.f;
+                for (int k = ln; k < a.blocks_per_image; k += 64) sum += a.dl_part[((size_t)b * a.blocks_per_image + k) * 12 + i];
+                sum = wave_sum(sum);
+                if (ln == 0) a.grad_lights[b * 9 + i] = sum;
+            }
+        }
     }
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
     if (tid == 0) {

@@ -8,7 +8,7 @@
 //   1. pixel_bwd   pixel-major, one lane per pixel: re-shades the pixel, writes dL/dbg, reduces dL/dlights per
 //                  workgroup (plain stores of partials), and leaves for every covered pixel the nine numbers the gather
 //                  needs: d/d(texture sample rgb), d/d(mask), d/d(u,v), d/d(normal).
-//   2a. texture_gather  one workgroup per (image, 32x32-texel texture tile), the tile's accumulators in LDS.  The faces
+//   2a. texture_gather  one workgroup per (image, 16x16-texel texture tile), the tile's accumulators in LDS.  The faces
 //                  that can sample the tile are a STATIC list (mm_build_uv_tiles).  16 lanes sweep each face's screen box;
 //                  the pixels it owns add their bilinear footprint to the LDS tile (LDS float adds).  The tile is then
 //                  written once with plain stores: no zero-fill pass over grad_textures.
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 //    issued together (these loops are latency-bound: a dependent HBM/L2 load per step).
 // ---------------------------------------------------------------------------------------------------------------------
 #define MM_TS MM_UV_TILE
-#define MM_SWEEP 4
+#define MM_SWEEP 8              // pixels per lane per trip: 128-pixel boxes (nearly every face) finish in one trip
 
 __device__ inline float group16_sum(float v) {
 #pragma unroll
@@ -216,16 +216,16 @@ struct __attribute__((aligned(16))) FaceSlot {
 
 struct __attribute__((aligned(16))) SweepStage {
     FaceSlot slot[4];
-    unsigned char items[4 * 64];     // (sweep slot << 6) | lane
+    unsigned short items[MM_SWEEP * 64];   // (sweep slot << 6) | lane
 };
 
 // ballot-compaction of four per-lane flags into an ordered LDS item list; returns the item count (wave-uniform)
-__device__ inline int compact4(const bool (&flag)[MM_SWEEP], int lane, unsigned char* items) {
+__device__ inline int compact4(const bool (&flag)[MM_SWEEP], int lane, unsigned short* items) {
     int base = 0;
 #pragma unroll
     for (int i = 0; i < MM_SWEEP; ++i) {
         const unsigned long long m = __ballot(flag[i]);
-        if (flag[i]) items[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)((i << 6) | lane);
+        if (flag[i]) items[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((i << 6) | lane);
         base += __popcll(m);
     }
     return base;
@@ -246,7 +246,7 @@ __device__ inline void item_pixel(const SweepStage* st, unsigned it, int base, i
     box_pixel(base + i * 16 + (l & 15), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
 }
 
-// 2a. texture gradient: one workgroup per (image, 32x32-texel tile), accumulators in LDS, every texel written once.
+// 2a. texture gradient: one workgroup per (image, 16x16-texel tile), accumulators in LDS, every texel written once.
 //     Each wave sweeps four faces at a time (16 lanes each, 4 pixels per lane per trip, loads issued together); the owned
 //     pixels found in a trip are ballot-compacted and finished by all 64 lanes.
 __device__ inline void texture_gather_block(const BwdArgs& a, int block, float (*s_acc)[MM_TS * MM_TS], SweepStage* s_stage) {

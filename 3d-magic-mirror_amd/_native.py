@@ -40,7 +40,7 @@ class MMReconDesc(ctypes.Structure):
                 ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p)]
 
 PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "bin")
-UV_TILE = 16
+UV_TILE = 32
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",

@@ -8,7 +8,7 @@
 //   1. pixel_bwd   pixel-major, one lane per pixel: re-shades the pixel, writes dL/dbg, reduces dL/dlights per
 //                  workgroup (plain stores of partials), and leaves for every covered pixel the nine numbers the gather
 //                  needs: d/d(texture sample rgb), d/d(mask), d/d(u,v), d/d(normal).
-//   2a. texture_gather  one workgroup per (image, 16x16-texel texture tile), the tile's accumulators in LDS.  The faces
+//   2a. texture_gather  one workgroup per (image, 32x32-texel texture tile), the tile's accumulators in LDS.  The faces
 //                  that can sample the tile are a STATIC list (mm_build_uv_tiles).  16 lanes sweep each face's screen box;
 //                  the pixels it owns add their bilinear footprint to the LDS tile (LDS float adds).  The tile is then
 //                  written once with plain stores: no zero-fill pass over grad_textures.
@@ -246,7 +246,7 @@ __device__ inline void item_pixel(const SweepStage* st, unsigned it, int base, i
     box_pixel(base + i * 16 + (l & 15), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
 }
 
-// 2a. texture gradient: one workgroup per (image, 16x16-texel tile), accumulators in LDS, every texel written once.
+// 2a. texture gradient: one workgroup per (image, 32x32-texel tile), accumulators in LDS, every texel written once.
 //     Each wave sweeps four faces at a time (16 lanes each, 4 pixels per lane per trip, loads issued together); the owned
 //     pixels found in a trip are ballot-compacted and finished by all 64 lanes.
 __device__ inline void texture_gather_block(const BwdArgs& a, int block, float (*s_acc)[MM_TS * MM_TS], SweepStage* s_stage) {

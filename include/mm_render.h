@@ -141,7 +141,7 @@ int mm_recon_data_backward(const MMReconDesc* desc, mm_stream_t stream);
  * its uv triangle (+1 texel) can touch; exactly one of those entries carries bit 31 (the face's primary tile).
  * Query: items == NULL -> *needed receives the number of entries.  offsets: (ntiles+1) with
  * ntiles = ceil(Wt/MM_UV_TILE) * ceil(Ht/MM_UV_TILE). */
-#define MM_UV_TILE 16
+#define MM_UV_TILE 32
 int mm_build_uv_tiles(int32_t F, const float* face_uvs_host, int32_t Ht, int32_t Wt, int32_t* offsets_host,
                       int32_t* items_host, int64_t capacity, int64_t* needed);
 /* Build the vertex -> corner CSR from HOST faces (F,3).  offsets: (V+1), items: (3F).  Returns MM_OK or an error. */

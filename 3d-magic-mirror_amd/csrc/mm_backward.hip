@@ -36,6 +36,7 @@ struct BwdArgs {
     float* dl_part;
     float* grad_bg;
     float* dTacc; unsigned* ticket;
+    int* tcnt; TexRecord* trec; int ntiles_;
     // gather
     const int32_t* uvt_offsets; const int32_t* uvt_faces;
     int ntx, nty;
@@ -71,6 +72,8 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     float dl[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) dl[i] = 0.f;
+    TexRecord rec; rec.xy = 0; rec.tx = rec.ty = rec.d0 = rec.d1 = rec.d2 = 0.f;
+    int rtile[4] = {-1, -1, -1, -1};
 
     if (in_img && (hf >= 0 || kNoMask)) {
         // recompute the forward quantities of this pixel (only face_idx and the soft-mask state were saved)
@@ -148,6 +151,35 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             a.gp0[pix] = make_float4(dtcv[0], dtcv[1], dtcv[2], dm);
             a.gp1[pix] = make_float4(du, dv, dnx, dny);
             a.gp2[pix] = dnz;
+            if (dtcv[0] != 0.f || dtcv[1] != 0.f || dtcv[2] != 0.f) {
+                rec.xy = (unsigned)s.x0 | ((unsigned)s.y0 << 16); rec.tx = s.tx; rec.ty = s.ty;
+                rec.d0 = dtcv[0]; rec.d1 = dtcv[1]; rec.d2 = dtcv[2];
+                // texture tiles under the bilinear footprint: up to 2x2 when it straddles a tile border
+                const int tcx0 = s.x0 / MM_UV_TILE, tcy0 = s.y0 / MM_UV_TILE;
+                const int tcx1 = (s.x1 < a.Wt ? s.x1 : s.x0) / MM_UV_TILE, tcy1 = (s.y1 < a.Ht ? s.y1 : s.y0) / MM_UV_TILE;
+                rtile[0] = tcy0 * a.ntx + tcx0;
+                rtile[1] = tcx1 != tcx0 ? tcy0 * a.ntx + tcx1 : -1;
+                rtile[2] = tcy1 != tcy0 ? tcy1 * a.ntx + tcx0 : -1;
+                rtile[3] = (tcx1 != tcx0 && tcy1 != tcy0) ? tcy1 * a.ntx + tcx1 : -1;
+            }
+        }
+    }
+    // append the records: one returning atomic per (wave, distinct tile), lanes of the same tile take consecutive slots
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        unsigned long long pending = __ballot(rtile[c] >= 0);
+        while (pending) {
+            const int leader = __ffsll((unsigned long long)pending) - 1;
+            const int tile = __shfl(rtile[c], leader, 64);
+            const unsigned long long m = __ballot(rtile[c] == tile);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(a.tcnt + (size_t)b * a.ntiles_ + tile, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (rtile[c] == tile) {
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < MM_TREC_CAP) a.trec[((size_t)b * a.ntiles_ + tile) * MM_TREC_CAP + slot] = rec;
+            }
+            pending &= ~m;
         }
     }
 
@@ -258,10 +290,34 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, float (
     for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) (&s_acc[0][0])[i] = 0.f;
     __syncthreads();
     const int tx0 = (T % a.ntx) * MM_TS, ty0 = (T / a.ntx) * MM_TS;
-    const int beg = a.uvt_offsets[T], end = a.uvt_offsets[T + 1];
     const int grp = lane >> 4, sl = lane & 15;
     const size_t hw = (size_t)a.H * a.W;
-
+    const int nrec = a.tcnt[(size_t)b * ntiles + T];
+    if (nrec <= MM_TREC_CAP) {
+        // ---- normal path: stream the records the pixel pass appended for this tile
+        const TexRecord* recs = a.trec + ((size_t)b * ntiles + T) * MM_TREC_CAP;
+        for (int r = tid; r < nrec; r += 256) {
+            const TexRecord rc = recs[r];
+            const int x0 = (int)(rc.xy & 0xFFFFu), y0 = (int)(rc.xy >> 16);
+            const int lx0 = x0 - tx0, lx1 = lx0 + 1, ly0 = y0 - ty0, ly1 = ly0 + 1;
+            const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && x0 + 1 < a.Wt;
+            const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && y0 + 1 < a.Ht;
+            const float ex = 1.f - rc.tx, ey = 1.f - rc.ty;
+            const float wnw = ex * ey, wne = rc.tx * ey, wsw = ex * rc.ty, wse = rc.tx * rc.ty;
+            const float dt[3] = {rc.d0, rc.d1, rc.d2};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (dt[c] != 0.f) {
+                    if (cx0 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx0], dt[c] * wnw);
+                    if (cx1 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx1], dt[c] * wne);
+                    if (cx0 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx0], dt[c] * wsw);
+                    if (cx1 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx1], dt[c] * wse);
+                }
+            }
+        }
+    }
+    // ---- overflow path (more than MM_TREC_CAP records): rediscover the tile's pixels by sweeping its faces' boxes
+    const int beg = nrec <= MM_TREC_CAP ? 0 : a.uvt_offsets[T], end = nrec <= MM_TREC_CAP ? 0 : a.uvt_offsets[T + 1];
     for (int k0 = beg + wave * 4; k0 < end; k0 += 16) {          // wave-uniform: four list entries per step
         const int k = k0 + grp;
         int f = -1; FaceBox fb; fb.npx = 0; fb.bw = 1; fb.px0 = fb.py0 = 0; fb.inv_bw = 1.f;
@@ -478,9 +534,11 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.face_idx = d->face_idx; a.softq = w.softq; a.lastf = w.lastf; a.grad_rgba = g->grad_rgba;
     a.gp0 = w.gp0; a.gp1 = w.gp1; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.dTacc = w.dTacc; a.ticket = w.ticket;
+    a.tcnt = w.tcnt; a.trec = w.trec; a.ntiles_ = w.ntiles;
     a.uvt_offsets = d->uvt_offsets; a.uvt_faces = d->uvt_faces;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures; a.dfxy = w.dfxy; a.dfn = w.dfn;
+    if (hipMemsetAsync(w.tcnt, 0, (size_t)d->B * w.ntiles * sizeof(int), s) != hipSuccess) return MM_ERR_LAUNCH;
     {
         ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
         dim3 grid(a.blocks_per_image * d->B);

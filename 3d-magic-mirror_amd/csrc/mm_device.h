@@ -36,6 +36,13 @@ __host__ __device__ inline int bin_shift_for(int H, int W, int F) {
     return 5;
 }
 
+// One covered pixel's contribution to the texture gradient, appended by the pixel backward to the list of every texture
+// tile its bilinear footprint touches; the tile's workgroup streams its list (no search, no atomics on HBM).
+struct TexRecord { unsigned xy; float tx, ty, d0, d1, d2; };       // xy = x0 | y0 << 16 (top-left texel)
+#ifndef MM_TREC_CAP
+#define MM_TREC_CAP 2048      // records per tile; a tile that overflows falls back to sweeping its faces' boxes
+#endif
+
 // ---- workspace carving (all offsets multiples of 256 bytes) ---------------------------------------------------------
 struct Workspace {
     float* T;              // (B,12)     camera transform [R;t], row-major (4,3)
@@ -54,6 +61,9 @@ struct Workspace {
     float* gp2;            // (B,H,W)    {dnz}
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
+    int* tcnt;             // (B,ntiles)  texture-gradient records appended per texture tile (zeroed every backward)
+    TexRecord* trec;       // (B,ntiles,MM_TREC_CAP)
+    int ntiles;
     int bin_shift, nbx, nby, words;
     size_t binmask_bytes;
     size_t bytes;
@@ -61,7 +71,7 @@ struct Workspace {
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-__host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, int H, int W) {
+__host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, int H, int W, int Ht, int Wt) {
     Workspace w;
     char* p = (char*)base;
     size_t o = 0;
@@ -85,6 +95,9 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.gp2 = (float*)(p + o);        o += align256((size_t)B * H * W * sizeof(float));
     w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
+    w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
+    w.tcnt = (int*)(p + o);         o += align256((size_t)B * w.ntiles * sizeof(int));
+    w.trec = (TexRecord*)(p + o);   o += align256((size_t)B * w.ntiles * MM_TREC_CAP * sizeof(TexRecord));
     w.bytes = o;
     return w;
 }

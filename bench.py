@@ -132,6 +132,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_value = float(step.loss) if args.mode != "torch" else None
+    # the same K steps strictly one after the other on one stream (no overlap between steps), for reference
+    one_stream = None
+    if args.mode == "eager" and args.streams > 1:
+        torch.cuda.synchronize(dev); barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step.run()
+        torch.cuda.synchronize(dev); barrier()
+        e1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e1], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e1 = float(t.item())
+        one_stream = round(world * B * args.steps / e1, 1)
 
     # ---- per-kernel durations (HIP events recorded by the library around each launch, same stream) ------------
     roofline, kernels_us = None, {}

@@ -4,7 +4,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out/stats
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python /root/repo/bench.py --mode eager --cpu-seconds 0 --profile-steps 0 --steps 50 --warmup 5 ${BENCH_ARGS:-} > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python /root/repo/bench.py --mode eager --streams 1 --cpu-seconds 0 --profile-steps 0 --steps 50 --warmup 5 ${BENCH_ARGS:-} > $OUT/bench.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('/root/repo/gpurun_out/stats/*kernel_stats.csv')[0]

@@ -8,12 +8,13 @@
 //   1. pixel_bwd   pixel-major, one lane per pixel: re-shades the pixel, writes dL/dbg, reduces dL/dlights per
 //                  workgroup (plain stores of partials), and leaves for every covered pixel the nine numbers the gather
 //                  needs: d/d(texture sample rgb), d/d(mask), d/d(u,v), d/d(normal).
-//                  It also APPENDS each covered pixel's texture contribution to the record list of every texture tile its
-//                  bilinear footprint touches (one returning atomic per wave and distinct tile, lanes take consecutive slots).
-//   2a. texture_gather  one workgroup per (image, 32x32-texel texture tile) streams its record list into LDS accumulators
-//                  (LDS float adds) and writes the tile once with plain stores: no zero-fill pass over grad_textures.
-//   2b. face_accum  one 1024-thread workgroup per (image, face range) keeps its faces' gradients in LDS: adds the K2
-//                  contributions of all covered pixels, replays the forward's soft-mask batches for K4, stores once per face.
+//   2a. texture_gather  one workgroup per (image, 32x32-texel texture tile), the tile's accumulators in LDS.  The faces
+//                  that can sample the tile are a STATIC list (mm_build_uv_tiles).  16 lanes sweep each face's screen box;
+//                  the pixels it owns add their bilinear footprint to the LDS tile (LDS float adds).  The tile is then
+//                  written once with plain stores: no zero-fill pass over grad_textures.
+//   2b. face_gather  16 lanes per (image, face) sweep the face's inflated screen box: pixels it owns give the K2
+//                  barycentric gradient, uncovered pixels that hold the face among their first knum soft-mask faces give
+//                  K4.  dL/d(face xy) and dL/d(face normal) are written once per face with plain stores.
 #include "mm_device.h"
 
 namespace mm {
@@ -35,8 +36,7 @@ struct BwdArgs {
     float* dl_part;
     float* grad_bg;
     float* dTacc; unsigned* ticket;
-    int* tcnt; TexRecord* trec; TexSpill* tspill; int ntiles_;
-    const int* sb_cnt; const uint64_t* sb_mask; const int* sb_ids; const int* sb_over; int tiles8_x, tiles8;
+    int* tcnt; TexRecord* trec; int ntiles_;
     // gather
     const int32_t* uvt_offsets; const int32_t* uvt_faces;
     int ntx, nty;
@@ -79,10 +79,9 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
         // recompute the forward quantities of this pixel (only face_idx and the soft-mask state were saved)
         float w0 = 0.f, w1 = 0.f, w2 = 0.f, nrm = 1.f, m = 0.f, u = 0.f, v = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
         float fu[6] = {0, 0, 0, 0, 0, 0}, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
         if (hf >= 0) {
             const float4* geo = a.geo + ((size_t)b * a.F + hf) * 3;
-            p0 = geo[0]; p1 = geo[1];
+            const float4 p0 = geo[0], p1 = geo[1];
             edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
             w0 /= nrm; w1 /= nrm; w2 /= nrm;
             const float* fuv = a.face_uvs + (size_t)hf * 6;
@@ -149,20 +148,9 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             const float dnx = dc * (((MM_SH_C1 * L[1] + MM_SH_C4 * ny * L[4]) + MM_SH_C7 * nz * L[7]) + 2.f * MM_SH_C8 * nx * L[8]);
             const float dny = dc * (((MM_SH_C1 * L[3] + MM_SH_C4 * nx * L[4]) + MM_SH_C4 * nz * L[5]) - 2.f * MM_SH_C8 * ny * L[8]);
             const float dnz = dc * (((MM_SH_C1 * L[2] + MM_SH_C4 * ny * L[5]) + 2.f * MM_SH_C6 * nz * L[6]) + MM_SH_C7 * nx * L[7]);
-            // K2 (Appendix A.1): this pixel's contribution to its face's corner and normal gradients; corner features are
-            // (1, u_k, v_k, n).  Stored per pixel; the per-image accumulation pass adds them up per face.
-            const float gnn = (dnx * n0 + dny * n1) + dnz * n2;
-            const float G0 = ((dm + du * fu[0]) + dv * fu[1]) + gnn;
-            const float G1 = ((dm + du * fu[2]) + dv * fu[3]) + gnn;
-            const float G2 = ((dm + du * fu[4]) + dv * fu[5]) + gnn;
-            const float Gm = (w0 * G0 + w1 * G1) + w2 * G2;
-            const float dw0 = (G0 - Gm) / nrm, dw1 = (G1 - Gm) / nrm, dw2 = (G2 - Gm) / nrm;
-            const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
-            a.gp0[pix] = make_float4((dw1 * (-cey) + dw2 * bey) * a.mult, (dw1 * cex + dw2 * (-bex)) * a.mult,
-                                     (dw0 * cey + dw2 * (-aey)) * a.mult, (dw0 * (-cex) + dw2 * aex) * a.mult);
-            a.gp1[pix] = make_float4((dw0 * (-bey) + dw1 * aey) * a.mult, (dw0 * bex + dw1 * (-aex)) * a.mult,
-                                     (w0 * dnx + w1 * dnx) + w2 * dnx, (w0 * dny + w1 * dny) + w2 * dny);
-            a.gp2[pix] = (w0 * dnz + w1 * dnz) + w2 * dnz;
+            a.gp0[pix] = make_float4(dtcv[0], dtcv[1], dtcv[2], dm);
+            a.gp1[pix] = make_float4(du, dv, dnx, dny);
+            a.gp2[pix] = dnz;
             if (dtcv[0] != 0.f || dtcv[1] != 0.f || dtcv[2] != 0.f) {
                 rec.xy = (unsigned)s.x0 | ((unsigned)s.y0 << 16); rec.tx = s.tx; rec.ty = s.ty;
                 rec.d0 = dtcv[0]; rec.d1 = dtcv[1]; rec.d2 = dtcv[2];
@@ -190,11 +178,6 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             if (rtile[c] == tile) {
                 const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (slot < MM_TREC_CAP) a.trec[((size_t)b * a.ntiles_ + tile) * MM_TREC_CAP + slot] = rec;
-                else {                                          // full tile (rare): the image's spill list
-                    const int os = atomicAdd(a.tcnt + (size_t)a.B * a.ntiles_ + b, 1);
-                    TexSpill sp; sp.r = rec; sp.tile = tile; sp.pad = 0;
-                    a.tspill[(size_t)b * 4 * a.H * a.W + os] = sp;
-                }
             }
             pending &= ~m;
         }
@@ -214,48 +197,187 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 2a. texture gradient: one workgroup per (image, 32x32-texel tile) streams the records the pixel pass appended for the
-//     tile into LDS accumulators and writes every texel of the tile once (no zero-fill pass, no HBM atomics).
+// 2. gathers.  Both sweep a face's screen box with 16 lanes, four pixels per lane per trip with the loads of a trip
+//    issued together (these loops are latency-bound: a dependent HBM/L2 load per step).
 // ---------------------------------------------------------------------------------------------------------------------
 #define MM_TS MM_UV_TILE
+#define MM_SWEEP 8              // pixels per lane per trip: 128-pixel boxes (nearly every face) finish in one trip
 
-__device__ inline void tex_accumulate(const BwdArgs& a, float (*s_acc)[MM_TS * MM_TS], const TexRecord& rc, int tx0, int ty0) {
-    const int x0 = (int)(rc.xy & 0xFFFFu), y0 = (int)(rc.xy >> 16);
-    const int lx0 = x0 - tx0, lx1 = lx0 + 1, ly0 = y0 - ty0, ly1 = ly0 + 1;
-    const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && x0 + 1 < a.Wt;
-    const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && y0 + 1 < a.Ht;
-    const float ex = 1.f - rc.tx, ey = 1.f - rc.ty;
-    const float wnw = ex * ey, wne = rc.tx * ey, wsw = ex * rc.ty, wse = rc.tx * rc.ty;
-    const float dt[3] = {rc.d0, rc.d1, rc.d2};
+__device__ inline float group16_sum(float v) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (dt[c] != 0.f) {
-            if (cx0 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx0], dt[c] * wnw);
-            if (cx1 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx1], dt[c] * wne);
-            if (cx0 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx0], dt[c] * wsw);
-            if (cx1 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx1], dt[c] * wse);
-        }
-    }
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
 }
 
-__global__ __launch_bounds__(256) void texture_gather_kernel(BwdArgs a) {
-    __shared__ float s_acc[3][MM_TS * MM_TS];
+struct FaceBox { float4 p0, p1; float xmin, ymin, xmax, ymax; int px0, py0, bw, npx; float inv_bw; };
+
+__device__ inline FaceBox face_box(const BwdArgs& a, size_t o, float pad) {
+    FaceBox fb;
+    fb.p0 = a.geo[o * 3 + 0]; fb.p1 = a.geo[o * 3 + 1];
+    fb.xmin = fminf(fminf(fb.p0.x, fb.p0.z), fb.p1.x); fb.ymin = fminf(fminf(fb.p0.y, fb.p0.w), fb.p1.y);
+    fb.xmax = fmaxf(fmaxf(fb.p0.x, fb.p0.z), fb.p1.x); fb.ymax = fmaxf(fmaxf(fb.p0.y, fb.p0.w), fb.p1.y);
+    int px1, py1;
+    pixel_range(fb.xmin - pad, fb.xmax + pad, a.mult, a.W, false, fb.px0, px1);
+    pixel_range(fb.ymin - pad, fb.ymax + pad, a.mult, a.H, true, fb.py0, py1);
+    fb.bw = px1 - fb.px0 + 1;
+    const int bh = py1 - fb.py0 + 1;
+    fb.npx = (fb.bw > 0 && bh > 0) ? fb.bw * bh : 0;
+    fb.inv_bw = 1.f / (float)(fb.bw > 0 ? fb.bw : 1);
+    return fb;
+}
+
+// pixel #idx of a box swept row-major (idx < 2^22: the float quotient is exact enough to be fixed up by one compare)
+__device__ inline void box_pixel(int idx, int px0, int py0, int bw, float inv_bw, int& px, int& py) {
+    int yy = (int)(((float)idx + 0.5f) * inv_bw);
+    if (yy * bw > idx) --yy;
+    if ((yy + 1) * bw <= idx) ++yy;
+    px = px0 + (idx - yy * bw); py = py0 + yy;
+}
+
+// What a wave keeps in LDS about the (up to) four faces its four 16-lane groups sweep, so that ANY lane can finish a
+// compacted work item of any of them.
+struct __attribute__((aligned(16))) FaceSlot {
+    float4 p0, p1;                   // ax,ay,bx,by | cx,cy,az,bz  (multiplier units)
+    float box[4];                    // xmin, ymin, xmax, ymax
+    float fu[6];                     // corner uvs
+    float n[3];                      // unit normal
+    int px0, py0, bw, f;
+    float inv_bw;
+    float acc[9];                    // dL/d(ax,ay,bx,by,cx,cy), dL/d(n)
+};
+
+struct __attribute__((aligned(16))) SweepStage {
+    FaceSlot slot[4];
+    unsigned short items[MM_SWEEP * 64];   // (sweep slot << 6) | lane
+};
+
+// ballot-compaction of four per-lane flags into an ordered LDS item list; returns the item count (wave-uniform)
+__device__ inline int compact4(const bool (&flag)[MM_SWEEP], int lane, unsigned short* items) {
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < MM_SWEEP; ++i) {
+        const unsigned long long m = __ballot(flag[i]);
+        if (flag[i]) items[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((i << 6) | lane);
+        base += __popcll(m);
+    }
+    return base;
+}
+
+__device__ inline void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// pixel index of item `it` of the current trip: the item names the sweeping lane (hence its 16-lane group = face slot and
+// its position in the box walk)
+__device__ inline void item_pixel(const SweepStage* st, unsigned it, int base, int& g, int& px, int& py) {
+    const int l = it & 63, i = it >> 6;
+    g = l >> 4;
+    const FaceSlot& fs = st->slot[g];
+    box_pixel(base + i * 16 + (l & 15), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
+}
+
+// 2a. texture gradient: one workgroup per (image, 32x32-texel tile), accumulators in LDS, every texel written once.
+//     Each wave sweeps four faces at a time (16 lanes each, 4 pixels per lane per trip, loads issued together); the owned
+//     pixels found in a trip are ballot-compacted and finished by all 64 lanes.
+__device__ inline void texture_gather_block(const BwdArgs& a, int block, float (*s_acc)[MM_TS * MM_TS], SweepStage* s_stage) {
     const int ntiles = a.ntx * a.nty;
     int b, T;
-    map_block(blockIdx.x, a.B, ntiles, b, T);
-    const int tid = threadIdx.x;
+    map_block(block, a.B, ntiles, b, T);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SweepStage* st = &s_stage[wave];
     for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) (&s_acc[0][0])[i] = 0.f;
     __syncthreads();
     const int tx0 = (T % a.ntx) * MM_TS, ty0 = (T / a.ntx) * MM_TS;
+    const int grp = lane >> 4, sl = lane & 15;
+    const size_t hw = (size_t)a.H * a.W;
     const int nrec = a.tcnt[(size_t)b * ntiles + T];
-    const TexRecord* recs = a.trec + ((size_t)b * ntiles + T) * MM_TREC_CAP;
-    for (int r = tid; r < min(nrec, MM_TREC_CAP); r += 256) tex_accumulate(a, s_acc, recs[r], tx0, ty0);
-    if (nrec > MM_TREC_CAP) {                                    // the tile's list was full: its remaining records are in the spill list
-        const int nsp = a.tcnt[(size_t)a.B * ntiles + b];
-        const TexSpill* sp = a.tspill + (size_t)b * 4 * a.H * a.W;
-        for (int r = tid; r < nsp; r += 256) if (sp[r].tile == T) tex_accumulate(a, s_acc, sp[r].r, tx0, ty0);
+    if (nrec <= MM_TREC_CAP) {
+        // ---- normal path: stream the records the pixel pass appended for this tile
+        const TexRecord* recs = a.trec + ((size_t)b * ntiles + T) * MM_TREC_CAP;
+        for (int r = tid; r < nrec; r += 256) {
+            const TexRecord rc = recs[r];
+            const int x0 = (int)(rc.xy & 0xFFFFu), y0 = (int)(rc.xy >> 16);
+            const int lx0 = x0 - tx0, lx1 = lx0 + 1, ly0 = y0 - ty0, ly1 = ly0 + 1;
+            const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && x0 + 1 < a.Wt;
+            const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && y0 + 1 < a.Ht;
+            const float ex = 1.f - rc.tx, ey = 1.f - rc.ty;
+            const float wnw = ex * ey, wne = rc.tx * ey, wsw = ex * rc.ty, wse = rc.tx * rc.ty;
+            const float dt[3] = {rc.d0, rc.d1, rc.d2};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (dt[c] != 0.f) {
+                    if (cx0 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx0], dt[c] * wnw);
+                    if (cx1 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx1], dt[c] * wne);
+                    if (cx0 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx0], dt[c] * wsw);
+                    if (cx1 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx1], dt[c] * wse);
+                }
+            }
+        }
+    }
+    // ---- overflow path (more than MM_TREC_CAP records): rediscover the tile's pixels by sweeping its faces' boxes
+    const int beg = nrec <= MM_TREC_CAP ? 0 : a.uvt_offsets[T], end = nrec <= MM_TREC_CAP ? 0 : a.uvt_offsets[T + 1];
+    for (int k0 = beg + wave * 4; k0 < end; k0 += 16) {          // wave-uniform: four list entries per step
+        const int k = k0 + grp;
+        int f = -1; FaceBox fb; fb.npx = 0; fb.bw = 1; fb.px0 = fb.py0 = 0; fb.inv_bw = 1.f;
+        if (k < end) {
+            f = a.uvt_faces[k] & 0x7FFFFFFF;
+            fb = face_box(a, (size_t)b * a.F + f, 0.f);          // owned pixels lie inside the face's own box
+            if (sl == 0) {
+                FaceSlot& fs = st->slot[grp];
+                fs.p0 = fb.p0; fs.p1 = fb.p1; fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f;
+                const float* fu = a.face_uvs + (size_t)f * 6;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) fs.fu[i] = fu[i];
+            }
+        }
+        int nmax = fb.npx;
+        nmax = max(nmax, __shfl_xor(nmax, 16, 64)); nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+        wave_sync_lds();
+        for (int base = 0; base < nmax; base += 16 * MM_SWEEP) {
+            bool own[MM_SWEEP];
+#pragma unroll
+            for (int i = 0; i < MM_SWEEP; ++i) {
+                const int idx = base + i * 16 + sl;
+                int px, py;
+                box_pixel(idx, fb.px0, fb.py0, fb.bw, fb.inv_bw, px, py);
+                own[i] = idx < fb.npx && a.face_idx[(size_t)b * hw + (size_t)py * a.W + px] == f;
+            }
+            const int n = compact4(own, lane, st->items);
+            wave_sync_lds();
+            for (int j = lane; j < n; j += 64) {
+                int g, px, py;
+                item_pixel(st, st->items[j], base, g, px, py);
+                const FaceSlot& fs = st->slot[g];
+                const size_t pix = (size_t)b * hw + (size_t)py * a.W + px;
+                const float4 q0 = a.gp0[pix];
+                const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
+                float w0, w1, w2, nrm;
+                edge_weights(fs.p0.x, fs.p0.y, fs.p0.z, fs.p0.w, fs.p1.x, fs.p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
+                w0 /= nrm; w1 /= nrm; w2 /= nrm;
+                const float u = (w0 * fs.fu[0] + w1 * fs.fu[2]) + w2 * fs.fu[4];
+                const float v = (w0 * fs.fu[1] + w1 * fs.fu[3]) + w2 * fs.fu[5];
+                const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
+                const int lx0 = s.x0 - tx0, lx1 = s.x1 - tx0, ly0 = s.y0 - ty0, ly1 = s.y1 - ty0;
+                const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && s.x1 < a.Wt;
+                const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && s.y1 < a.Ht;
+                const float dt[3] = {q0.x, q0.y, q0.z};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (dt[c] != 0.f) {
+                        if (cx0 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx0], dt[c] * s.wnw);
+                        if (cx1 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx1], dt[c] * s.wne);
+                        if (cx0 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx0], dt[c] * s.wsw);
+                        if (cx1 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx1], dt[c] * s.wse);
+                    }
+                }
+            }
+            wave_sync_lds();
+        }
     }
     __syncthreads();
+    // write the tile once (also where nothing landed: no separate zero-fill of grad_textures)
     for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) {
         const int c = i / (MM_TS * MM_TS), r = i - c * (MM_TS * MM_TS);
         const int ly = r / MM_TS, lx = r - ly * MM_TS;
@@ -264,133 +386,142 @@ __global__ __launch_bounds__(256) void texture_gather_kernel(BwdArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// 2b. per-face gradients: one 1024-thread workgroup per (image, range of <= Fr faces) keeps dL/d(face corner xy) and
-//     dL/d(face normal) of its faces in LDS and adds into them with LDS float adds:
-//       K2: every covered pixel's nine contributions, computed by the pixel pass;
-//       K4 (Appendix A.2): for every uncovered pixel with a live soft-mask gradient, the faces it took in the forward --
-//           replayed from the (tile, batch) masks and id tables the forward kept, one wave per 8x8 tile.
-//     Then one plain store per face.  Images in which a tile needed more than MM_SB_CAP batches redo the forward's rule
-//     directly (all faces in index order, first knum whose inflated box holds the pixel).
-// ---------------------------------------------------------------------------------------------------------------------
-#define MM_FA_THREADS 1024
-#define MM_FA_WAVES (MM_FA_THREADS / 64)
-
-struct __attribute__((aligned(16))) K4Stage { float4 p0[64], p1[64]; int ids[64]; };
-
-// adds d(soft)/d(face f) for pixel (x0,y0): ga = dL/dalpha, sq = forward product state, p0/p1 = face xy
-__device__ inline void k4_accumulate(const BwdArgs& a, float* acc9, float x0, float y0, const float4& p0, const float4& p1, float ga, float sq) {
+// 2b. per-face gradients: 16 lanes per (image, face) sweep the face's inflated box; pixels it owns give the K2 barycentric
+//     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The two kinds of hits are
+//     ballot-compacted per wave (four faces) and finished by all 64 lanes into per-face LDS accumulators; one plain store
+//     per face at the end.
+__device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage* s_stage) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4, sl = lane & 15;
+    SweepStage* st = &s_stage[wave];
+    const long long gid = (long long)block * 16 + (threadIdx.x >> 4);
+    const bool live = gid < (long long)a.B * a.F;
+    const int b = live ? (int)(gid / a.F) : 0, f = live ? (int)(gid - (long long)b * a.F) : 0;
+    const size_t o = (size_t)b * a.F + f, hw = (size_t)a.H * a.W;
     const float s2 = a.mult * a.mult;
-    int r, ty;
-    float d = seg_dist2(x0, y0, p0.x, p0.y, p0.z, p0.w, ty);
-    const float d1 = seg_dist2(x0, y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
-    const float d2 = seg_dist2(x0, y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
-    const float p = expf(-((d / s2) * a.sigmainv));
-    const float q = 1.f - p;
-    const float qnz = fabsf(sq);
-    const bool onezero = sq < 0.f;
-    const float excl = (q != 0.f) ? (onezero ? 0.f : qnz / q) : (onezero ? qnz : 0.f);
-    const float gd = ga * excl * (-(p * a.sigmainv) / s2);
-    if (gd == 0.f) return;
-    const int e = ty / 3, reg = ty - e * 3;
-    const float ux = e == 0 ? p0.x : (e == 1 ? p0.z : p1.x), uy = e == 0 ? p0.y : (e == 1 ? p0.w : p1.y);
-    const float wx = e == 0 ? p0.z : (e == 1 ? p1.x : p0.x), wy = e == 0 ? p0.w : (e == 1 ? p1.y : p0.y);
-    float dux = 0.f, duy = 0.f, dvx = 0.f, dvy = 0.f;
-    if (reg == 0) { dux = -2.f * (x0 - ux); duy = -2.f * (y0 - uy); }
-    else if (reg == 2) { dvx = -2.f * (x0 - wx); dvy = -2.f * (y0 - wy); }
-    else {
-        const float ex = wx - ux, ey = wy - uy, rx = x0 - ux, ry = y0 - uy;
-        const float tt = (rx * ex + ry * ey) / (ex * ex + ey * ey);
-        const float qx = x0 - (ux + tt * ex), qy = y0 - (uy + tt * ey);
-        dux = -2.f * (1.f - tt) * qx; duy = -2.f * (1.f - tt) * qy;
-        dvx = -2.f * tt * qx; dvy = -2.f * tt * qy;
+    FaceBox fb = face_box(a, o, a.infl);
+    if (!live) fb.npx = 0;
+    if (sl == 0) {
+        FaceSlot& fs = st->slot[grp];
+        fs.p0 = fb.p0; fs.p1 = fb.p1; fs.box[0] = fb.xmin; fs.box[1] = fb.ymin; fs.box[2] = fb.xmax; fs.box[3] = fb.ymax;
+        fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f;
+        const float* fu = a.face_uvs + (size_t)f * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) fs.fu[i] = fu[i];
+        const float* nn = a.fn + o * 3;
+        fs.n[0] = nn[0]; fs.n[1] = nn[1]; fs.n[2] = nn[2];
     }
-    const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;          // edge e runs from corner e to corner (e+1)%3
-    atomicAdd(acc9 + iu, gd * dux * a.mult); atomicAdd(acc9 + iu + 1, gd * duy * a.mult);
-    atomicAdd(acc9 + iv, gd * dvx * a.mult); atomicAdd(acc9 + iv + 1, gd * dvy * a.mult);
+    if (sl < 9) st->slot[grp].acc[sl] = 0.f;
+    int nmax = fb.npx;
+    nmax = max(nmax, __shfl_xor(nmax, 16, 64)); nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+    wave_sync_lds();
+
+    for (int base = 0; base < nmax; base += 16 * MM_SWEEP) {
+        bool own[MM_SWEEP], opn[MM_SWEEP];
+#pragma unroll
+        for (int i = 0; i < MM_SWEEP; ++i) {
+            const int idx = base + i * 16 + sl;
+            int px, py;
+            box_pixel(idx, fb.px0, fb.py0, fb.bw, fb.inv_bw, px, py);
+            const int fi = idx < fb.npx ? a.face_idx[(size_t)b * hw + (size_t)py * a.W + px] : -2;
+            own[i] = fi == f; opn[i] = fi == -1;
+        }
+        // ---- K2 (Appendix A.1) for the pixels these faces own: features per corner k = (1, u_k, v_k, n)
+        int n = compact4(own, lane, st->items);
+        wave_sync_lds();
+        for (int j = lane; j < n; j += 64) {
+            int g, px, py;
+            item_pixel(st, st->items[j], base, g, px, py);
+            FaceSlot& fs = st->slot[g];
+            const int bb = (int)(((long long)block * 16 + wave * 4 + g) / a.F);
+            const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
+            const float4 q0 = a.gp0[pix], q1 = a.gp1[pix];
+            const float dnz = a.gp2[pix];
+            const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
+            const float4 p0 = fs.p0, p1 = fs.p1;
+            float w0, w1, w2, nrm;
+            edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
+            w0 /= nrm; w1 /= nrm; w2 /= nrm;
+            const float dm = q0.w, du = q1.x, dv = q1.y, dnx = q1.z, dny = q1.w;
+            const float gnn = (dnx * fs.n[0] + dny * fs.n[1]) + dnz * fs.n[2];
+            const float G0 = ((dm + du * fs.fu[0]) + dv * fs.fu[1]) + gnn;
+            const float G1 = ((dm + du * fs.fu[2]) + dv * fs.fu[3]) + gnn;
+            const float G2 = ((dm + du * fs.fu[4]) + dv * fs.fu[5]) + gnn;
+            const float Gm = (w0 * G0 + w1 * G1) + w2 * G2;
+            const float dw0 = (G0 - Gm) / nrm, dw1 = (G1 - Gm) / nrm, dw2 = (G2 - Gm) / nrm;
+            const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
+            atomicAdd(&fs.acc[0], (dw1 * (-cey) + dw2 * bey) * a.mult);
+            atomicAdd(&fs.acc[1], (dw1 * cex + dw2 * (-bex)) * a.mult);
+            atomicAdd(&fs.acc[2], (dw0 * cey + dw2 * (-aey)) * a.mult);
+            atomicAdd(&fs.acc[3], (dw0 * (-cex) + dw2 * aex) * a.mult);
+            atomicAdd(&fs.acc[4], (dw0 * (-bey) + dw1 * aey) * a.mult);
+            atomicAdd(&fs.acc[5], (dw0 * bex + dw1 * (-aex)) * a.mult);
+            atomicAdd(&fs.acc[6], (w0 * dnx + w1 * dnx) + w2 * dnx);
+            atomicAdd(&fs.acc[7], (w0 * dny + w1 * dny) + w2 * dny);
+            atomicAdd(&fs.acc[8], (w0 * dnz + w1 * dnz) + w2 * dnz);
+        }
+        wave_sync_lds();
+        // ---- K4 (Appendix A.2) for uncovered pixels that may hold one of these faces among their first knum faces
+        n = compact4(opn, lane, st->items);
+        wave_sync_lds();
+        for (int j = lane; j < n; j += 64) {
+            int g, px, py;
+            item_pixel(st, st->items[j], base, g, px, py);
+            FaceSlot& fs = st->slot[g];
+            const int bb = (int)(((long long)block * 16 + wave * 4 + g) / a.F);
+            const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
+            const float sq = a.softq[pix];
+            const int lf = a.lastf[pix];
+            const float ga = a.grad_rgba[pix * 4 + 3];
+            const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
+            if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= lf &&
+                !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl)) {
+                const float4 p0 = fs.p0, p1 = fs.p1;
+                int r, ty;
+                float d = seg_dist2(x0, y0, p0.x, p0.y, p0.z, p0.w, ty);
+                const float d1 = seg_dist2(x0, y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
+                const float d2 = seg_dist2(x0, y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
+                const float p = expf(-((d / s2) * a.sigmainv));
+                const float q = 1.f - p;
+                const float qnz = fabsf(sq);
+                const bool onezero = sq < 0.f;
+                const float excl = (q != 0.f) ? (onezero ? 0.f : qnz / q) : (onezero ? qnz : 0.f);
+                const float gd = ga * excl * (-(p * a.sigmainv) / s2);
+                if (gd != 0.f) {
+                    const int e = ty / 3, reg = ty - e * 3;
+                    const float ux = e == 0 ? p0.x : (e == 1 ? p0.z : p1.x), uy = e == 0 ? p0.y : (e == 1 ? p0.w : p1.y);
+                    const float wx = e == 0 ? p0.z : (e == 1 ? p1.x : p0.x), wy = e == 0 ? p0.w : (e == 1 ? p1.y : p0.y);
+                    float dux = 0.f, duy = 0.f, dvx = 0.f, dvy = 0.f;
+                    if (reg == 0) { dux = -2.f * (x0 - ux); duy = -2.f * (y0 - uy); }
+                    else if (reg == 2) { dvx = -2.f * (x0 - wx); dvy = -2.f * (y0 - wy); }
+                    else {
+                        const float ex = wx - ux, ey = wy - uy, rx = x0 - ux, ry = y0 - uy;
+                        const float tt = (rx * ex + ry * ey) / (ex * ex + ey * ey);
+                        const float qx = x0 - (ux + tt * ex), qy = y0 - (uy + tt * ey);
+                        dux = -2.f * (1.f - tt) * qx; duy = -2.f * (1.f - tt) * qy;
+                        dvx = -2.f * tt * qx; dvy = -2.f * tt * qy;
+                    }
+                    // edge e runs from corner e to corner (e+1)%3
+                    const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;
+                    atomicAdd(&fs.acc[iu], gd * dux * a.mult); atomicAdd(&fs.acc[iu + 1], gd * duy * a.mult);
+                    atomicAdd(&fs.acc[iv], gd * dvx * a.mult); atomicAdd(&fs.acc[iv + 1], gd * dvy * a.mult);
+                }
+            }
+        }
+        wave_sync_lds();
+    }
+    if (live && sl < 9) {
+        const float v = st->slot[grp].acc[sl];
+        if (sl < 6) a.dfxy[o * 6 + sl] = v; else a.dfn[o * 3 + (sl - 6)] = v;
+    }
 }
 
-__global__ __launch_bounds__(MM_FA_THREADS) void face_accum_kernel(BwdArgs a, int Fr, int R) {
-    extern __shared__ __attribute__((aligned(16))) char s_raw[];
-    K4Stage* stage = (K4Stage*)s_raw;                            // one per wave
-    float* acc = (float*)(s_raw + MM_FA_WAVES * sizeof(K4Stage)); // (Fr, 9)
-    const int b = blockIdx.x / R, r = blockIdx.x - b * R;
-    const int f_lo = r * Fr, f_hi = min(a.F, f_lo + Fr), nf = f_hi - f_lo;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hw = a.H * a.W;
-    for (int i = tid; i < nf * 9; i += MM_FA_THREADS) acc[i] = 0.f;
-    __syncthreads();
-
-    // ---- K2: stream the image's pixels, four per thread per trip so that the loads of a trip are in flight together
-    for (int base = 0; base < hw; base += MM_FA_THREADS * 4) {
-        int fi[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const int p = base + k * MM_FA_THREADS + tid; fi[k] = p < hw ? a.face_idx[(size_t)b * hw + p] : -1; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (fi[k] >= f_lo && fi[k] < f_hi) {
-                const size_t pix = (size_t)b * hw + base + k * MM_FA_THREADS + tid;
-                const float4 q0 = a.gp0[pix], q1 = a.gp1[pix];
-                const float q2 = a.gp2[pix];
-                float* o = acc + (size_t)(fi[k] - f_lo) * 9;
-                atomicAdd(o + 0, q0.x); atomicAdd(o + 1, q0.y); atomicAdd(o + 2, q0.z); atomicAdd(o + 3, q0.w);
-                atomicAdd(o + 4, q1.x); atomicAdd(o + 5, q1.y); atomicAdd(o + 6, q1.z); atomicAdd(o + 7, q1.w);
-                atomicAdd(o + 8, q2);
-            }
-        }
-    }
-
-    // ---- K4: one wave per 8x8 pixel tile, lane = pixel
-    const bool slow = a.sb_over[b] != 0;
-    K4Stage* st = stage + wave;
-    for (int tile = wave; tile < a.tiles8; tile += MM_FA_WAVES) {
-        const int nb = a.sb_cnt[(size_t)b * a.tiles8 + tile];
-        if (nb == 0 && !slow) continue;
-        const int px = (tile % a.tiles8_x) * MM_TILE + (lane & 7), py = (tile / a.tiles8_x) * MM_TILE + (lane >> 3);
-        const bool in_img = px < a.W && py < a.H;
-        const size_t pix = (size_t)b * hw + (size_t)py * a.W + px;
-        float sq = 0.f, ga = 0.f;
-        if (in_img && a.face_idx[pix] < 0) { sq = a.softq[pix]; ga = a.grad_rgba[pix * 4 + 3]; }
-        const bool active = sq != 0.f && sq != 1.f && ga != 0.f;
-        if (__ballot(active) == 0) continue;
-        const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
-        if (!slow) {
-            const size_t row = ((size_t)b * a.tiles8 + tile) * MM_SB_CAP;
-            for (int i = 0; i < nb; ++i) {
-                uint64_t m = active ? a.sb_mask[(row + i) * 64 + lane] : 0;
-                const int id = a.sb_ids[(row + i) * 64 + lane];
-                st->ids[lane] = id;
-                if (id >= 0) { st->p0[lane] = a.geo[((size_t)b * a.F + id) * 3]; st->p1[lane] = a.geo[((size_t)b * a.F + id) * 3 + 1]; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                while (__ballot(m != 0)) {
-                    if (m) {
-                        const int j = __ffsll((unsigned long long)m) - 1;
-                        m &= m - 1;
-                        const int f = st->ids[j];
-                        if (f >= f_lo && f < f_hi) k4_accumulate(a, acc + (size_t)(f - f_lo) * 9, x0, y0, st->p0[j], st->p1[j], ga, sq);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        } else if (active) {
-            // slow path: the forward's rule restated -- faces in index order, first knum whose inflated box holds the pixel
-            int cnt = 0;
-            for (int f = 0; f < a.F && cnt < a.knum; ++f) {
-                const float4 p0 = a.geo[((size_t)b * a.F + f) * 3], p1 = a.geo[((size_t)b * a.F + f) * 3 + 1];
-                const float xmin = fminf(fminf(p0.x, p0.z), p1.x), ymin = fminf(fminf(p0.y, p0.w), p1.y);
-                const float xmax = fmaxf(fmaxf(p0.x, p0.z), p1.x), ymax = fmaxf(fmaxf(p0.y, p0.w), p1.y);
-                if (x0 < xmin - a.infl || x0 > xmax + a.infl || y0 < ymin - a.infl || y0 > ymax + a.infl) continue;
-                ++cnt;
-                if (f >= f_lo && f < f_hi) k4_accumulate(a, acc + (size_t)(f - f_lo) * 9, x0, y0, p0, p1, ga, sq);
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < nf * 9; i += MM_FA_THREADS) {
-        const int f = i / 9, c = i - f * 9;
-        const size_t o = (size_t)b * a.F + f_lo + f;
-        if (c < 6) a.dfxy[o * 6 + c] = acc[i]; else a.dfn[o * 3 + (c - 6)] = acc[i];
-    }
+// One launch for both gathers: they only depend on the pixel pass, and each is latency-bound with a long tail, so their
+// workgroups are interleaved in a single grid (texture tiles first: they are the heavier ones).
+__global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
+    __shared__ float s_acc[3][MM_TS * MM_TS];
+    __shared__ SweepStage s_stage[4];
+    if ((int)blockIdx.x < ntex) texture_gather_block(a, blockIdx.x, s_acc, s_stage);
+    else face_gather_block(a, blockIdx.x - ntex, s_stage);
 }
 
 int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
@@ -403,12 +534,11 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.face_idx = d->face_idx; a.softq = w.softq; a.lastf = w.lastf; a.grad_rgba = g->grad_rgba;
     a.gp0 = w.gp0; a.gp1 = w.gp1; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.dTacc = w.dTacc; a.ticket = w.ticket;
-    a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;
-    a.sb_cnt = w.sb_cnt; a.sb_mask = w.sb_mask; a.sb_ids = w.sb_ids; a.sb_over = w.sb_over; a.tiles8_x = w.tiles8_x; a.tiles8 = w.tiles8;
+    a.tcnt = w.tcnt; a.trec = w.trec; a.ntiles_ = w.ntiles;
     a.uvt_offsets = d->uvt_offsets; a.uvt_faces = d->uvt_faces;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures; a.dfxy = w.dfxy; a.dfn = w.dfn;
-    if (hipMemsetAsync(w.tcnt, 0, ((size_t)d->B * w.ntiles + d->B) * sizeof(int), s) != hipSuccess) return MM_ERR_LAUNCH;
+    if (hipMemsetAsync(w.tcnt, 0, (size_t)d->B * w.ntiles * sizeof(int), s) != hipSuccess) return MM_ERR_LAUNCH;
     {
         ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
         dim3 grid(a.blocks_per_image * d->B);
@@ -418,15 +548,9 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     if (hipGetLastError() != hipSuccess) return MM_ERR_LAUNCH;
     {
         ProfScope p(d->prof_events, MM_PROF_GATHER_BWD, s);
-        hipLaunchKernelGGL(texture_gather_kernel, dim3(a.ntx * a.nty * d->B), dim3(256), 0, s, a);
-        // faces per workgroup: as many as fit in LDS beside the 16 per-wave K4 stages (160 KiB per CU, keep two resident)
-        const int Fr = d->F < 1536 ? d->F : 1536;
-        const int R = (d->F + Fr - 1) / Fr;
-        const size_t lds = MM_FA_WAVES * sizeof(K4Stage) + (size_t)Fr * 9 * sizeof(float);
-        if (lds > 64 * 1024 &&
-            hipFuncSetAttribute((const void*)face_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MM_ERR_LAUNCH;
-        hipLaunchKernelGGL(face_accum_kernel, dim3(d->B * R), dim3(MM_FA_THREADS), lds, s, a, Fr, R);
+        const int ntex = a.ntx * a.nty * d->B;
+        const unsigned nface = (unsigned)(((long long)d->B * d->F + 15) / 16);
+        hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex);
     }
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
 }

@@ -39,13 +39,8 @@ __host__ __device__ inline int bin_shift_for(int H, int W, int F) {
 // One covered pixel's contribution to the texture gradient, appended by the pixel backward to the list of every texture
 // tile its bilinear footprint touches; the tile's workgroup streams its list (no search, no atomics on HBM).
 struct TexRecord { unsigned xy; float tx, ty, d0, d1, d2; };       // xy = x0 | y0 << 16 (top-left texel)
-struct TexSpill { TexRecord r; int tile; int pad; };
 #ifndef MM_TREC_CAP
-#define MM_TREC_CAP 2048      // records per tile; further records of a full tile go to the image's spill list
-#endif
-
-#ifndef MM_SB_CAP
-#define MM_SB_CAP 8            // soft-mask batches kept per 8x8 tile for the backward; beyond that the image takes the slow path
+#define MM_TREC_CAP 2048      // records per tile; a tile that overflows falls back to sweeping its faces' boxes
 #endif
 
 // ---- workspace carving (all offsets multiples of 256 bytes) ---------------------------------------------------------
@@ -66,15 +61,8 @@ struct Workspace {
     float* gp2;            // (B,H,W)    {dnz}
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
-    int* sb_cnt;           // (B,tiles8)  soft-mask batches stored for the backward per 8x8 pixel tile
-    uint64_t* sb_mask;     // (B,tiles8,MM_SB_CAP,64) per pixel: which of the batch's 64 candidates it took (after the knum cut)
-    int* sb_ids;           // (B,tiles8,MM_SB_CAP,64) face id of every candidate of the batch
-    int* sb_over;          // (B)         set when a tile of the image needed more than MM_SB_CAP batches
-    int tiles8_x, tiles8;
-    int* tcnt;             // (B,ntiles)+(B) texture-gradient records appended per texture tile, then per-image overflow counts
-                           //             (zeroed every backward)
+    int* tcnt;             // (B,ntiles)  texture-gradient records appended per texture tile (zeroed every backward)
     TexRecord* trec;       // (B,ntiles,MM_TREC_CAP)
-    TexSpill* tspill;      // (B,4*H*W)   records of tiles whose list is full (worst case: every pixel, 2x2 tiles)
     int ntiles;
     int bin_shift, nbx, nby, words;
     size_t binmask_bytes;
@@ -107,14 +95,8 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.gp2 = (float*)(p + o);        o += align256((size_t)B * H * W * sizeof(float));
     w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
-    w.tiles8_x = (W + MM_TILE - 1) / MM_TILE; w.tiles8 = w.tiles8_x * ((H + MM_TILE - 1) / MM_TILE);
-    w.sb_cnt = (int*)(p + o);       o += align256((size_t)B * w.tiles8 * sizeof(int));
-    w.sb_mask = (uint64_t*)(p + o); o += align256((size_t)B * w.tiles8 * MM_SB_CAP * 64 * sizeof(uint64_t));
-    w.sb_ids = (int*)(p + o);       o += align256((size_t)B * w.tiles8 * MM_SB_CAP * 64 * sizeof(int));
-    w.sb_over = (int*)(p + o);      o += align256((size_t)B * sizeof(int));
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
-    w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + B) * sizeof(int));
-    w.tspill = (TexSpill*)(p + o);  o += align256((size_t)B * 4 * H * W * sizeof(TexSpill));
+    w.tcnt = (int*)(p + o);         o += align256((size_t)B * w.ntiles * sizeof(int));
     w.trec = (TexRecord*)(p + o);   o += align256((size_t)B * w.ntiles * MM_TREC_CAP * sizeof(TexRecord));
     w.bytes = o;
     return w;

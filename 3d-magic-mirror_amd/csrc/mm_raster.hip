@@ -38,7 +38,6 @@ struct RasterArgs {
     const float* bg;
     float* softq;
     int* lastf;
-    int* sb_cnt; uint64_t* sb_mask; int* sb_ids; int* sb_over; int tiles8_x, tiles8;
     // outputs
     float* rgba;
     int32_t* face_idx;
@@ -295,8 +294,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
     // K3: soft silhouette for the lanes no front face covers.  prod(1-p) is order-free, so it is accumulated per pixel
     // as an integer sum of log2(1-p) in 2^-32 fixed point (exact, commutative LDS adds) plus a count of exact zeros.
     float qnz = 1.f;
-    int zeros = 0, lastf = 0x7FFFFFFF, nstored = 0;
-    const size_t tile8 = (size_t)t.b * a.tiles8 + (size_t)(t.ty0 / MM_TILE) * a.tiles8_x + t.tx0 / MM_TILE;
+    int zeros = 0, lastf = 0x7FFFFFFF;
     const bool open = t.in_img && h.f < 0;
     if (__ballot(open)) {
         int cnt = 0;
@@ -307,13 +305,6 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
             sm = soft_take(sm, open, a.knum - cnt);              // pixel-major: the first knum hits of this pixel, in order
             cnt += __popcll(sm);
             if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);   // knum-th face taken
-            if (__ballot(sm != 0)) {                             // keep the batch for the backward: who took which candidate
-                if (nstored < MM_SB_CAP) {
-                    a.sb_mask[(tile8 * MM_SB_CAP + nstored) * 64 + t.lane] = sm;
-                    a.sb_ids[(tile8 * MM_SB_CAP + nstored) * 64 + t.lane] = t.lane < n ? __float_as_int(st->p2[t.lane].z) : -1;
-                }
-                ++nstored;
-            }
             pair_parallel(t, st, sm, [&](int l, int j, bool live) {   // pixel l of the tile, candidate j of the batch
                 const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
                 int ty;
@@ -329,10 +320,6 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
         wave_lds_sync();
         zeros = st->zeros[t.lane];
         qnz = exp2f((float)((double)st->logsum[t.lane] * (1.0 / 4294967296.0)));
-    }
-    if (t.lane == 0 && t.tx0 < a.W && t.ty0 < a.H) {
-        a.sb_cnt[tile8] = nstored;
-        if (nstored > MM_SB_CAP) a.sb_over[t.b] = 1;
     }
     if (!t.in_img) return;
 
@@ -395,7 +382,6 @@ static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.geo = w.geo; a.binmask = w.binmask; a.binmask_hard = w.binmask_hard; a.softq = w.softq; a.lastf = w.lastf;
-    a.sb_cnt = w.sb_cnt; a.sb_mask = w.sb_mask; a.sb_ids = w.sb_ids; a.sb_over = w.sb_over; a.tiles8_x = w.tiles8_x; a.tiles8 = w.tiles8;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     return a;

@@ -19,7 +19,6 @@ struct VertexFwdArgs {
     float* T;
     float4* geo;
     float* face_normals;
-    int* sb_over;
 };
 
 __device__ inline void block_camera(const float* azim, const float* elev, const float* dist, const float* bias, int b,
@@ -41,7 +40,6 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     const int b = blockIdx.y, tid = threadIdx.x;
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
     if (blockIdx.x == 0 && tid < 12) a.T[b * 12 + tid] = s_cam.T[tid];
-    if (blockIdx.x == 0 && tid == 12) a.sb_over[b] = 0;          // raised by the raster stage when a tile overflows
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_cam.T[i];
@@ -289,7 +287,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2]; a.mult = d->multiplier;
     a.faces = d->faces; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
-    a.T = w.T; a.geo = w.geo; a.face_normals = d->face_normals; a.sb_over = w.sb_over;
+    a.T = w.T; a.geo = w.geo; a.face_normals = d->face_normals;
     dim3 grid((d->F + 255) / 256, d->B);
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
       hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }

@@ -25,7 +25,8 @@ class MMRenderDesc(ctypes.Structure):
                 ("vertices", c_p), ("textures", c_p), ("lights", c_p), ("bg", c_p), ("azimuths", c_p), ("elevations", c_p),
                 ("distances", c_p), ("biases", c_p),
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
-                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p)]
+                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p),
+                ("fused_gt", c_p), ("fused_image_weight", c_f), ("fused_loss", c_p), ("fused_grad_loss", c_p)]
 
 
 class MMRenderGrads(ctypes.Structure):

@@ -49,7 +49,7 @@ int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
 int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {
     int st = check_render(d, true);
     if (st != MM_OK) return st;
-    if (!g || !g->grad_rgba || !g->grad_vertices || !g->grad_textures || !g->grad_lights || !g->grad_azimuths ||
+    if (!g || (!g->grad_rgba && !d->fused_gt) || !g->grad_vertices || !g->grad_textures || !g->grad_lights || !g->grad_azimuths ||
         !g->grad_elevations || !g->grad_distances || !g->grad_biases)
         return MM_ERR_NULL_POINTER;
     if (d->no_mask && !g->grad_bg) return MM_ERR_NULL_POINTER;

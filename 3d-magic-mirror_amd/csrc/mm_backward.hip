@@ -37,6 +37,8 @@ struct BwdArgs {
     float* grad_bg;
     float* dTacc; unsigned* ticket;
     int* tcnt; TexRecord* trec; int ntiles_;
+    // fused recon_data (gt == nullptr: off)
+    const float* gt; const float4* lpart; const float* rgba; const float* grad_loss; float* loss; float image_weight;
     // gather
     const int32_t* uvt_offsets; const int32_t* uvt_faces;
     int ntx, nty;
@@ -67,7 +69,52 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int hf = -1;
-    if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
+    if (a.gt) {
+        // fused recon_data backward (Appendix A.4): totals of this image = fixed-order sum of its raster-workgroup partials
+        __shared__ float s_tot[MM_BLOCK_WAVES][4];
+        __shared__ float s_loss[MM_BLOCK_WAVES][3];
+        const int nparts = 4 * a.blocks_per_image;
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = threadIdx.x; k < nparts; k += 256) { const float4 q = a.lpart[(size_t)b * nparts + k]; t1 += q.y; t2 += q.z; }
+        t1 = wave_sum(t1); t2 = wave_sum(t2);
+        if (lane == 0) { s_tot[wave][0] = t1; s_tot[wave][1] = t2; }
+        __syncthreads();
+        const float up = ((s_tot[0][0] + s_tot[1][0]) + s_tot[2][0]) + s_tot[3][0];
+        const float U = (((s_tot[0][1] + s_tot[1][1]) + s_tot[2][1]) + s_tot[3][1]) + 1e-10f;
+        const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
+        const float cnt = (float)a.B * 3.f * (float)a.H * (float)a.W;
+        if (in_img) {
+            hf = a.face_idx[pix];
+            const float4 pr = *(const float4*)(a.rgba + pix * 4);
+            const float* g = a.gt + (size_t)b * 4 * hw;
+            const float gm = g[3 * hw + pin];
+            float gq[3];
+            const float prc[3] = {pr.x, pr.y, pr.z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gi = g[c * hw + pin] * gm + 1.f * (1.f - gm);
+                const float pi = prc[c] * gm + 1.f * (1.f - gm);
+                const float df = pi - gi, sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+                gq[c] = gs * a.image_weight * sg * gm / cnt;
+            }
+            g4 = make_float4(gq[0], gq[1], gq[2], gs * (-(1.f / (float)a.B) * (gm / U - up * (1.f - gm) / (U * U))));
+        }
+        if (a.loss && blockIdx.x == 0) {                          // the loss value itself, once per launch
+            float l1 = 0.f, iou = 0.f;
+            for (int bb = 0; bb < a.B; ++bb) {
+                float p1 = 0.f, p2 = 0.f, p3 = 0.f;
+                for (int k = threadIdx.x; k < nparts; k += 256) { const float4 q = a.lpart[(size_t)bb * nparts + k]; p1 += q.x; p2 += q.y; p3 += q.z; }
+                p1 = wave_sum(p1); p2 = wave_sum(p2); p3 = wave_sum(p3);
+                __syncthreads();
+                if (lane == 0) { s_loss[wave][0] = p1; s_loss[wave][1] = p2; s_loss[wave][2] = p3; }
+                __syncthreads();
+                l1 += ((s_loss[0][0] + s_loss[1][0]) + s_loss[2][0]) + s_loss[3][0];
+                iou += (((s_loss[0][1] + s_loss[1][1]) + s_loss[2][1]) + s_loss[3][1]) /
+                       ((((s_loss[0][2] + s_loss[1][2]) + s_loss[2][2]) + s_loss[3][2]) + 1e-10f);
+            }
+            if (threadIdx.x == 0) a.loss[0] = a.image_weight * (l1 / cnt) + 1.f * (1.f - iou / (float)a.B);
+        }
+    } else if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
     const float gin[3] = {g4.x, g4.y, g4.z};
     float dl[9];
 #pragma unroll
@@ -535,6 +582,8 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.gp0 = w.gp0; a.gp1 = w.gp1; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.dTacc = w.dTacc; a.ticket = w.ticket;
     a.tcnt = w.tcnt; a.trec = w.trec; a.ntiles_ = w.ntiles;
+    a.gt = d->fused_gt; a.lpart = w.lpart; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
+    a.image_weight = d->fused_image_weight;
     a.uvt_offsets = d->uvt_offsets; a.uvt_faces = d->uvt_faces;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures; a.dfxy = w.dfxy; a.dfn = w.dfn;

@@ -38,6 +38,7 @@ struct RasterArgs {
     const float* bg;
     float* softq;
     int* lastf;
+    const float* gt; float4* lpart;          // fused recon_data partial sums (gt == nullptr: off)
     // outputs
     float* rgba;
     int32_t* face_idx;
@@ -59,7 +60,7 @@ struct __attribute__((aligned(16))) WaveStage {
 };
 
 struct TileCtx {
-    int b, px, py, tx0, ty0, lane, wave;
+    int b, blk, px, py, tx0, ty0, lane, wave;
     bool in_img;
     float x0, y0;
     float xs[MM_TILE], ys[MM_TILE];         // pixel-centre columns / rows of the tile (same in every lane)
@@ -73,6 +74,7 @@ __device__ inline TileCtx make_tile(const RasterArgs& a) {
     // one wave per workgroup (a slow tile then never pins the LDS of three finished neighbours); four consecutive
     // workgroups are the 2x2 tiles of one 16x16 block
     map_block(blockIdx.x >> 2, a.B, a.blocks_per_image, t.b, blk);
+    t.blk = blk;
     t.lane = threadIdx.x & 63; t.wave = blockIdx.x & 3;
     const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
     const int tx0 = bx * MM_BLOCK_PX + (t.wave & 1) * MM_TILE, ty0 = by * MM_BLOCK_PX + (t.wave >> 1) * MM_TILE;
@@ -321,10 +323,12 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
         zeros = st->zeros[t.lane];
         qnz = exp2f((float)((double)st->logsum[t.lane] * (1.0 / 4294967296.0)));
     }
-    if (!t.in_img) return;
+    if (!t.in_img && !a.gt) return;
 
     // ---- shading (a9-a11).  Uncovered pixels carry zero features exactly like kaolin's interpolated_features.
-    const size_t pix = ((size_t)t.b * a.H + t.py) * a.W + t.px;
+    // (lanes outside a ragged image only stay for the fused loss reduction: they address a clamped pixel and store nothing)
+    const int cpx = min(t.px, a.W - 1), cpy = min(t.py, a.H - 1);
+    const size_t pix = ((size_t)t.b * a.H + cpy) * a.W + cpx;
     float m = 0.f, u = 0.f, v = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
     if (h.f >= 0) {
         const float* fu = a.face_uvs + (size_t)h.f * 6;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) coef += bnd[i] * L[i];
     float out[4];
-    const size_t hw = (size_t)a.H * a.W, pin = (size_t)t.py * a.W + t.px;
+    const size_t hw = (size_t)a.H * a.W, pin = (size_t)cpy * a.W + cpx;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* tex = a.textures + ((size_t)t.b * 3 + c) * a.Ht * a.Wt;
@@ -367,11 +371,29 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
     }
     const float keepprod = zeros > 0 ? 0.f : qnz;
     out[3] = (h.f >= 0) ? 1.f : (1.f - keepprod);
-    *(float4*)(a.rgba + pix * 4) = make_float4(out[0], out[1], out[2], out[3]);
-    a.face_idx[pix] = h.f;
-    a.softq[pix] = (h.f >= 0 || zeros >= 2) ? 0.f : (zeros == 1 ? -qnz : qnz);
-    if (h.f < 0) a.lastf[pix] = lastf;
-    if (a.imnormal) { a.imnormal[pix * 3] = nx; a.imnormal[pix * 3 + 1] = ny; a.imnormal[pix * 3 + 2] = nz; }
+    if (t.in_img) {
+        *(float4*)(a.rgba + pix * 4) = make_float4(out[0], out[1], out[2], out[3]);
+        a.face_idx[pix] = h.f;
+        a.softq[pix] = (h.f >= 0 || zeros >= 2) ? 0.f : (zeros == 1 ? -qnz : qnz);
+        if (h.f < 0) a.lastf[pix] = lastf;
+        if (a.imnormal) { a.imnormal[pix * 3] = nx; a.imnormal[pix * 3 + 1] = ny; a.imnormal[pix * 3 + 2] = nz; }
+    }
+    if (a.gt) {                                                  // recon_data terms of this tile (networks.py:370-377)
+        float l1 = 0.f, up = 0.f, down = 0.f;
+        if (t.in_img) {
+            const float* g = a.gt + (size_t)t.b * 4 * hw;
+            const float gm = g[3 * hw + pin];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gi = g[c * hw + pin] * gm + 1.f * (1.f - gm);
+                const float pi = out[c] * gm + 1.f * (1.f - gm);
+                l1 += fabsf(pi - gi);
+            }
+            up = out[3] * gm; down = (out[3] + gm) - up;
+        }
+        l1 = wave_sum(l1); up = wave_sum(up); down = wave_sum(down);
+        if (t.lane == 0) a.lpart[((size_t)t.b * a.blocks_per_image + t.blk) * 4 + t.wave] = make_float4(l1, up, down, 0.f);
+    }
 }
 
 static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
@@ -381,7 +403,7 @@ static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
     a.blocks_per_image = w.blocks_per_image;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
-    a.geo = w.geo; a.binmask = w.binmask; a.binmask_hard = w.binmask_hard; a.softq = w.softq; a.lastf = w.lastf;
+    a.geo = w.geo; a.binmask = w.binmask; a.binmask_hard = w.binmask_hard; a.softq = w.softq; a.lastf = w.lastf; a.gt = d->fused_gt; a.lpart = w.lpart;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     return a;

@@ -75,6 +75,13 @@ class RenderLossStep:
         self.rws = torch.empty(N.lib().mm_recon_query_workspace(ctypes.byref(r)), device=dev, dtype=torch.uint8)
         r.workspace, r.workspace_bytes = N.ptr(self.rws), self.rws.numel()
         self.r = r
+        # fused mode: recon_data (contour = 0) folded into the render kernels (MMRenderDesc.fused_*): two ABI calls per step
+        self.fused = bool(fused) and not contour
+        if self.fused:
+            self.d.fused_gt = N.ptr(self.gt)
+            self.d.fused_image_weight = float(dr.image_weight)
+            self.d.fused_loss = N.ptr(self.loss)
+            self.d.fused_grad_loss = N.ptr(self.loss_scale)
         self.graph = None
         self.ev_render = self.ev_recon = None
 
@@ -83,8 +90,9 @@ class RenderLossStep:
         L = N.lib()
         s = ctypes.c_void_p((stream or torch.cuda.current_stream(self.dev)).cuda_stream)
         N.check(L.mm_render_forward(ctypes.byref(self.d), s), "mm_render_forward")
-        N.check(L.mm_recon_data_forward(ctypes.byref(self.r), s), "mm_recon_data_forward")
-        N.check(L.mm_recon_data_backward(ctypes.byref(self.r), s), "mm_recon_data_backward")
+        if not self.fused:
+            N.check(L.mm_recon_data_forward(ctypes.byref(self.r), s), "mm_recon_data_forward")
+            N.check(L.mm_recon_data_backward(ctypes.byref(self.r), s), "mm_recon_data_backward")
         N.check(L.mm_render_backward(ctypes.byref(self.d), ctypes.byref(self.g), s), "mm_render_backward")
 
     def capture(self):
@@ -117,5 +125,6 @@ class RenderLossStep:
     def kernel_times_ms(self):
         """Call after run() + synchronize with profiling enabled."""
         out = {name: self.ev_render.elapsed_ms(i) for i, name in enumerate(N.PROF_RENDER)}
-        out.update({name: self.ev_recon.elapsed_ms(i) for i, name in enumerate(N.PROF_RECON) if name != "recon_contour" or self.r.contour > 0})
+        if not self.fused:
+            out.update({name: self.ev_recon.elapsed_ms(i) for i, name in enumerate(N.PROF_RECON) if name != "recon_contour" or self.r.contour > 0})
         return out

@@ -61,6 +61,7 @@ def main():
                     help="hipgraph: whole step replayed as one HIP graph; eager: 4 ABI calls per step; torch: DiffRender autograd API")
     ap.add_argument("--streams", type=int, default=3,
                     help="successive (independent) steps are enqueued round-robin on this many HIP streams, each with its own buffers")
+    ap.add_argument("--unfused", action="store_true", help="recon_data as its own three launches instead of folded into the render kernels")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--profile-steps", type=int, default=30, help="extra eager steps with per-kernel HIP events")
     args = ap.parse_args()
@@ -95,12 +96,12 @@ def main():
         if world > 1:
             dist.barrier()
 
-    step = stepmod.RenderLossStep(dr, datt, gtd, no_mask=True)
+    step = stepmod.RenderLossStep(dr, datt, gtd, no_mask=True, fused=not args.unfused)
     if args.mode == "hipgraph":
         step.capture()
         one = step.replay
     elif args.mode == "eager" and args.streams > 1:
-        steps_ = [step] + [stepmod.RenderLossStep(dr, datt, gtd, no_mask=True) for _ in range(args.streams - 1)]
+        steps_ = [step] + [stepmod.RenderLossStep(dr, datt, gtd, no_mask=True, fused=not args.unfused) for _ in range(args.streams - 1)]
         streams_ = [torch.cuda.Stream(dev) for _ in steps_]
         ctr = [0]
 

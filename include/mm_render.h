@@ -84,6 +84,14 @@ typedef struct MMRenderDesc {
     /* optional profiling: NULL, or an array of 2*MM_PROF_RENDER_SLOTS hipEvent_t created by the caller; the library
      * records events [2*slot] / [2*slot+1] on the stream immediately before / after the kernel of that slot. */
     void** prof_events;
+    /* optional FUSED reconstruction loss = DiffRender.recon_data with contour = 0 (networks.py:364-378) folded into the render
+     * kernels: with fused_gt set, mm_render_forward also reduces the loss terms while it shades, and mm_render_backward
+     * derives dL/d rgba on the fly (MMRenderGrads.grad_rgba is then ignored and may be NULL) and writes the loss value.
+     * Same arithmetic as mm_recon_data_forward/backward; saves three launches and the grad_rgba round trip. */
+    const float* fused_gt;          /* (B,4,H,W) dense rgb + mask, or NULL */
+    float fused_image_weight;       /* DiffRender.image_weight */
+    float* fused_loss;              /* (1) device scalar, written by mm_render_backward; may be NULL */
+    const float* fused_grad_loss;   /* (1) device scalar dL/dloss, or NULL for 1 */
 } MMRenderDesc;
 
 enum { MM_PROF_VERTEX_FWD = 0, MM_PROF_RASTER_FWD = 1, MM_PROF_PIXEL_BWD = 2, MM_PROF_GATHER_BWD = 3, MM_PROF_VERTEX_BWD = 4,
@@ -93,7 +101,7 @@ enum { MM_PROF_RECON_PARTIAL = 0, MM_PROF_RECON_FINAL = 1, MM_PROF_RECON_BWD = 2
 
 /* Gradients of one render call.  Every non-NULL output is OVERWRITTEN (the library zero-fills what it accumulates). */
 typedef struct MMRenderGrads {
-    const float* grad_rgba;          /* (B,H,W,4) NHWC, dL/d rgba; required */
+    const float* grad_rgba;          /* (B,H,W,4) NHWC, dL/d rgba; required unless MMRenderDesc.fused_gt is set */
     const float* grad_face_normals;  /* (B,F,3) or NULL: dL/d attributes['face_normals'] (used by calc_reg_loss, :422-431) */
     float* grad_vertices;            /* (B,V,3) */
     float* grad_textures;            /* (B,3,Ht,Wt) */

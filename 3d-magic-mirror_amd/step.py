@@ -39,7 +39,7 @@ class HipEvents:
 
 
 class RenderLossStep:
-    def __init__(self, dr, attributes, gt, no_mask=True, contour=0.0, emit_imnormal=False):
+    def __init__(self, dr, attributes, gt, no_mask=True, contour=0.0, emit_imnormal=False, loss_scale=None, fused=False):
         dev = attributes["azimuths"].device
         N.require_device(*[attributes[k] for k in LEAVES if attributes.get(k) is not None], gt)
         self.dr, self.dev, self.no_mask = dr, dev, bool(no_mask)
@@ -71,7 +71,9 @@ class RenderLossStep:
         for k, s in enumerate((H * W * 4, 1, W * 4, 4)):
             r.pred_strides[k] = s
         r.image_weight, r.contour = float(dr.image_weight), float(contour)
-        r.loss, r.grad_loss, r.grad_pred = N.ptr(self.loss), None, N.ptr(self.grad_rgba)
+        # loss_scale: dL/dloss, e.g. B_rank/B_global when several steps share one batch mean
+        self.loss_scale = None if loss_scale is None else torch.full((), float(loss_scale), device=dev)
+        r.loss, r.grad_loss, r.grad_pred = N.ptr(self.loss), N.ptr(self.loss_scale), N.ptr(self.grad_rgba)
         self.rws = torch.empty(N.lib().mm_recon_query_workspace(ctypes.byref(r)), device=dev, dtype=torch.uint8)
         r.workspace, r.workspace_bytes = N.ptr(self.rws), self.rws.numel()
         self.r = r

@@ -39,6 +39,7 @@ struct BwdArgs {
     int* tcnt; TexRecord* trec; int ntiles_;
     // fused recon_data (gt == nullptr: off)
     const float* gt; const float4* lpart; const float* rgba; const float* grad_loss; float* loss; float image_weight;
+    float* ltot;                                                 // (B,2) per image {sum|pi-gi|, IoU}
     // gather
     const int32_t* uvt_offsets; const int32_t* uvt_faces;
     int ntx, nty;
@@ -99,23 +100,20 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             }
             g4 = make_float4(gq[0], gq[1], gq[2], gs * (-(1.f / (float)a.B) * (gm / U - up * (1.f - gm) / (U * U))));
         }
-        if (a.loss && blockIdx.x == 0) {                          // the loss value itself, once per launch
-            float l1 = 0.f, iou = 0.f;
-            for (int bb = 0; bb < a.B; ++bb) {
-                float p1 = 0.f, p2 = 0.f, p3 = 0.f;
-                for (int k = threadIdx.x; k < nparts; k += 256) { const float4 q = a.lpart[(size_t)bb * nparts + k]; p1 += q.x; p2 += q.y; p3 += q.z; }
-                p1 = wave_sum(p1); p2 = wave_sum(p2); p3 = wave_sum(p3);
-                __syncthreads();
-                if (lane == 0) { s_loss[wave][0] = p1; s_loss[wave][1] = p2; s_loss[wave][2] = p3; }
-                __syncthreads();
-                l1 += ((s_loss[0][0] + s_loss[1][0]) + s_loss[2][0]) + s_loss[3][0];
-                iou += (((s_loss[0][1] + s_loss[1][1]) + s_loss[2][1]) + s_loss[3][1]) /
-                       ((((s_loss[0][2] + s_loss[1][2]) + s_loss[2][2]) + s_loss[3][2]) + 1e-10f);
+        if (a.loss && blk == 0) {                                 // this image's loss terms, summed over images by the gather launch
+            float t0 = 0.f;
+            for (int k = threadIdx.x; k < nparts; k += 256) t0 += a.lpart[(size_t)b * nparts + k].x;
+            t0 = wave_sum(t0);
+            if (lane == 0) s_loss[wave][0] = t0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                a.ltot[b * 2 + 0] = ((s_loss[0][0] + s_loss[1][0]) + s_loss[2][0]) + s_loss[3][0];
+                a.ltot[b * 2 + 1] = up / U;
             }
-            if (threadIdx.x == 0) a.loss[0] = a.image_weight * (l1 / cnt) + 1.f * (1.f - iou / (float)a.B);
         }
     } else if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
     const float gin[3] = {g4.x, g4.y, g4.z};
+    if (in_img && hf < 0) a.gp2[pix] = g4.w;                     // the face gather (K4) needs dL/dalpha of uncovered pixels
     float dl[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) dl[i] = 0.f;
@@ -518,7 +516,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
             const float sq = a.softq[pix];
             const int lf = a.lastf[pix];
-            const float ga = a.grad_rgba[pix * 4 + 3];
+            const float ga = a.gp2[pix];                              // dL/dalpha, left by the pixel pass for uncovered pixels
             const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
             if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= lf &&
                 !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl)) {
@@ -567,6 +565,13 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
 __global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
     __shared__ float s_acc[3][MM_TS * MM_TS];
     __shared__ SweepStage s_stage[4];
+    if (a.gt && a.loss && blockIdx.x == 0 && threadIdx.x < 64) {  // fused recon_data value: fixed-order sum over images
+        float l1 = 0.f, iou = 0.f;
+        for (int bb = threadIdx.x; bb < a.B; bb += 64) { l1 += a.ltot[bb * 2]; iou += a.ltot[bb * 2 + 1]; }
+        l1 = wave_sum(l1); iou = wave_sum(iou);
+        if (threadIdx.x == 0)
+            a.loss[0] = a.image_weight * (l1 / ((float)a.B * 3.f * (float)a.H * (float)a.W)) + 1.f * (1.f - iou / (float)a.B);
+    }
     if ((int)blockIdx.x < ntex) texture_gather_block(a, blockIdx.x, s_acc, s_stage);
     else face_gather_block(a, blockIdx.x - ntex, s_stage);
 }
@@ -583,7 +588,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.dTacc = w.dTacc; a.ticket = w.ticket;
     a.tcnt = w.tcnt; a.trec = w.trec; a.ntiles_ = w.ntiles;
     a.gt = d->fused_gt; a.lpart = w.lpart; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
-    a.image_weight = d->fused_image_weight;
+    a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
     a.uvt_offsets = d->uvt_offsets; a.uvt_faces = d->uvt_faces;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures; a.dfxy = w.dfxy; a.dfn = w.dfn;

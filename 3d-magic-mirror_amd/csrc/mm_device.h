@@ -61,6 +61,7 @@ struct Workspace {
     float* gp2;            // (B,H,W)    {dnz}
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
+    float* ltot;           // (B,2)       fused loss: per image {sum|pi-gi|, IoU}
     float4* lpart;         // (B,4*blocks) fused loss: per raster workgroup {sum|pi-gi|, sum p*g, sum p+g-p*g, 0}
     int* tcnt;             // (B,ntiles)  texture-gradient records appended per texture tile (zeroed every backward)
     TexRecord* trec;       // (B,ntiles,MM_TREC_CAP)
@@ -97,6 +98,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
     w.lpart = (float4*)(p + o);     o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(float4));
+    w.ltot = (float*)(p + o);       o += align256((size_t)B * 2 * sizeof(float));
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
     w.tcnt = (int*)(p + o);         o += align256((size_t)B * w.ntiles * sizeof(int));
     w.trec = (TexRecord*)(p + o);   o += align256((size_t)B * w.ntiles * MM_TREC_CAP * sizeof(TexRecord));

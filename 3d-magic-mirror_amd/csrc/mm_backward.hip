@@ -36,7 +36,7 @@ struct BwdArgs {
     float* dl_part;
     float* grad_bg;
     float* dTacc; unsigned* ticket;
-    int* tcnt; TexRecord* trec; int ntiles_;
+    int* tcnt; TexRecord* trec; TexSpill* tspill; int ntiles_;
     // fused recon_data (gt == nullptr: off)
     const float* gt; const float4* lpart; const float* rgba; const float* grad_loss; float* loss; float image_weight;
     float* ltot;                                                 // (B,2) per image {sum|pi-gi|, IoU}
@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
         // recompute the forward quantities of this pixel (only face_idx and the soft-mask state were saved)
         float w0 = 0.f, w1 = 0.f, w2 = 0.f, nrm = 1.f, m = 0.f, u = 0.f, v = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
         float fu[6] = {0, 0, 0, 0, 0, 0}, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
         if (hf >= 0) {
             const float4* geo = a.geo + ((size_t)b * a.F + hf) * 3;
-            const float4 p0 = geo[0], p1 = geo[1];
+            p0 = geo[0]; p1 = geo[1];
             edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
             w0 /= nrm; w1 /= nrm; w2 /= nrm;
             const float* fuv = a.face_uvs + (size_t)hf * 6;
@@ -193,9 +194,20 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             const float dnx = dc * (((MM_SH_C1 * L[1] + MM_SH_C4 * ny * L[4]) + MM_SH_C7 * nz * L[7]) + 2.f * MM_SH_C8 * nx * L[8]);
             const float dny = dc * (((MM_SH_C1 * L[3] + MM_SH_C4 * nx * L[4]) + MM_SH_C4 * nz * L[5]) - 2.f * MM_SH_C8 * ny * L[8]);
             const float dnz = dc * (((MM_SH_C1 * L[2] + MM_SH_C4 * ny * L[5]) + 2.f * MM_SH_C6 * nz * L[6]) + MM_SH_C7 * nx * L[7]);
-            a.gp0[pix] = make_float4(dtcv[0], dtcv[1], dtcv[2], dm);
-            a.gp1[pix] = make_float4(du, dv, dnx, dny);
-            a.gp2[pix] = dnz;
+            // K2 (Appendix A.1): this pixel's contribution to its face's corner and normal gradients; corner features are
+            // (1, u_k, v_k, n).  Left per pixel; the face gather only has to add them up.
+            const float gnn = (dnx * n0 + dny * n1) + dnz * n2;
+            const float G0 = ((dm + du * fu[0]) + dv * fu[1]) + gnn;
+            const float G1 = ((dm + du * fu[2]) + dv * fu[3]) + gnn;
+            const float G2 = ((dm + du * fu[4]) + dv * fu[5]) + gnn;
+            const float Gm = (w0 * G0 + w1 * G1) + w2 * G2;
+            const float dw0 = (G0 - Gm) / nrm, dw1 = (G1 - Gm) / nrm, dw2 = (G2 - Gm) / nrm;
+            const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
+            a.gp0[pix] = make_float4((dw1 * (-cey) + dw2 * bey) * a.mult, (dw1 * cex + dw2 * (-bex)) * a.mult,
+                                     (dw0 * cey + dw2 * (-aey)) * a.mult, (dw0 * (-cex) + dw2 * aex) * a.mult);
+            a.gp1[pix] = make_float4((dw0 * (-bey) + dw1 * aey) * a.mult, (dw0 * bex + dw1 * (-aex)) * a.mult,
+                                     (w0 * dnx + w1 * dnx) + w2 * dnx, (w0 * dny + w1 * dny) + w2 * dny);
+            a.gp2[pix] = (w0 * dnz + w1 * dnz) + w2 * dnz;
             if (dtcv[0] != 0.f || dtcv[1] != 0.f || dtcv[2] != 0.f) {
                 rec.xy = (unsigned)s.x0 | ((unsigned)s.y0 << 16); rec.tx = s.tx; rec.ty = s.ty;
                 rec.d0 = dtcv[0]; rec.d1 = dtcv[1]; rec.d2 = dtcv[2];
@@ -223,6 +235,11 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             if (rtile[c] == tile) {
                 const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (slot < MM_TREC_CAP) a.trec[((size_t)b * a.ntiles_ + tile) * MM_TREC_CAP + slot] = rec;
+                else {                                          // full tile (rare): the image's spill list
+                    const int os = atomicAdd(a.tcnt + (size_t)a.B * a.ntiles_ + b, 1);
+                    TexSpill sp; sp.r = rec; sp.tile = tile; sp.pad = 0;
+                    a.tspill[(size_t)b * 4 * a.H * a.W + os] = sp;
+                }
             }
             pending &= ~m;
         }
@@ -323,103 +340,42 @@ __device__ inline void item_pixel(const SweepStage* st, unsigned it, int base, i
     box_pixel(base + i * 16 + (l & 15), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
 }
 
-// 2a. texture gradient: one workgroup per (image, 32x32-texel tile), accumulators in LDS, every texel written once.
-//     Each wave sweeps four faces at a time (16 lanes each, 4 pixels per lane per trip, loads issued together); the owned
-//     pixels found in a trip are ballot-compacted and finished by all 64 lanes.
-__device__ inline void texture_gather_block(const BwdArgs& a, int block, float (*s_acc)[MM_TS * MM_TS], SweepStage* s_stage) {
+__device__ inline void tex_accumulate(const BwdArgs& a, float (*s_acc)[MM_TS * MM_TS], const TexRecord& rc, int tx0, int ty0) {
+    const int x0 = (int)(rc.xy & 0xFFFFu), y0 = (int)(rc.xy >> 16);
+    const int lx0 = x0 - tx0, lx1 = lx0 + 1, ly0 = y0 - ty0, ly1 = ly0 + 1;
+    const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && x0 + 1 < a.Wt;
+    const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && y0 + 1 < a.Ht;
+    const float ex = 1.f - rc.tx, ey = 1.f - rc.ty;
+    const float wnw = ex * ey, wne = rc.tx * ey, wsw = ex * rc.ty, wse = rc.tx * rc.ty;
+    const float dt[3] = {rc.d0, rc.d1, rc.d2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (dt[c] != 0.f) {
+            if (cx0 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx0], dt[c] * wnw);
+            if (cx1 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx1], dt[c] * wne);
+            if (cx0 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx0], dt[c] * wsw);
+            if (cx1 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx1], dt[c] * wse);
+        }
+    }
+}
+
+// 2a. texture gradient: one workgroup per (image, 32x32-texel tile) streams the records the pixel pass appended for the
+//     tile into LDS accumulators and writes every texel of the tile once.
+__device__ inline void texture_gather_block(const BwdArgs& a, int block, float (*s_acc)[MM_TS * MM_TS]) {
     const int ntiles = a.ntx * a.nty;
     int b, T;
     map_block(block, a.B, ntiles, b, T);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    SweepStage* st = &s_stage[wave];
+    const int tid = threadIdx.x;
     for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) (&s_acc[0][0])[i] = 0.f;
     __syncthreads();
     const int tx0 = (T % a.ntx) * MM_TS, ty0 = (T / a.ntx) * MM_TS;
-    const int grp = lane >> 4, sl = lane & 15;
-    const size_t hw = (size_t)a.H * a.W;
     const int nrec = a.tcnt[(size_t)b * ntiles + T];
-    if (nrec <= MM_TREC_CAP) {
-        // ---- normal path: stream the records the pixel pass appended for this tile
-        const TexRecord* recs = a.trec + ((size_t)b * ntiles + T) * MM_TREC_CAP;
-        for (int r = tid; r < nrec; r += 256) {
-            const TexRecord rc = recs[r];
-            const int x0 = (int)(rc.xy & 0xFFFFu), y0 = (int)(rc.xy >> 16);
-            const int lx0 = x0 - tx0, lx1 = lx0 + 1, ly0 = y0 - ty0, ly1 = ly0 + 1;
-            const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && x0 + 1 < a.Wt;
-            const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && y0 + 1 < a.Ht;
-            const float ex = 1.f - rc.tx, ey = 1.f - rc.ty;
-            const float wnw = ex * ey, wne = rc.tx * ey, wsw = ex * rc.ty, wse = rc.tx * rc.ty;
-            const float dt[3] = {rc.d0, rc.d1, rc.d2};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (dt[c] != 0.f) {
-                    if (cx0 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx0], dt[c] * wnw);
-                    if (cx1 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx1], dt[c] * wne);
-                    if (cx0 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx0], dt[c] * wsw);
-                    if (cx1 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx1], dt[c] * wse);
-                }
-            }
-        }
-    }
-    // ---- overflow path (more than MM_TREC_CAP records): rediscover the tile's pixels by sweeping its faces' boxes
-    const int beg = nrec <= MM_TREC_CAP ? 0 : a.uvt_offsets[T], end = nrec <= MM_TREC_CAP ? 0 : a.uvt_offsets[T + 1];
-    for (int k0 = beg + wave * 4; k0 < end; k0 += 16) {          // wave-uniform: four list entries per step
-        const int k = k0 + grp;
-        int f = -1; FaceBox fb; fb.npx = 0; fb.bw = 1; fb.px0 = fb.py0 = 0; fb.inv_bw = 1.f;
-        if (k < end) {
-            f = a.uvt_faces[k] & 0x7FFFFFFF;
-            fb = face_box(a, (size_t)b * a.F + f, 0.f);          // owned pixels lie inside the face's own box
-            if (sl == 0) {
-                FaceSlot& fs = st->slot[grp];
-                fs.p0 = fb.p0; fs.p1 = fb.p1; fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f;
-                const float* fu = a.face_uvs + (size_t)f * 6;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) fs.fu[i] = fu[i];
-            }
-        }
-        int nmax = fb.npx;
-        nmax = max(nmax, __shfl_xor(nmax, 16, 64)); nmax = max(nmax, __shfl_xor(nmax, 32, 64));
-        wave_sync_lds();
-        for (int base = 0; base < nmax; base += 16 * MM_SWEEP) {
-            bool own[MM_SWEEP];
-#pragma unroll
-            for (int i = 0; i < MM_SWEEP; ++i) {
-                const int idx = base + i * 16 + sl;
-                int px, py;
-                box_pixel(idx, fb.px0, fb.py0, fb.bw, fb.inv_bw, px, py);
-                own[i] = idx < fb.npx && a.face_idx[(size_t)b * hw + (size_t)py * a.W + px] == f;
-            }
-            const int n = compact4(own, lane, st->items);
-            wave_sync_lds();
-            for (int j = lane; j < n; j += 64) {
-                int g, px, py;
-                item_pixel(st, st->items[j], base, g, px, py);
-                const FaceSlot& fs = st->slot[g];
-                const size_t pix = (size_t)b * hw + (size_t)py * a.W + px;
-                const float4 q0 = a.gp0[pix];
-                const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
-                float w0, w1, w2, nrm;
-                edge_weights(fs.p0.x, fs.p0.y, fs.p0.z, fs.p0.w, fs.p1.x, fs.p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
-                w0 /= nrm; w1 /= nrm; w2 /= nrm;
-                const float u = (w0 * fs.fu[0] + w1 * fs.fu[2]) + w2 * fs.fu[4];
-                const float v = (w0 * fs.fu[1] + w1 * fs.fu[3]) + w2 * fs.fu[5];
-                const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
-                const int lx0 = s.x0 - tx0, lx1 = s.x1 - tx0, ly0 = s.y0 - ty0, ly1 = s.y1 - ty0;
-                const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && s.x1 < a.Wt;
-                const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && s.y1 < a.Ht;
-                const float dt[3] = {q0.x, q0.y, q0.z};
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (dt[c] != 0.f) {
-                        if (cx0 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx0], dt[c] * s.wnw);
-                        if (cx1 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx1], dt[c] * s.wne);
-                        if (cx0 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx0], dt[c] * s.wsw);
-                        if (cx1 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx1], dt[c] * s.wse);
-                    }
-                }
-            }
-            wave_sync_lds();
-        }
+    const TexRecord* recs = a.trec + ((size_t)b * ntiles + T) * MM_TREC_CAP;
+    for (int r = tid; r < min(nrec, MM_TREC_CAP); r += 256) tex_accumulate(a, s_acc, recs[r], tx0, ty0);
+    if (nrec > MM_TREC_CAP) {                                    // the list was full: the tile's other records are in the spill list
+        const int nsp = a.tcnt[(size_t)a.B * ntiles + b];
+        const TexSpill* sp = a.tspill + (size_t)b * 4 * a.H * a.W;
+        for (int r = tid; r < nsp; r += 256) if (sp[r].tile == T) tex_accumulate(a, s_acc, sp[r].r, tx0, ty0);
     }
     __syncthreads();
     // write the tile once (also where nothing landed: no separate zero-fill of grad_textures)
@@ -470,8 +426,12 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             const int fi = idx < fb.npx ? a.face_idx[(size_t)b * hw + (size_t)py * a.W + px] : -2;
             own[i] = fi == f; opn[i] = fi == -1;
         }
-        // ---- K2 (Appendix A.1) for the pixels these faces own: features per corner k = (1, u_k, v_k, n)
-        int n = compact4(own, lane, st->items);
+        // one compacted item list for both kinds of hit: pixels these faces own (K2: add the pixel pass's contributions)
+        // and uncovered pixels that may hold one of these faces among their first knum soft-mask faces (K4, Appendix A.2)
+        bool hit[MM_SWEEP];
+#pragma unroll
+        for (int i = 0; i < MM_SWEEP; ++i) hit[i] = own[i] || opn[i];
+        const int n = compact4(hit, lane, st->items);
         wave_sync_lds();
         for (int j = lane; j < n; j += 64) {
             int g, px, py;
@@ -479,44 +439,19 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             FaceSlot& fs = st->slot[g];
             const int bb = (int)(((long long)block * 16 + wave * 4 + g) / a.F);
             const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
+            // issue every load of the item first; which ones matter depends on the pixel's owner
+            const int fi = a.face_idx[pix];
             const float4 q0 = a.gp0[pix], q1 = a.gp1[pix];
-            const float dnz = a.gp2[pix];
-            const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
-            const float4 p0 = fs.p0, p1 = fs.p1;
-            float w0, w1, w2, nrm;
-            edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
-            w0 /= nrm; w1 /= nrm; w2 /= nrm;
-            const float dm = q0.w, du = q1.x, dv = q1.y, dnx = q1.z, dny = q1.w;
-            const float gnn = (dnx * fs.n[0] + dny * fs.n[1]) + dnz * fs.n[2];
-            const float G0 = ((dm + du * fs.fu[0]) + dv * fs.fu[1]) + gnn;
-            const float G1 = ((dm + du * fs.fu[2]) + dv * fs.fu[3]) + gnn;
-            const float G2 = ((dm + du * fs.fu[4]) + dv * fs.fu[5]) + gnn;
-            const float Gm = (w0 * G0 + w1 * G1) + w2 * G2;
-            const float dw0 = (G0 - Gm) / nrm, dw1 = (G1 - Gm) / nrm, dw2 = (G2 - Gm) / nrm;
-            const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
-            atomicAdd(&fs.acc[0], (dw1 * (-cey) + dw2 * bey) * a.mult);
-            atomicAdd(&fs.acc[1], (dw1 * cex + dw2 * (-bex)) * a.mult);
-            atomicAdd(&fs.acc[2], (dw0 * cey + dw2 * (-aey)) * a.mult);
-            atomicAdd(&fs.acc[3], (dw0 * (-cex) + dw2 * aex) * a.mult);
-            atomicAdd(&fs.acc[4], (dw0 * (-bey) + dw1 * aey) * a.mult);
-            atomicAdd(&fs.acc[5], (dw0 * bex + dw1 * (-aex)) * a.mult);
-            atomicAdd(&fs.acc[6], (w0 * dnx + w1 * dnx) + w2 * dnx);
-            atomicAdd(&fs.acc[7], (w0 * dny + w1 * dny) + w2 * dny);
-            atomicAdd(&fs.acc[8], (w0 * dnz + w1 * dnz) + w2 * dnz);
-        }
-        wave_sync_lds();
-        // ---- K4 (Appendix A.2) for uncovered pixels that may hold one of these faces among their first knum faces
-        n = compact4(opn, lane, st->items);
-        wave_sync_lds();
-        for (int j = lane; j < n; j += 64) {
-            int g, px, py;
-            item_pixel(st, st->items[j], base, g, px, py);
-            FaceSlot& fs = st->slot[g];
-            const int bb = (int)(((long long)block * 16 + wave * 4 + g) / a.F);
-            const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
+            const float q2 = a.gp2[pix];
             const float sq = a.softq[pix];
             const int lf = a.lastf[pix];
-            const float ga = a.gp2[pix];                              // dL/dalpha, left by the pixel pass for uncovered pixels
+            if (fi == fs.f) {
+                atomicAdd(&fs.acc[0], q0.x); atomicAdd(&fs.acc[1], q0.y); atomicAdd(&fs.acc[2], q0.z); atomicAdd(&fs.acc[3], q0.w);
+                atomicAdd(&fs.acc[4], q1.x); atomicAdd(&fs.acc[5], q1.y); atomicAdd(&fs.acc[6], q1.z); atomicAdd(&fs.acc[7], q1.w);
+                atomicAdd(&fs.acc[8], q2);
+                continue;
+            }
+            const float ga = q2;                                 // uncovered pixels: the pixel pass left dL/dalpha here
             const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
             if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= lf &&
                 !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl)) {
@@ -572,7 +507,7 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
         if (threadIdx.x == 0)
             a.loss[0] = a.image_weight * (l1 / ((float)a.B * 3.f * (float)a.H * (float)a.W)) + 1.f * (1.f - iou / (float)a.B);
     }
-    if ((int)blockIdx.x < ntex) texture_gather_block(a, blockIdx.x, s_acc, s_stage);
+    if ((int)blockIdx.x < ntex) texture_gather_block(a, blockIdx.x, s_acc);
     else face_gather_block(a, blockIdx.x - ntex, s_stage);
 }
 
@@ -586,13 +521,13 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.face_idx = d->face_idx; a.softq = w.softq; a.lastf = w.lastf; a.grad_rgba = g->grad_rgba;
     a.gp0 = w.gp0; a.gp1 = w.gp1; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.dTacc = w.dTacc; a.ticket = w.ticket;
-    a.tcnt = w.tcnt; a.trec = w.trec; a.ntiles_ = w.ntiles;
+    a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;
     a.gt = d->fused_gt; a.lpart = w.lpart; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
     a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
     a.uvt_offsets = d->uvt_offsets; a.uvt_faces = d->uvt_faces;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures; a.dfxy = w.dfxy; a.dfn = w.dfn;
-    if (hipMemsetAsync(w.tcnt, 0, (size_t)d->B * w.ntiles * sizeof(int), s) != hipSuccess) return MM_ERR_LAUNCH;
+    if (hipMemsetAsync(w.tcnt, 0, ((size_t)d->B * w.ntiles + d->B) * sizeof(int), s) != hipSuccess) return MM_ERR_LAUNCH;
     {
         ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
         dim3 grid(a.blocks_per_image * d->B);

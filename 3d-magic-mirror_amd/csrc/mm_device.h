@@ -39,8 +39,9 @@ __host__ __device__ inline int bin_shift_for(int H, int W, int F) {
 // One covered pixel's contribution to the texture gradient, appended by the pixel backward to the list of every texture
 // tile its bilinear footprint touches; the tile's workgroup streams its list (no search, no atomics on HBM).
 struct TexRecord { unsigned xy; float tx, ty, d0, d1, d2; };       // xy = x0 | y0 << 16 (top-left texel)
+struct TexSpill { TexRecord r; int tile; int pad; };
 #ifndef MM_TREC_CAP
-#define MM_TREC_CAP 2048      // records per tile; a tile that overflows falls back to sweeping its faces' boxes
+#define MM_TREC_CAP 2048      // records per tile; further records of a full tile go to the image's spill list
 #endif
 
 // ---- workspace carving (all offsets multiples of 256 bytes) ---------------------------------------------------------
@@ -56,15 +57,16 @@ struct Workspace {
     float* dTacc;          // (B,12)     backward accumulator: dL/d camera transform (zeroed by the pixel backward)
     unsigned* ticket;      // (B)        arrival counter of the vertex-backward workgroups of an image (same)
     int* lastf;            // (B,H,W)    uncovered pixels: id of the knum-th soft-mask face taken, INT_MAX if fewer were
-    float4* gp0;           // (B,H,W)    covered pixels, written by the pixel backward for the gather: {dtex rgb, dmask}
-    float4* gp1;           // (B,H,W)    {du, dv, dnx, dny}
-    float* gp2;            // (B,H,W)    {dnz}
+    float4* gp0;           // (B,H,W)    covered pixels: K2 contributions d/d(ax,ay,bx,by) of the pixel to its face
+    float4* gp1;           // (B,H,W)    d/d(cx,cy), d/d(nx,ny)
+    float* gp2;            // (B,H,W)    d/d(nz); uncovered pixels: dL/dalpha
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
     float* ltot;           // (B,2)       fused loss: per image {sum|pi-gi|, IoU}
     float4* lpart;         // (B,4*blocks) fused loss: per raster workgroup {sum|pi-gi|, sum p*g, sum p+g-p*g, 0}
-    int* tcnt;             // (B,ntiles)  texture-gradient records appended per texture tile (zeroed every backward)
+    int* tcnt;             // (B,ntiles)+(B) records appended per texture tile, then per-image spill counts (zeroed every backward)
     TexRecord* trec;       // (B,ntiles,MM_TREC_CAP)
+    TexSpill* tspill;      // (B,4*H*W)   records of tiles whose list is full (worst case: every pixel, 2x2 tiles)
     int ntiles;
     int bin_shift, nbx, nby, words;
     size_t binmask_bytes;
@@ -100,7 +102,8 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.lpart = (float4*)(p + o);     o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(float4));
     w.ltot = (float*)(p + o);       o += align256((size_t)B * 2 * sizeof(float));
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
-    w.tcnt = (int*)(p + o);         o += align256((size_t)B * w.ntiles * sizeof(int));
+    w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + B) * sizeof(int));
+    w.tspill = (TexSpill*)(p + o);  o += align256((size_t)B * 4 * H * W * sizeof(TexSpill));
     w.trec = (TexRecord*)(p + o);   o += align256((size_t)B * w.ntiles * MM_TREC_CAP * sizeof(TexRecord));
     w.bytes = o;
     return w;

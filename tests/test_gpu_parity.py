@@ -35,7 +35,9 @@ def _close(got, ref, tol=1e-4):
     ("sphere", 4, 64, 1, False, 1),
     ("smpl_uv_642", 3, 32, 2, True, 2),     # Market shape: H = 2W
     ("ellipsoid", 2, 96, 1, True, 3),
-    ("sphere", 2, 50, 1, True, 4),          # ragged: not a multiple of the 32x8 strip
+    ("sphere", 2, 50, 1, True, 4),          # ragged: not a multiple of the 16x16 block
+    ("smpl_uv", 2, 96, 1, True, 5),         # 13 776 faces: 216 mask words (multi-group walk), 16-px screen bins
+    ("sphere2", 2, 40, 1, False, 6),        # 5 120 faces, white background
 ])
 def test_render_loss_backward_matches_oracle(pkg, oracle, name, B, S, ratio, no_mask, seed):
     dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, ratio=ratio, seed=seed, no_mask=no_mask)

@@ -62,6 +62,7 @@ struct Workspace {
     float* gp2;            // (B,H,W)    d/d(nz); uncovered pixels: dL/dalpha
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
+    unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
     float* ltot;           // (B,2)       fused loss: per image {sum|pi-gi|, IoU}
     float4* lpart;         // (B,4*blocks) fused loss: per raster workgroup {sum|pi-gi|, sum p*g, sum p+g-p*g, 0}
     int* tcnt;             // (B,ntiles)+(B) records appended per texture tile, then per-image spill counts (zeroed every backward)
@@ -101,6 +102,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
     w.lpart = (float4*)(p + o);     o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(float4));
     w.ltot = (float*)(p + o);       o += align256((size_t)B * 2 * sizeof(float));
+    w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
     w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + B) * sizeof(int));
     w.tspill = (TexSpill*)(p + o);  o += align256((size_t)B * 4 * H * W * sizeof(TexSpill));

@@ -39,6 +39,7 @@ struct RasterArgs {
     float* softq;
     int* lastf;
     const float* gt; float4* lpart;          // fused recon_data partial sums (gt == nullptr: off)
+    const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     // outputs
     float* rgba;
     int32_t* face_idx;
@@ -71,11 +72,19 @@ struct TileCtx {
 __device__ inline TileCtx make_tile(const RasterArgs& a) {
     TileCtx t;
     int blk;
-    // one wave per workgroup (a slow tile then never pins the LDS of three finished neighbours); four consecutive
-    // workgroups are the 2x2 tiles of one 16x16 block
-    map_block(blockIdx.x >> 2, a.B, a.blocks_per_image, t.b, blk);
+    // one wave per workgroup (a slow tile then never pins the LDS of finished neighbours).  Launch order: the tiles with
+    // the most candidates first (order_kernel), images interleaved -- the kernel's duration is set by its slowest waves, so
+    // they must not start last.  Workgroup i -> image i % B (XCD i % 8 = image % 8 when 8 | B), rank i / B.
+    if (a.order) {
+        t.b = blockIdx.x % a.B;
+        const int slot = a.order[(size_t)t.b * 4 * a.blocks_per_image + blockIdx.x / a.B];
+        blk = slot >> 2; t.wave = slot & 3;
+    } else {
+        map_block(blockIdx.x >> 2, a.B, a.blocks_per_image, t.b, blk);
+        t.wave = blockIdx.x & 3;
+    }
     t.blk = blk;
-    t.lane = threadIdx.x & 63; t.wave = blockIdx.x & 3;
+    t.lane = threadIdx.x & 63;
     const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
     const int tx0 = bx * MM_BLOCK_PX + (t.wave & 1) * MM_TILE, ty0 = by * MM_BLOCK_PX + (t.wave >> 1) * MM_TILE;
     t.tx0 = tx0; t.ty0 = ty0;
@@ -396,6 +405,38 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
     }
 }
 
+// Sorts the tile slots (16x16 block * 4 + quadrant) of every image by their soft-mask candidate count, descending:
+// counting sort in LDS, one workgroup per image.  Only the launch ORDER of raster_fwd depends on it.
+__global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short* order) {
+    __shared__ int s_hist[1025];
+    __shared__ int s_cnt[4096];
+    const int b = blockIdx.x, nslot = 4 * a.blocks_per_image;
+    for (int i = threadIdx.x; i < 1025; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    for (int slot = threadIdx.x; slot < nslot; slot += 256) {
+        const int blk = slot >> 2, q = slot & 3;
+        const int tx0 = (blk % a.blocks_x) * MM_BLOCK_PX + (q & 1) * MM_TILE, ty0 = (blk / a.blocks_x) * MM_BLOCK_PX + (q >> 1) * MM_TILE;
+        int c = 0;
+        if (tx0 < a.W && ty0 < a.H) {
+            const uint64_t* row = a.binmask + ((size_t)b * a.nbx * a.nby + (size_t)(ty0 >> a.bin_shift) * a.nbx + (tx0 >> a.bin_shift)) * a.words;
+            for (int w = 0; w < a.words; ++w) c += __popcll(row[w]);
+        }
+        c = c > 1023 ? 1023 : c;
+        s_cnt[slot] = c;
+        atomicAdd(&s_hist[1023 - c], 1);                        // bucket 0 = heaviest
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                      // exclusive prefix over 1024 buckets
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { const int h = s_hist[i]; s_hist[i] = run; run += h; }
+    }
+    __syncthreads();
+    for (int slot = threadIdx.x; slot < nslot; slot += 256) {
+        const int pos = atomicAdd(&s_hist[1023 - s_cnt[slot]], 1);
+        order[(size_t)b * nslot + pos] = (unsigned short)slot;
+    }
+}
+
 static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
     RasterArgs a;
     a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.Ht = d->Ht; a.Wt = d->Wt; a.knum = d->knum;
@@ -413,6 +454,11 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     RasterArgs a = make_args(d, w);
     dim3 grid(a.blocks_per_image * d->B * 4);
     ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
+    a.order = nullptr;
+    if (4 * a.blocks_per_image <= 4096 && a.words <= 64) {       // heavy-first launch order (skipped where the sort would not pay)
+        hipLaunchKernelGGL(order_kernel, dim3(d->B), dim3(256), 0, s, a, w.order);
+        a.order = w.order;
+    }
     if (d->no_mask) hipLaunchKernelGGL(raster_fwd_kernel<true>, grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL(raster_fwd_kernel<false>, grid, dim3(64), 0, s, a);
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;

@@ -205,7 +205,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: template %s (V=%d,F=%d), B=%d per GPU, %dx%d, texture %dx%d, no_mask, fwd+loss+bwd to all "
                                    "8 inputs" % (args.config, name, dr.num_vertices, dr.num_faces, B, H, W, Ht, Wt),
-                       "mode": args.mode, "sharding": "batch, no data-path collective"},
+                       "mode": args.mode, "streams": args.streams if args.mode == "eager" else 1, "fused_loss": not args.unfused,
+                       "sharding": "batch, no data-path collective"},
             "value_one_stream": one_stream, "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},
             "loss": loss_value,
         }

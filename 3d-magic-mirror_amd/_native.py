@@ -21,7 +21,7 @@ class MMRenderDesc(ctypes.Structure):
     _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("V", c_i), ("F", c_i), ("Ht", c_i), ("Wt", c_i), ("no_mask", c_i),
                 ("knum", c_i), ("proj", c_f * 3), ("sigmainv", c_f), ("boxlen", c_f), ("multiplier", c_f), ("eps", c_f),
                 ("faces", c_p), ("face_uvs", c_p), ("vc_offsets", c_p), ("vc_items", c_p), ("uvt_offsets", c_p), ("uvt_faces", c_p),
-                ("uvt_size", c_i),
+                ("uvt_size", c_i), ("face_order", c_p),
                 ("vertices", c_p), ("textures", c_p), ("lights", c_p), ("bg", c_p), ("azimuths", c_p), ("elevations", c_p),
                 ("distances", c_p), ("biases", c_p),
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),

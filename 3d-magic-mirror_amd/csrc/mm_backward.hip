@@ -42,6 +42,7 @@ struct BwdArgs {
     float* ltot;                                                 // (B,2) per image {sum|pi-gi|, IoU}
     // gather
     const int32_t* uvt_offsets; const int32_t* uvt_faces;
+    const int32_t* face_order;
     int ntx, nty;
     float* grad_textures;
     float* dfxy;
@@ -396,7 +397,10 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     SweepStage* st = &s_stage[wave];
     const long long gid = (long long)block * 16 + (threadIdx.x >> 4);
     const bool live = gid < (long long)a.B * a.F;
-    const int b = live ? (int)(gid / a.F) : 0, f = live ? (int)(gid - (long long)b * a.F) : 0;
+    // group g -> image g % B, face rank g / B: the four groups of a wave sweep faces of the same rank (similar box sizes)
+    // in different images, and the ranks with the biggest boxes start first
+    const int b = live ? (int)(gid % a.B) : 0, rk = live ? (int)(gid / a.B) : 0;
+    const int f = a.face_order ? a.face_order[rk] : rk;
     const size_t o = (size_t)b * a.F + f, hw = (size_t)a.H * a.W;
     const float s2 = a.mult * a.mult;
     FaceBox fb = face_box(a, o, a.infl);
@@ -437,7 +441,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             int g, px, py;
             item_pixel(st, st->items[j], base, g, px, py);
             FaceSlot& fs = st->slot[g];
-            const int bb = (int)(((long long)block * 16 + wave * 4 + g) / a.F);
+            const int bb = (int)(((long long)block * 16 + wave * 4 + g) % a.B);
             const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
             // issue every load of the item first; which ones matter depends on the pixel's owner
             const int fi = a.face_idx[pix];
@@ -524,7 +528,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;
     a.gt = d->fused_gt; a.lpart = w.lpart; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
     a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
-    a.uvt_offsets = d->uvt_offsets; a.uvt_faces = d->uvt_faces;
+    a.uvt_offsets = d->uvt_offsets; a.uvt_faces = d->uvt_faces; a.face_order = d->face_order;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures; a.dfxy = w.dfxy; a.dfn = w.dfn;
     if (hipMemsetAsync(w.tcnt, 0, ((size_t)d->B * w.ntiles + d->B) * sizeof(int), s) != hipSuccess) return MM_ERR_LAUNCH;

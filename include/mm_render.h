@@ -64,6 +64,8 @@ typedef struct MMRenderDesc {
     const int32_t* uvt_offsets; /* (ntiles+1) CSR: texture tile -> faces that may sample it   (backward only; mm_build_uv_tiles) */
     const int32_t* uvt_faces;   /* face id, bit 31 set on the face's primary tile              (backward only) */
     int32_t uvt_size;           /* texture tile edge in texels (MM_UV_TILE)                    (backward only) */
+    const int32_t* face_order;  /* (F) optional: faces sorted by decreasing template area; only the ORDER in which the
+                                 *     backward visits faces depends on it (big screen boxes first); NULL = index order */
     /* per-sample attributes (device), the 'attributes' dict of networks.py:259-270 */
     const float* vertices;      /* (B,V,3) */
     const float* textures;      /* (B,3,Ht,Wt) */

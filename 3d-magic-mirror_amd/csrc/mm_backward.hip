@@ -222,27 +222,35 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             }
         }
     }
-    // append the records: one returning atomic per (wave, distinct tile), lanes of the same tile take consecutive slots
+    // append the records: one returning atomic per (wave, distinct tile), lanes of the same tile take consecutive slots.
+    // The grouping is pure lane arithmetic; all leaders then issue their atomics in ONE instruction per footprint corner
+    // (and the four corners' atomics are in flight together), so a wave pays one fabric round trip, not one per tile.
+    int leader[4], rank[4], base[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+        leader[c] = -1; rank[c] = 0; base[c] = 0;
+        int size = 0;
         unsigned long long pending = __ballot(rtile[c] >= 0);
         while (pending) {
-            const int leader = __ffsll((unsigned long long)pending) - 1;
-            const int tile = __shfl(rtile[c], leader, 64);
+            const int ld = __ffsll((unsigned long long)pending) - 1;
+            const int tile = __shfl(rtile[c], ld, 64);
             const unsigned long long m = __ballot(rtile[c] == tile);
-            int base = 0;
-            if (lane == leader) base = atomicAdd(a.tcnt + (size_t)b * a.ntiles_ + tile, __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (rtile[c] == tile) {
-                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < MM_TREC_CAP) a.trec[((size_t)b * a.ntiles_ + tile) * MM_TREC_CAP + slot] = rec;
-                else {                                          // full tile (rare): the image's spill list
-                    const int os = atomicAdd(a.tcnt + (size_t)a.B * a.ntiles_ + b, 1);
-                    TexSpill sp; sp.r = rec; sp.tile = tile; sp.pad = 0;
-                    a.tspill[(size_t)b * 4 * a.H * a.W + os] = sp;
-                }
-            }
+            if (rtile[c] == tile) { leader[c] = ld; rank[c] = __popcll(m & ((1ull << lane) - 1ull)); size = __popcll(m); }
             pending &= ~m;
+        }
+        if (leader[c] == lane) base[c] = atomicAdd(a.tcnt + (size_t)b * a.ntiles_ + rtile[c], size);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int bs = __shfl(base[c], leader[c] < 0 ? lane : leader[c], 64);
+        if (rtile[c] >= 0) {
+            const int slot = bs + rank[c];
+            if (slot < MM_TREC_CAP) a.trec[((size_t)b * a.ntiles_ + rtile[c]) * MM_TREC_CAP + slot] = rec;
+            else {                                               // full tile (rare): the image's spill list
+                const int os = atomicAdd(a.tcnt + (size_t)a.B * a.ntiles_ + b, 1);
+                TexSpill sp; sp.r = rec; sp.tile = rtile[c]; sp.pad = 0;
+                a.tspill[(size_t)b * 4 * a.H * a.W + os] = sp;
+            }
         }
     }
 

@@ -405,35 +405,45 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
     }
 }
 
-// Sorts the tile slots (16x16 block * 4 + quadrant) of every image by their soft-mask candidate count, descending:
-// counting sort in LDS, one workgroup per image.  Only the launch ORDER of raster_fwd depends on it.
+// Ranks the tile slots (16x16 block * 4 + quadrant) of every image by their soft-mask candidate count, descending
+// (rank by counting, all pairs, in LDS: slots per image <= 1024).  Only the launch ORDER of raster_fwd depends on it.
 __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short* order) {
-    __shared__ int s_hist[1025];
-    __shared__ int s_cnt[4096];
-    const int b = blockIdx.x, nslot = 4 * a.blocks_per_image;
-    for (int i = threadIdx.x; i < 1025; i += 256) s_hist[i] = 0;
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) int s_cnt[1024];
+    const int b = blockIdx.x, nslot = 4 * a.blocks_per_image;          // a multiple of 4
     for (int slot = threadIdx.x; slot < nslot; slot += 256) {
         const int blk = slot >> 2, q = slot & 3;
         const int tx0 = (blk % a.blocks_x) * MM_BLOCK_PX + (q & 1) * MM_TILE, ty0 = (blk / a.blocks_x) * MM_BLOCK_PX + (q >> 1) * MM_TILE;
         int c = 0;
         if (tx0 < a.W && ty0 < a.H) {
             const uint64_t* row = a.binmask + ((size_t)b * a.nbx * a.nby + (size_t)(ty0 >> a.bin_shift) * a.nbx + (tx0 >> a.bin_shift)) * a.words;
-            for (int w = 0; w < a.words; ++w) c += __popcll(row[w]);
+            for (int w0 = 0; w0 < a.words; w0 += 8) {             // eight loads in flight per trip
+                uint64_t r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = (w0 + k < a.words) ? row[w0 + k] : 0ull;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c += __popcll(r[k]);
+            }
         }
-        c = c > 1023 ? 1023 : c;
         s_cnt[slot] = c;
-        atomicAdd(&s_hist[1023 - c], 1);                        // bucket 0 = heaviest
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {                                      // exclusive prefix over 1024 buckets
-        int run = 0;
-        for (int i = 0; i < 1024; ++i) { const int h = s_hist[i]; s_hist[i] = run; run += h; }
     }
     __syncthreads();
     for (int slot = threadIdx.x; slot < nslot; slot += 256) {
-        const int pos = atomicAdd(&s_hist[1023 - s_cnt[slot]], 1);
-        order[(size_t)b * nslot + pos] = (unsigned short)slot;
+        const int c = s_cnt[slot];
+        int rank = 0;
+        for (int j = 0; j < nslot; j += 16) {                      // four 16-byte LDS reads in flight per trip
+            int4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (j + 4 * k < nslot) ? *(const int4*)&s_cnt[j + 4 * k] : make_int4(-1, -1, -1, -1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int jj = j + 4 * k;
+                rank += (v[k].x > c) || (v[k].x == c && jj < slot);
+                rank += (v[k].y > c) || (v[k].y == c && jj + 1 < slot);
+                rank += (v[k].z > c) || (v[k].z == c && jj + 2 < slot);
+                rank += (v[k].w > c) || (v[k].w == c && jj + 3 < slot);
+            }
+        }
+        order[(size_t)b * nslot + rank] = (unsigned short)slot;
     }
 }
 
@@ -455,7 +465,7 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     dim3 grid(a.blocks_per_image * d->B * 4);
     ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
     a.order = nullptr;
-    if (4 * a.blocks_per_image <= 4096 && a.words <= 64) {       // heavy-first launch order (skipped where the sort would not pay)
+    if (4 * a.blocks_per_image <= 1024 && a.words <= 64) {       // heavy-first launch order (skipped where the sort would not pay)
         hipLaunchKernelGGL(order_kernel, dim3(d->B), dim3(256), 0, s, a, w.order);
         a.order = w.order;
     }

@@ -40,7 +40,7 @@ class MMReconDesc(ctypes.Structure):
                 ("image_weight", c_f), ("contour", c_f), ("loss", c_p), ("grad_loss", c_p), ("grad_pred", c_p),
                 ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p)]
 
-PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "bin")
+PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "bin", "order")
 UV_TILE = 32
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 

@@ -463,12 +463,13 @@ static RasterArgs make_args(const MMRenderDesc* d, const Workspace& w) {
 int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     RasterArgs a = make_args(d, w);
     dim3 grid(a.blocks_per_image * d->B * 4);
-    ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
     a.order = nullptr;
     if (4 * a.blocks_per_image <= 1024 && a.words <= 64) {       // heavy-first launch order (skipped where the sort would not pay)
+        ProfScope po(d->prof_events, MM_PROF_ORDER, s);
         hipLaunchKernelGGL(order_kernel, dim3(d->B), dim3(256), 0, s, a, w.order);
         a.order = w.order;
     }
+    ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
     if (d->no_mask) hipLaunchKernelGGL(raster_fwd_kernel<true>, grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL(raster_fwd_kernel<false>, grid, dim3(64), 0, s, a);
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;

@@ -44,6 +44,7 @@ def algorithmic_bytes(kernel, B, F, V, HW, T):
         "recon_partial": 32 * HW,
         "recon_bwd": 48 * HW,
         "bin": 48 * F,
+        "order": 0,
         "pixel_bwd": 52 * F + 12 * T + 20 * HW,
         "gather_bwd": 36 * F + 12 * T,
         "vertex_bwd": 36 * F + 24 * V,
@@ -160,7 +161,7 @@ def main():
                 for k, v in step.kernel_times_ms().items():
                     acc.setdefault(k, []).append(v * 1e3)
         step.disable_profiling()
-        kernels_us = {k: float(np.mean(v)) for k, v in acc.items()}
+        kernels_us = {k: float(np.mean(v)) for k, v in acc.items() if np.isfinite(np.mean(v))}
         dom = max(kernels_us, key=kernels_us.get)
         nbytes = algorithmic_bytes(dom, B, dr.num_faces, dr.num_vertices, H * W, Ht * Wt)
         achieved = nbytes / (kernels_us[dom] * 1e-6) / 1e9

@@ -45,7 +45,7 @@ UV_TILE = 32
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",
-           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_uv_tiles", "mm_status_string",
+           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_uv_tiles", "mm_nearest_neighbour", "mm_status_string",
            "mm_abi_version")
 
 
@@ -75,6 +75,7 @@ def lib():
     L.mm_recon_query_workspace.argtypes = [ctypes.POINTER(MMReconDesc)]
     L.mm_recon_data_forward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
     L.mm_recon_data_backward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
+    L.mm_nearest_neighbour.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]
     L.mm_build_vertex_corner_csr.argtypes = [c_i, c_i, c_p, c_p, c_p]
     L.mm_build_uv_tiles.argtypes = [c_i, c_p, c_i, c_i, c_p, c_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.mm_status_string.restype = ctypes.c_char_p

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmm_render.so")
-SOURCES = ["mm_abi.hip", "mm_vertex.hip", "mm_raster.hip", "mm_backward.hip", "mm_loss.hip"]
+SOURCES = ["mm_abi.hip", "mm_vertex.hip", "mm_raster.hip", "mm_backward.hip", "mm_loss.hip", "mm_nn.hip"]
 HEADERS = ["mm_device.h", os.path.join("..", "..", "include", "mm_render.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -11,6 +11,7 @@ int launch_raster_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace
 size_t recon_workspace_bytes(const MMReconDesc*);
 int launch_recon_fwd(const MMReconDesc*, hipStream_t);
 int launch_recon_bwd(const MMReconDesc*, hipStream_t);
+int launch_nn(int, int, int, const float*, const float*, float*, int32_t*, hipStream_t);
 }  // namespace mm
 
 static int check_render(const MMRenderDesc* d, bool backward) {
@@ -86,6 +87,13 @@ int mm_recon_data_backward(const MMReconDesc* d, mm_stream_t stream) {
     int st = check_recon(d, true);
     if (st != MM_OK) return st;
     return mm::launch_recon_bwd(d, (hipStream_t)stream);
+}
+
+int mm_nearest_neighbour(int32_t B, int32_t N, int32_t M, const float* x, const float* y, float* dist, int32_t* idx,
+                         mm_stream_t stream) {
+    if (!x || !y || !dist || !idx) return MM_ERR_NULL_POINTER;
+    if (B <= 0 || N <= 0 || M <= 0) return MM_ERR_BAD_SHAPE;
+    return mm::launch_nn(B, N, M, x, y, dist, idx, (hipStream_t)stream);
 }
 
 int mm_build_uv_tiles(int32_t F, const float* fuv, int32_t Ht, int32_t Wt, int32_t* offsets, int32_t* items, int64_t capacity,

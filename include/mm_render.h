@@ -145,6 +145,14 @@ int mm_recon_data_forward(const MMReconDesc* desc, mm_stream_t stream);
 int mm_recon_data_backward(const MMReconDesc* desc, mm_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------------------------------
+ * Nearest neighbour of every point of x (B,N,3) in y (B,M,3): squared distance (B,N) and index (B,N) int32, lowest index
+ * on ties.  The O(N*M) half of pytorch3d.loss.chamfer_distance (knn_points, K=1) that DiffRender.recon_att(chamfer=True)
+ * needs (networks.py:342,356); the differentiable tail is a gather.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int mm_nearest_neighbour(int32_t B, int32_t N, int32_t M, const float* x, const float* y, float* dist, int32_t* idx,
+                         mm_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------------------------------
  * Host helpers (no GPU involved)
  * ------------------------------------------------------------------------------------------------------------------ */
 /* Texture-space tiling used by the backward (static per template and texture size).  A face is listed in every tile

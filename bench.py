@@ -55,8 +55,8 @@ def algorithmic_bytes(kernel, B, F, V, HW, T):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="config2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="eager", choices=["hipgraph", "eager", "torch"],
                     help="hipgraph: whole step replayed as one HIP graph; eager: 4 ABI calls per step; torch: DiffRender autograd API")

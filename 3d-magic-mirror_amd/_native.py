@@ -45,7 +45,7 @@ UV_TILE = 32
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",
-           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_uv_tiles", "mm_nearest_neighbour", "mm_status_string",
+           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_uv_tiles", "mm_nearest_neighbour", "mm_status_string", "mm_last_error_detail",
            "mm_abi_version")
 
 
@@ -80,13 +80,17 @@ def lib():
     L.mm_build_uv_tiles.argtypes = [c_i, c_p, c_i, c_i, c_p, c_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.mm_status_string.restype = ctypes.c_char_p
     L.mm_status_string.argtypes = [ctypes.c_int]
+    L.mm_last_error_detail.restype = ctypes.c_char_p
+    L.mm_last_error_detail.argtypes = []
     _LIB = L
     return L
 
 
 def check(status, what):
     if status != 0:
-        raise RuntimeError("%s failed: %s (MMStatus %d)" % (what, lib().mm_status_string(status).decode(), status))
+        detail = lib().mm_last_error_detail().decode() if status == -4 else ""
+        raise RuntimeError("%s failed: %s (MMStatus %d)%s" % (what, lib().mm_status_string(status).decode(), status,
+                                                            " [" + detail + "]" if detail else ""))
 
 
 def ptr(t):

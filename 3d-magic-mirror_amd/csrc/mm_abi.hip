@@ -1,5 +1,6 @@
 // mm_abi.hip -- extern "C" entry points of libmm_render.so (declared in include/mm_render.h): argument validation,
 // workspace carving and launch sequencing.  No allocation, no host synchronisation, no global state.
+#include <cstdio>
 #include "mm_device.h"
 
 namespace mm {
@@ -40,6 +41,7 @@ int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
     if (st != MM_OK) return st;
     const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->F, d->H, d->W, d->Ht, d->Wt);
     hipStream_t s = (hipStream_t)stream;
+    mm::clear_stale_error();
     st = mm::launch_vertex_fwd(d, w, s);
     if (st != MM_OK) return st;
     st = mm::launch_bin(d, w, s);
@@ -56,6 +58,7 @@ int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_
     if (d->no_mask && !g->grad_bg) return MM_ERR_NULL_POINTER;
     const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->F, d->H, d->W, d->Ht, d->Wt);
     hipStream_t s = (hipStream_t)stream;
+    mm::clear_stale_error();
     st = mm::launch_raster_bwd(d, g, w, s);
     if (st != MM_OK) return st;
     return mm::launch_vertex_bwd(d, g, w, s);
@@ -80,12 +83,14 @@ size_t mm_recon_query_workspace(const MMReconDesc* d) {
 int mm_recon_data_forward(const MMReconDesc* d, mm_stream_t stream) {
     int st = check_recon(d, false);
     if (st != MM_OK) return st;
+    mm::clear_stale_error();
     return mm::launch_recon_fwd(d, (hipStream_t)stream);
 }
 
 int mm_recon_data_backward(const MMReconDesc* d, mm_stream_t stream) {
     int st = check_recon(d, true);
     if (st != MM_OK) return st;
+    mm::clear_stale_error();
     return mm::launch_recon_bwd(d, (hipStream_t)stream);
 }
 
@@ -93,6 +98,7 @@ int mm_nearest_neighbour(int32_t B, int32_t N, int32_t M, const float* x, const 
                          mm_stream_t stream) {
     if (!x || !y || !dist || !idx) return MM_ERR_NULL_POINTER;
     if (B <= 0 || N <= 0 || M <= 0) return MM_ERR_BAD_SHAPE;
+    mm::clear_stale_error();
     return mm::launch_nn(B, N, M, x, y, dist, idx, (hipStream_t)stream);
 }
 
@@ -162,6 +168,14 @@ const char* mm_status_string(int status) {
         case MM_ERR_UNSUPPORTED: return "unsupported option";
         default: return "unknown status";
     }
+}
+
+const char* mm_last_error_detail(void) {
+    static thread_local char buf[160];
+    const mm::LaunchError& e = mm::last_launch_error();
+    if (e.code == hipSuccess) return "";
+    snprintf(buf, sizeof buf, "%s: %s (hipError %d)", e.what, hipGetErrorString(e.code), (int)e.code);
+    return buf;
 }
 
 int mm_abi_version(void) { return 1; }

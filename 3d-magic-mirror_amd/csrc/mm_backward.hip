@@ -546,14 +546,14 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
         if (d->no_mask) hipLaunchKernelGGL(pixel_bwd_kernel<true>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(pixel_bwd_kernel<false>, grid, dim3(256), 0, s, a);
     }
-    if (hipGetLastError() != hipSuccess) return MM_ERR_LAUNCH;
+    if (launch_ok("pixel_bwd") != MM_OK) return MM_ERR_LAUNCH;
     {
         ProfScope p(d->prof_events, MM_PROF_GATHER_BWD, s);
         const int ntex = a.ntx * a.nty * d->B;
         const unsigned nface = (unsigned)(((long long)d->B * d->F + 15) / 16);
         hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex);
     }
-    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+    return launch_ok("raster_bwd");
 }
 
 }  // namespace mm

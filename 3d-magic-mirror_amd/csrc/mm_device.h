@@ -285,6 +285,18 @@ struct ProfScope {
     ~ProfScope() { if (ev) (void)hipEventRecord((hipEvent_t)ev[2 * slot + 1], s); }
 };
 
+// launch check shared by every launcher: the HIP error (if any) is kept per host thread for mm_last_error_detail()
+struct LaunchError { hipError_t code; const char* what; };
+inline LaunchError& last_launch_error() { static thread_local LaunchError e = {hipSuccess, ""}; return e; }
+inline int launch_ok(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MM_OK;
+    last_launch_error() = {e, what};
+    return MM_ERR_LAUNCH;
+}
+// errors left behind by the caller's own earlier runtime calls (e.g. hipEventQuery -> hipErrorNotReady) are not ours
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -156,7 +156,7 @@ int launch_recon_fwd(const MMReconDesc* d, hipStream_t s) {
       hipLaunchKernelGGL(recon_partial_kernel, dim3(MM_LOSS_CHUNKS, d->B), dim3(256), 0, s, a); }
     { ProfScope p(d->prof_events, MM_PROF_RECON_FINAL, s);
       hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(64), 0, s, a); }
-    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+    return launch_ok("recon_fwd");
 }
 
 int launch_recon_bwd(const MMReconDesc* d, hipStream_t s) {
@@ -168,7 +168,7 @@ int launch_recon_bwd(const MMReconDesc* d, hipStream_t s) {
         ProfScope p(d->prof_events, MM_PROF_RECON_CONTOUR, s);
         hipLaunchKernelGGL(recon_contour_bwd_kernel, grid, dim3(256), 0, s, a);
     }
-    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+    return launch_ok("recon_bwd");
 }
 
 }  // namespace mm

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void nn_kernel(int B, int N, int M, const floa
 
 int launch_nn(int B, int N, int M, const float* x, const float* y, float* dist, int32_t* idx, hipStream_t s) {
     hipLaunchKernelGGL(nn_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, B, N, M, x, y, dist, idx);
-    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+    return launch_ok("nearest_neighbour");
 }
 
 }  // namespace mm

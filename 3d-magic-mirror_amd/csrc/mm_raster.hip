@@ -472,7 +472,7 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
     if (d->no_mask) hipLaunchKernelGGL(raster_fwd_kernel<true>, grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL(raster_fwd_kernel<false>, grid, dim3(64), 0, s, a);
-    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+    return launch_ok("raster_fwd");
 }
 
 }  // namespace mm

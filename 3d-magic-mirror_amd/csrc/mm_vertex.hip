@@ -291,7 +291,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     dim3 grid((d->F + 255) / 256, d->B);
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
       hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }
-    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+    return launch_ok("vertex_fwd");
 }
 
 int launch_bin(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
@@ -302,7 +302,7 @@ int launch_bin(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     const long long waves = (long long)d->B * ((w.nbx + 3) / 4) * ((w.nby + 3) / 4) * w.words;
     { ProfScope ps(d->prof_events, MM_PROF_BIN, s);
       hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); }
-    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+    return launch_ok("bin");
 }
 
 int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
@@ -318,7 +318,7 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.grad_azim = g->grad_azimuths; a.grad_elev = g->grad_elevations; a.grad_dist = g->grad_distances; a.grad_bias = g->grad_biases;
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_BWD, s);
       hipLaunchKernelGGL(vertex_bwd_kernel, dim3((d->V + 31) / 32, d->B), dim3(256), 0, s, a); }
-    return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+    return launch_ok("vertex_bwd");
 }
 
 }  // namespace mm

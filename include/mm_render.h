@@ -165,6 +165,8 @@ int mm_build_uv_tiles(int32_t F, const float* face_uvs_host, int32_t Ht, int32_t
 /* Build the vertex -> corner CSR from HOST faces (F,3).  offsets: (V+1), items: (3F).  Returns MM_OK or an error. */
 int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces_host, int32_t* offsets_host, int32_t* items_host);
 const char* mm_status_string(int status);
+/* After MM_ERR_LAUNCH on this host thread: "<kernel>: <hipGetErrorString> (hipError n)"; "" if none was recorded. */
+const char* mm_last_error_detail(void);
 int mm_abi_version(void);
 
 #ifdef __cplusplus

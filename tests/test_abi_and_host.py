@@ -25,6 +25,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert set(N.EXPORTS) == declared
     assert lib.mm_abi_version() >= 1
     assert lib.mm_status_string(-3).decode().startswith("workspace")
+    assert lib.mm_last_error_detail().decode() == ""            # nothing launched, nothing recorded
     # struct layout agrees with the header (the library sizes the workspace from the same struct)
     d = N.MMRenderDesc()
     d.B, d.H, d.W, d.V, d.F, d.Ht, d.Wt = 2, 64, 64, 642, 1280, 128, 64

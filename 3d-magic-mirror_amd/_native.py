@@ -26,7 +26,8 @@ class MMRenderDesc(ctypes.Structure):
                 ("distances", c_p), ("biases", c_p),
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
                 ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p),
-                ("fused_gt", c_p), ("fused_image_weight", c_f), ("fused_loss", c_p), ("fused_grad_loss", c_p)]
+                ("fused_gt", c_p), ("fused_image_weight", c_f), ("fused_loss", c_p), ("fused_grad_loss", c_p),
+                ("options", c_i)]
 
 
 class MMRenderGrads(ctypes.Structure):
@@ -42,6 +43,8 @@ class MMReconDesc(ctypes.Structure):
 
 PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "bin", "order")
 UV_TILE = 32
+OPT_STREAMED = 1
+OPT_RESIDENT = 2
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",

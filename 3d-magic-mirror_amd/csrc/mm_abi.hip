@@ -44,9 +44,7 @@ int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
     mm::clear_stale_error();
     st = mm::launch_vertex_fwd(d, w, s);
     if (st != MM_OK) return st;
-    st = mm::launch_bin(d, w, s);
-    if (st != MM_OK) return st;
-    return mm::launch_raster_fwd(d, w, s);
+    return mm::launch_raster_fwd(d, w, s);      // streamed: bin masks + tile order + raster; resident: one launch
 }
 
 int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {

@@ -1,0 +1,317 @@
+// mm_raster_common.h -- pieces shared by the two forward pixel kernels of libmm_render.so (gfx950):
+//   mm_raster.hip           "streamed": any mesh size; candidates come from the bin masks, face records from HBM/L2
+//   mm_raster_resident.hip  "resident": small templates (the reference's 642-vertex meshes); the image's transformed
+//                           vertices live in LDS and nothing but the texture is fetched on the critical path
+// Both evaluate the SAME fp32 expressions on the same values, so their outputs are
+// bit-identical; tests/test_gpu_parity.py holds them to that.
+#pragma once
+#include "mm_device.h"
+
+namespace mm {
+
+struct RasterArgs {
+    int B, H, W, F, Ht, Wt, knum, blocks_x, blocks_per_image;
+    int bin_shift, nbx, nby, words;
+    float mult, eps, sigmainv, infl;        // infl = boxlen * multiplier
+    const float4* geo;
+    const uint64_t* binmask;                // soft candidates (inflated boxes, all faces)
+    const uint64_t* binmask_hard;           // colour candidates (front faces)
+    const float* face_uvs;
+    const float* fn;                        // (B,F,3) unit normals
+    const float* textures;
+    const float* lights;
+    const float* bg;
+    float* softq;
+    int* lastf;
+    const float* gt; float4* lpart;          // fused recon_data partial sums (gt == nullptr: off)
+    const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
+    // resident kernel only
+    int V, regions_x, regions_per_image;
+    float proj0, proj1, proj2;
+    const int32_t* faces;
+    const float* vertices;
+    const float* T;                         // (B,12) camera transforms written by the vertex stage
+    // outputs
+    float* rgba;
+    int32_t* face_idx;
+    float* imnormal;
+};
+
+#define MM_PAIR_ROUND 512
+
+struct TileCtx {
+    int b, blk, px, py, tx0, ty0, lane, wave;   // wave = quadrant of the 16x16 block `blk`
+    bool in_img;
+    float x0, y0;
+    float xs[MM_TILE], ys[MM_TILE];         // pixel-centre columns / rows of the tile (same in every lane)
+    const uint64_t* mask;                   // streamed: this wave's bin row (soft candidates): `words` 64-bit words
+    const uint64_t* mask_hard;              // streamed: same bin, colour candidates
+};
+
+__device__ inline void tile_pixels(const RasterArgs& a, TileCtx& t) {
+    t.px = t.tx0 + (t.lane & 7); t.py = t.ty0 + (t.lane >> 3);
+    t.in_img = t.px < a.W && t.py < a.H;
+    t.x0 = pixel_x(t.px, a.W, a.mult); t.y0 = pixel_y(t.py, a.H, a.mult);
+#pragma unroll
+    for (int i = 0; i < MM_TILE; ++i) { t.xs[i] = pixel_x(t.tx0 + i, a.W, a.mult); t.ys[i] = pixel_y(t.ty0 + i, a.H, a.mult); }
+}
+
+__device__ inline int wave_prefix_excl(int v, int lane, int& total) {
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+
+__device__ inline void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// number of set bits of a ballot below this lane
+__device__ inline int ballot_rank(uint64_t bal) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+}
+
+// 64x64 bit-matrix transpose across the wave: lane i holds row i on entry and column i on exit (6 butterfly stages).
+template <int S>
+__device__ inline uint64_t transpose_stage(uint64_t x, int lane) {
+    // m: bit positions whose index has bit S clear
+    constexpr uint64_t m = S == 32 ? 0x00000000FFFFFFFFull : S == 16 ? 0x0000FFFF0000FFFFull : S == 8 ? 0x00FF00FF00FF00FFull
+                         : S == 4 ? 0x0F0F0F0F0F0F0F0Full : S == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+    const unsigned lo = __shfl_xor((unsigned)x, S, 64), hi = __shfl_xor((unsigned)(x >> 32), S, 64);
+    const uint64_t y = ((uint64_t)hi << 32) | lo;
+    return (lane & S) ? (((y >> S) & m) | (x & ~m)) : ((x & m) | ((y & m) << S));
+}
+
+__device__ inline uint64_t wave_transpose64(uint64_t x, int lane) {
+    x = transpose_stage<32>(x, lane);
+    x = transpose_stage<16>(x, lane);
+    x = transpose_stage<8>(x, lane);
+    x = transpose_stage<4>(x, lane);
+    x = transpose_stage<2>(x, lane);
+    x = transpose_stage<1>(x, lane);
+    return x;
+}
+
+// box-vs-tile for ONE candidate (this lane's): bit (r*8+c) set iff pixel (row r, column c) of the tile passes the
+// separable closed-box test  !(x < lo || x > hi)  -- the same comparisons on the same floats as the per-pixel test.
+__device__ inline uint64_t box_pixels(const TileCtx& t, float xlo, float ylo, float xhi, float yhi) {
+    unsigned col = 0, row = 0;
+#pragma unroll
+    for (int i = 0; i < MM_TILE; ++i) {
+        col |= (unsigned)(!(t.xs[i] < xlo || t.xs[i] > xhi)) << i;
+        row |= (unsigned)(!(t.ys[i] < ylo || t.ys[i] > yhi)) << i;
+    }
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        lo |= ((row >> r) & 1u) ? (col << (8 * r)) : 0u;
+        hi |= ((row >> (r + 4)) & 1u) ? (col << (8 * r)) : 0u;
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Balanced evaluation of a batch's (row, column) pairs: every lane owns one ROW of the bit matrix `m` (a candidate, or a
+// pixel) and the set bits are its columns.  The pairs of all lanes are laid out row-major in LDS and evaluated 64 at a
+// time by WHICHEVER lane, eval(row, col); results are combined by the caller through commutative, exact LDS atomics
+// (64-bit max / integer add), so the wave's critical path is pairs/64 evaluations, not its busiest lane, and the outcome
+// does not depend on evaluation order.
+template <class Stage, class Eval>
+__device__ inline void pair_parallel(const TileCtx& t, Stage* st, uint64_t m, Eval&& eval) {
+    int total;
+    int k = wave_prefix_excl(__popcll(m), t.lane, total);       // index of this lane's next unwritten pair
+    uint64_t rem = m;
+    for (int base = 0; base < total; base += MM_PAIR_ROUND) {
+        const int lim = min(MM_PAIR_ROUND, total - base);
+        while (rem && k < base + lim) {                          // every set bit is visited exactly once overall
+            const int j = __ffsll((unsigned long long)rem) - 1;
+            rem &= rem - 1;
+            st->pairs[k - base] = (unsigned short)((t.lane << 8) | j);
+            ++k;
+        }
+        wave_lds_sync();
+        for (int p = t.lane; p < lim; p += 128) {                // two independent pairs per trip: ILP for a lone wave
+            const unsigned pr0 = st->pairs[p];
+            const bool two = p + 64 < lim;
+            const unsigned pr1 = two ? st->pairs[p + 64] : pr0;
+            eval((int)(pr0 >> 8), (int)(pr0 & 255u), true);
+            eval((int)(pr1 >> 8), (int)(pr1 & 255u), two);
+        }
+        wave_lds_sync();
+    }
+}
+
+// (z, -rank) packed so that an unsigned 64-bit max is kaolin's "strict z > best, lowest index on ties"; rank = any value
+// that grows with the face index (the face id itself, or its position in an index-ordered list)
+__device__ inline unsigned long long depth_key(float z, int rank) {
+    const unsigned bits = __float_as_uint(z + 0.f);              // -0 -> +0: equal depths must tie
+    const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    return ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)rank);
+}
+__device__ inline int depth_key_rank(unsigned long long k) { return (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)); }
+
+struct Hit { int f; float w0, w1, w2; };
+
+// K1, one (candidate j, pixel l) pair of the staged batch: barycentrics, inside test, depth -> 64-bit LDS max.
+// straight-line on purpose (two of these are interleaved per trip): the IEEE divisions the oracle takes
+template <class Stage>
+__device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* st, int j, int l, bool live) {
+    const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
+    const float4 p0 = st->p0[j], p1 = st->p1[j], p2 = st->p2[j];
+    float w0, w1, w2, nrm;
+    edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
+    w0 /= nrm; w1 /= nrm; w2 /= nrm;
+    const float z0 = (w0 * p1.z + w1 * p1.w) + w2 * p2.x;
+    if (live && !(w0 < 0.f || w1 < 0.f || w2 < 0.f) && z0 > -INFINITY)
+        atomicMax(&st->key[l], depth_key(z0, __float_as_int(p2.z)));
+}
+
+// closest of the three edge segments: squared distance (multiplier units) and type = edge*3 + region
+__device__ inline float tri_dist2(float x0, float y0, const float4& p0, const float4& p1, int& ty) {
+    int r;
+    float d = seg_dist2(x0, y0, p0.x, p0.y, p0.z, p0.w, ty);
+    const float d1 = seg_dist2(x0, y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
+    const float d2 = seg_dist2(x0, y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
+    return d;
+}
+
+// The silhouette is held to 1e-4, not to the bit (only face_idx is), and its pair evaluations are most of the forward's
+// instructions: they use the hardware reciprocal / exp2 / log2 (about 1 ulp each) instead of the IEEE sequences.
+__device__ inline float seg_dist2_fast(float px, float py, float ux, float uy, float vx, float vy) {
+    const float ex = vx - ux, ey = vy - uy, rx = px - ux, ry = py - uy;
+    const float len2 = ex * ex + ey * ey;
+    const float dot = rx * ex + ry * ey;
+    float t = (len2 > 0.f) ? dot * __builtin_amdgcn_rcpf(len2) : 0.f;
+    t = fminf(fmaxf(t, 0.f), 1.f);                                // clamped projection: the three regions of seg_dist2 in one form
+    const float qx = rx - t * ex, qy = ry - t * ey;
+    return qx * qx + qy * qy;
+}
+
+// K3, one (pixel l, candidate j) pair: factor q = 1 - exp(-sigma d^2) folded into the pixel's integer log2 sum.
+// sig2 = sigmainv / multiplier^2 (d is in multiplier units).
+template <class Stage>
+__device__ inline void soft_pair(const RasterArgs& a, const TileCtx& t, Stage* st, float sig2, int l, int j, bool live) {
+    const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
+    const float4 p0 = st->p0[j], p1 = st->p1[j];
+    const float d = fminf(fminf(seg_dist2_fast(x0, y0, p0.x, p0.y, p0.z, p0.w), seg_dist2_fast(x0, y0, p0.z, p0.w, p1.x, p1.y)),
+                          seg_dist2_fast(x0, y0, p1.x, p1.y, p0.x, p0.y));
+    const float q = 1.f - __builtin_amdgcn_exp2f(-(d * sig2) * 1.4426950408889634f);
+    if (live) {
+        if (q == 0.f) atomicAdd(&st->zeros[l], 1);
+        else {                                                   // log2(q) in 2^-32 fixed point: floor part and 32 fraction bits
+            const float x = __builtin_amdgcn_logf(q);
+            const float hi = floorf(x);
+            const unsigned lo = (unsigned)((x - hi) * 4294967296.f);
+            atomicAdd((unsigned long long*)&st->logsum[l], ((unsigned long long)(long long)(int)hi << 32) + lo);
+        }
+    }
+}
+
+// soft-mask candidates of this lane in the staged batch: its inflated-box hits, in order, truncated so that the lane
+// never takes more than `room` further faces (kaolin keeps the first knum).
+__device__ inline uint64_t soft_take(uint64_t sm, bool open, int room) {
+    if (!open || room <= 0) return 0;
+    if (__popcll(sm) > room) {                                   // keep the first `room` set bits (rare)
+        uint64_t kept = 0;
+        for (int i = 0; i < room; ++i) { const uint64_t low = sm & (~sm + 1); kept |= low; sm ^= low; }
+        sm = kept;
+    }
+    return sm;
+}
+
+struct SoftState { float qnz; int zeros, lastf; };
+
+// ---- shading (a9-a11), stores, fused recon_data partial sums.  Uncovered pixels carry zero features exactly like kaolin's
+// interpolated_features.  (n0,n1,n2) = unit normal of the winning face (ignored when h.f < 0).
+// (lanes outside a ragged image only stay for the fused loss reduction: they address a clamped pixel and store nothing)
+template <bool kNoMask>
+__device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const Hit& h, float n0, float n1, float n2, const SoftState& ss) {
+    if (!t.in_img && !a.gt) return;
+    const int cpx = min(t.px, a.W - 1), cpy = min(t.py, a.H - 1);
+    const size_t pix = ((size_t)t.b * a.H + cpy) * a.W + cpx;
+    const size_t hw = (size_t)a.H * a.W, pin = (size_t)cpy * a.W + cpx;
+    // background and ground truth depend on nothing: issue their loads ahead of the uv -> texel chain
+    float bgv[3] = {0.f, 0.f, 0.f}, gtv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kNoMask) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bgv[c] = a.bg[((size_t)t.b * 3 + c) * hw + pin];
+    }
+    if (a.gt && t.in_img) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gtv[c] = a.gt[((size_t)t.b * 4 + c) * hw + pin];
+    }
+    float m = 0.f, u = 0.f, v = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    if (h.f >= 0) {
+        const float* fu = a.face_uvs + (size_t)h.f * 6;
+        m = (h.w0 + h.w1) + h.w2;
+        u = (h.w0 * fu[0] + h.w1 * fu[2]) + h.w2 * fu[4];
+        v = (h.w0 * fu[1] + h.w1 * fu[3]) + h.w2 * fu[5];
+        nx = (h.w0 * n0 + h.w1 * n0) + h.w2 * n0;
+        ny = (h.w0 * n1 + h.w1 * n1) + h.w2 * n1;
+        nz = (h.w0 * n2 + h.w1 * n2) + h.w2 * n2;
+    }
+    const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
+    const bool inw = s.x0 < a.Wt && s.y0 < a.Ht, ine = s.x1 < a.Wt && s.y0 < a.Ht;
+    const bool isw = s.x0 < a.Wt && s.y1 < a.Ht, ise = s.x1 < a.Wt && s.y1 < a.Ht;
+    float bnd[9];
+    sh_bands(nx, ny, nz, bnd);
+    const float* L = a.lights + t.b * 9;
+    float coef = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) coef += bnd[i] * L[i];
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* tex = a.textures + ((size_t)t.b * 3 + c) * a.Ht * a.Wt;
+        float tc = 0.f;
+        if (inw) tc += tex[(size_t)s.y0 * a.Wt + s.x0] * s.wnw;
+        if (ine) tc += tex[(size_t)s.y0 * a.Wt + s.x1] * s.wne;
+        if (isw) tc += tex[(size_t)s.y1 * a.Wt + s.x0] * s.wsw;
+        if (ise) tc += tex[(size_t)s.y1 * a.Wt + s.x1] * s.wse;
+        float val;
+        if (kNoMask) {
+            const float g = bgv[c];
+            val = (tc * m + g * (1.f - m)) * coef;
+        } else {
+            val = (tc * m) * coef + 1.f * (1.f - m);
+        }
+        out[c] = val < 0.f ? 0.f : (val > 1.f ? 1.f : val);
+    }
+    const float keepprod = ss.zeros > 0 ? 0.f : ss.qnz;
+    out[3] = (h.f >= 0) ? 1.f : (1.f - keepprod);
+    if (t.in_img) {
+        *(float4*)(a.rgba + pix * 4) = make_float4(out[0], out[1], out[2], out[3]);
+        a.face_idx[pix] = h.f;
+        a.softq[pix] = (h.f >= 0 || ss.zeros >= 2) ? 0.f : (ss.zeros == 1 ? -ss.qnz : ss.qnz);
+        if (h.f < 0) a.lastf[pix] = ss.lastf;
+        if (a.imnormal) { a.imnormal[pix * 3] = nx; a.imnormal[pix * 3 + 1] = ny; a.imnormal[pix * 3 + 2] = nz; }
+    }
+    if (a.gt) {                                                  // recon_data terms of this tile (networks.py:370-377)
+        float l1 = 0.f, up = 0.f, down = 0.f;
+        if (t.in_img) {
+            const float gm = gtv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gi = gtv[c] * gm + 1.f * (1.f - gm);
+                const float pi = out[c] * gm + 1.f * (1.f - gm);
+                l1 += fabsf(pi - gi);
+            }
+            up = out[3] * gm; down = (out[3] + gm) - up;
+        }
+        l1 = wave_sum(l1); up = wave_sum(up); down = wave_sum(down);
+        if (t.lane == 0) a.lpart[((size_t)t.b * a.blocks_per_image + t.blk) * 4 + t.wave] = make_float4(l1, up, down, 0.f);
+    }
+}
+
+// launch plumbing shared by the two kernels' translation units
+RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w);
+bool resident_path(const MMRenderDesc* d);
+int launch_raster_fwd_resident(const MMRenderDesc* d, const Workspace& w, hipStream_t s);
+
+}  // namespace mm

@@ -72,12 +72,14 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
 }
 
 // ---- screen binning ---------------------------------------------------------------------------------------------------
-// One wave per (image, REGION of 4x4 bins, mask word = 64 faces): every lane tests its face's box against the
-// region's 4 bin columns and 4 bin rows (closed-box test on the pixel-centre extent of each bin, computed with the same
-// monotone formula as the pixel centres, so it is exactly conservative), and 16 ballots per kind turn the lanes'
-// 4x4 coverage into the 16 bins' mask words.  Plain stores, every word written: no atomics and no zero-fill.
+// One wave per (image, mask word = 64 faces, one of `parts` slices of the image's REGIONS of 4x4 bins): every lane loads its
+// face once, then for each region of the slice tests the box against the region (wave-wide reject: most region/word pairs
+// are empty and only get their zeros stored) and, if some lane touches it, against the region's 4 bin columns and 4 bin
+// rows (closed-box test on the pixel-centre extent of each bin, computed with the same monotone formula as the pixel
+// centres, so it is exactly conservative); 16 ballots per kind turn the lanes' 4x4 coverage into the 16 bins' mask words.
+// Plain stores, every word written: no atomics and no zero-fill.
 struct BinArgs {
-    int B, F, H, W, bin_shift, nbx, nby, words;
+    int B, F, H, W, bin_shift, nbx, nby, words, parts;
     float mult, infl;
     const float4* geo;
     uint64_t* soft;
@@ -87,50 +89,70 @@ struct BinArgs {
 __global__ __launch_bounds__(256) void bin_kernel(BinArgs a) {
     const int lane = threadIdx.x & 63;
     const int rx = (a.nbx + 3) >> 2, ry = (a.nby + 3) >> 2;
-    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per (image, region, mask word)
-    if (gw >= (long long)a.B * rx * ry * a.words) return;
-    const int c = (int)(gw % a.words);
-    const int br = (int)(gw / a.words);
-    const int b = br / (rx * ry), r = br - b * (rx * ry);
-    const int bx0 = (r % rx) * 4, by0 = (r / rx) * 4;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= (long long)a.B * a.words * a.parts) return;
+    const int part = (int)(gw % a.parts);
+    const int bc = (int)(gw / a.parts);
+    const int c = bc % a.words, b = bc / a.words;
     const int f = c * 64 + lane;
-    unsigned cs = 0, ch = 0;
-    if (f < a.F) {
+    const bool on = f < a.F;
+    float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
+    bool front = false;
+    if (on) {
         const float4* geo = a.geo + ((size_t)b * a.F + f) * 3;
         const float4 g0 = geo[0], g1 = geo[1];
-        const float nz = geo[2].y;
-        const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
-        const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
-        unsigned cols = 0, rows = 0, colh = 0, rowh = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // pixel-centre extent of bin column / row i of this region
-            const int px0 = (bx0 + i) << a.bin_shift, px1 = min(((bx0 + i + 1) << a.bin_shift) - 1, a.W - 1);
-            const int py0 = (by0 + i) << a.bin_shift, py1 = min(((by0 + i + 1) << a.bin_shift) - 1, a.H - 1);
-            const float xlo = pixel_x(px0, a.W, a.mult), xhi = pixel_x(px1, a.W, a.mult);
-            const float yhi = pixel_y(py0, a.H, a.mult), ylo = pixel_y(py1, a.H, a.mult);
-            cols |= (unsigned)(!(xmax + a.infl < xlo || xmin - a.infl > xhi)) << i;
-            rows |= (unsigned)(!(ymax + a.infl < ylo || ymin - a.infl > yhi)) << i;
-            colh |= (unsigned)(!(xmax < xlo || xmin > xhi)) << i;
-            rowh |= (unsigned)(!(ymax < ylo || ymin > yhi)) << i;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cs |= ((rows >> k) & 1u) ? (cols << (4 * k)) : 0u;
-            ch |= ((rowh >> k) & 1u) ? (colh << (4 * k)) : 0u;
-        }
-        if (!(nz >= 0.f)) ch = 0;                                // colour only sees front faces (a8)
+        front = geo[2].y >= 0.f;                                  // colour only sees front faces (a8)
+        xmin = fminf(fminf(g0.x, g0.z), g1.x); ymin = fminf(fminf(g0.y, g0.w), g1.y);
+        xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x); ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
     }
-    uint64_t ms = 0, mh = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint64_t s1 = __ballot((cs >> j) & 1u), h1 = __ballot((ch >> j) & 1u);
-        if (lane == j) { ms = s1; mh = h1; }
-    }
+    const float sxmin = xmin - a.infl, sxmax = xmax + a.infl, symin = ymin - a.infl, symax = ymax + a.infl;
     const int i4 = lane & 3, k4 = (lane >> 2) & 3;
-    if (lane < 16 && (bx0 + i4) < a.nbx && (by0 + k4) < a.nby) {
-        const size_t row = ((size_t)b * a.nbx * a.nby + (size_t)(by0 + k4) * a.nbx + (bx0 + i4)) * a.words;
-        a.soft[row + c] = ms; a.hard[row + c] = mh;
+    for (int r = part; r < rx * ry; r += a.parts) {
+        const int bx0 = (r % rx) * 4, by0 = (r / rx) * 4;
+        // pixel-centre extent of the whole region
+        const float rxlo = pixel_x(bx0 << a.bin_shift, a.W, a.mult), rxhi = pixel_x(min(((bx0 + 4) << a.bin_shift) - 1, a.W - 1), a.W, a.mult);
+        const float ryhi = pixel_y(by0 << a.bin_shift, a.H, a.mult), rylo = pixel_y(min(((by0 + 4) << a.bin_shift) - 1, a.H - 1), a.H, a.mult);
+        const bool touch = on && !(sxmax < rxlo || sxmin > rxhi) && !(symax < rylo || symin > ryhi);
+        uint64_t ms = 0, mh = 0;
+        if (__ballot(touch)) {
+            unsigned cols = 0, rows = 0, colh = 0, rowh = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // pixel-centre extent of bin column / row i of this region
+                const int px0 = (bx0 + i) << a.bin_shift, px1 = min(((bx0 + i + 1) << a.bin_shift) - 1, a.W - 1);
+                const int py0 = (by0 + i) << a.bin_shift, py1 = min(((by0 + i + 1) << a.bin_shift) - 1, a.H - 1);
+                const float xlo = pixel_x(px0, a.W, a.mult), xhi = pixel_x(px1, a.W, a.mult);
+                const float yhi = pixel_y(py0, a.H, a.mult), ylo = pixel_y(py1, a.H, a.mult);
+                cols |= (unsigned)(!(sxmax < xlo || sxmin > xhi)) << i;
+                rows |= (unsigned)(!(symax < ylo || symin > yhi)) << i;
+                colh |= (unsigned)(!(xmax < xlo || xmin > xhi)) << i;
+                rowh |= (unsigned)(!(ymax < ylo || ymin > yhi)) << i;
+            }
+            unsigned cs = 0, ch = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cs |= ((rows >> k) & 1u) ? (cols << (4 * k)) : 0u;
+                ch |= ((rowh >> k) & 1u) ? (colh << (4 * k)) : 0u;
+            }
+            if (!on) cs = 0;
+            if (!on || !front) ch = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint64_t s1 = __ballot((cs >> j) & 1u);
+                if (lane == j) ms = s1;
+            }
+            if (__ballot(ch != 0)) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t h1 = __ballot((ch >> j) & 1u);
+                    if (lane == j) mh = h1;
+                }
+            }
+        }
+        if (lane < 16 && (bx0 + i4) < a.nbx && (by0 + k4) < a.nby) {
+            const size_t row = ((size_t)b * a.nbx * a.nby + (size_t)(by0 + k4) * a.nbx + (bx0 + i4)) * a.words;
+            a.soft[row + c] = ms; a.hard[row + c] = mh;
+        }
     }
 }
 
@@ -299,7 +321,9 @@ int launch_bin(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     a.B = d->B; a.F = d->F; a.H = d->H; a.W = d->W; a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.infl = d->boxlen * d->multiplier;
     a.geo = w.geo; a.soft = w.binmask; a.hard = w.binmask_hard;
-    const long long waves = (long long)d->B * ((w.nbx + 3) / 4) * ((w.nby + 3) / 4) * w.words;
+    const int regions = ((w.nbx + 3) / 4) * ((w.nby + 3) / 4);
+    a.parts = regions >= 16 ? 4 : (regions >= 4 ? 2 : 1);        // waves per (image, word): enough of them to fill the chip
+    const long long waves = (long long)d->B * w.words * a.parts;
     { ProfScope ps(d->prof_events, MM_PROF_BIN, s);
       hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); }
     return launch_ok("bin");

@@ -147,6 +147,7 @@ class DiffRender(object):
         self.lambda_flat = lambda_flat
         self.ratio = ratio
         self.emit_imnormal = emit_imnormal
+        self.options = 0                                # MMRenderDesc.options (N.OPT_RESIDENT: LDS-resident forward kernel)
         camera_fovy = np.arctan(1.0 / 2.5) * 2
         self.cam_proj = template.generate_perspective_projection(camera_fovy, ratio=1 / ratio)     # networks.py:172-174
         mesh = obj_io.load_template(mesh_name)                                                   # :176
@@ -224,6 +225,7 @@ class DiffRender(object):
         uo, uf = self._uv_tiles(vertices.device, d.Ht, d.Wt)
         d.uvt_offsets, d.uvt_faces, d.uvt_size = N.ptr(uo), N.ptr(uf), N.UV_TILE
         d.face_order = N.ptr(st["face_order"])
+        d.options = self.options
         return d
 
     # ---- networks.py:258-324 -------------------------------------------------------------------------------------

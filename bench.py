@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="successive (independent) steps are enqueued round-robin on this many HIP streams, each with its own buffers")
     ap.add_argument("--unfused", action="store_true", help="recon_data as its own three launches instead of folded into the render kernels")
+    ap.add_argument("--resident", action="store_true", help="opt into the LDS-resident forward kernel (MM_OPT_RESIDENT)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--profile-steps", type=int, default=30, help="extra eager steps with per-kernel HIP events")
     args = ap.parse_args()
@@ -87,6 +88,8 @@ def main():
     stepmod = importlib.import_module("3d-magic-mirror_amd.step")
     name, B, S, ratio = CONFIGS[args.config]
     dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio, emit_imnormal=False)
+    if args.resident:
+        dr.options = pkg._native.OPT_RESIDENT
     H, W = dr.render_height, dr.image_size
     att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=rank)
     datt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}

@@ -94,7 +94,14 @@ typedef struct MMRenderDesc {
     float fused_image_weight;       /* DiffRender.image_weight */
     float* fused_loss;              /* (1) device scalar, written by mm_render_backward; may be NULL */
     const float* fused_grad_loss;   /* (1) device scalar dL/dloss, or NULL for 1 */
+    int32_t options;                /* bit set of MM_OPT_*; 0 = let the library choose */
 } MMRenderDesc;
+
+/* mm_render_forward has two pixel kernels with bit-identical results: "streamed" (any mesh size, via screen-bin masks; the
+ * default) and "resident" (templates whose transformed vertices fit the LDS of a workgroup -- the reference's 642-vertex
+ * meshes: fewer vector instructions and no bin / order launches, but a longer tail; opt-in while it is being tuned). */
+enum { MM_OPT_STREAMED = 1,         /* force the streamed kernels */
+       MM_OPT_RESIDENT = 2 };       /* use the resident kernel when the template fits (else streamed) */
 
 enum { MM_PROF_VERTEX_FWD = 0, MM_PROF_RASTER_FWD = 1, MM_PROF_PIXEL_BWD = 2, MM_PROF_GATHER_BWD = 3, MM_PROF_VERTEX_BWD = 4,
        MM_PROF_BIN = 5, MM_PROF_ORDER = 6, MM_PROF_RENDER_SLOTS = 7 };

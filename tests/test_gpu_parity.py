@@ -93,6 +93,37 @@ def test_resident_and_streamed_forward_kernels_agree_bit_for_bit(pkg, name, B, S
         _close(a[4][k].cpu().numpy(), b[4][k].cpu().numpy(), 1e-6)
 
 
+@pytest.mark.parametrize("knum,boxlen,sigmainv,dist,resident", [
+    (3, 0.02, 7000.0, None, False),      # knum far below the candidates per pixel: the "first knum faces in index order" rule
+    (3, 0.02, 7000.0, None, True),
+    (30, 0.02, 7000.0, 9.0, False),      # far camera: the whole mesh in a few tiles, > 30 candidates per silhouette pixel
+    (30, 0.02, 7000.0, 9.0, True),
+    (7, 0.08, 900.0, None, False),       # wide soft margin, flat falloff: many more faces per pixel, tiles with > 64 candidates
+    (7, 0.08, 900.0, None, True),
+])
+def test_soft_mask_truncation_and_margins_match_oracle(pkg, oracle, knum, boxlen, sigmainv, dist, resident):
+    """dibr_rasterization's knum / boxlen / sigmainv away from their defaults: forward and backward."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "sphere", 3, 64, seed=11)
+    dr.knum, dr.boxlen, dr.sigmainv = knum, boxlen, sigmainv
+    dr.options = pkg._native.OPT_RESIDENT if resident else 0
+    if dist is not None:
+        with torch.no_grad():
+            datt["distances"].fill_(dist)
+        inp["distances"] = np.full_like(inp["distances"], dist)
+    rgbs, out = dr.render(no_mask=True, **datt)
+    dr.recon_data(rgbs, gt.to(dev), no_mask=True).backward()
+    kw = dict(knum=knum, boxlen=boxlen, sigmainv=sigmainv)
+    rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, True, proj, **kw)
+    loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+    g_o = oracle.render_backward(inp, H, W, True, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None, **kw)
+    assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
+    alpha = rgba_o[..., 3]
+    assert ((alpha > 0.01) & (alpha < 0.99)).mean() > 0.005          # there is a silhouette band to get wrong
+    _close(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
+    for k in LEAVES:
+        _close(datt[k].grad.cpu().numpy(), g_o[k])
+
+
 def test_recon_data_matches_reference_golden(pkg):
     z = np.load(os.path.join(GOLDEN, "losses.npz"))
     dev = torch.device("cuda:0")

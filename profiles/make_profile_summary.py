@@ -41,6 +41,22 @@ if os.path.exists(pm):
         traffic[name] = int(b)
         hit = c.get("TCC_HIT_sum", 0); miss = c.get("TCC_MISS_sum", 0)
         lines.append("| %s | %.0f | %.0f | %.2f | %.0f | %.0f |" % (k, c["FETCH_SIZE"], c.get("WRITE_SIZE", 0), b / 1e6, 100 * hit / max(1, hit + miss), c.get("TCC_EA0_ATOMIC_sum", 0)))
+    # VALU issue: a wave64 vector instruction occupies its SIMD16 for 4 cycles, so a kernel cannot finish before
+    # SQ_INSTS_VALU * 4 / (256 CUs * 4 SIMDs) cycles; at 2.4 GHz that bound is compared with the measured duration.
+    if st:
+        dur = {r["Name"].split("(")[0].replace("void ", "").replace("mm::", ""): float(r["AverageNs"]) / 1e3 for r in rows}
+        lines += ["", "## Vector-instruction issue (SQ_INSTS_VALU per launch; floor = 4 cycles each over 1024 SIMDs at 2.4 GHz)", "",
+                  "| kernel | waves | VALU instr | VALU/wave | SALU instr | LDS instr | issue floor us | measured us | floor/measured |", "|---|---|---|---|---|---|---|---|---|"]
+        tot_floor = 0.0
+        for k, c in sorted(s.items()):
+            if "SQ_INSTS_VALU" not in c or k not in dur: continue
+            floor = c["SQ_INSTS_VALU"] * 4 / 1024 / 2400.0
+            tot_floor += floor
+            lines.append("| %s | %.0f | %.0f | %.0f | %.0f | %.0f | %.1f | %.1f | %.2f |" % (
+                k, c.get("SQ_WAVES", 0), c["SQ_INSTS_VALU"], c["SQ_INSTS_VALU"] / max(1, c.get("SQ_WAVES", 1)), c.get("SQ_INSTS_SALU", 0),
+                c.get("SQ_INSTS_LDS", 0), floor, dur[k], floor / dur[k]))
+        lines += ["", "sum of issue floors: %.1f us per step (%.0f images/s at B=48): the ceiling of this instruction mix however well launches overlap" % (
+            tot_floor, 48 / (tot_floor * 1e-6))]
     if "recon_bwd" in traffic:
         lines += ["", "calibration: recon_bwd should move 48 B/pixel * 48*128*128 = %.2f MB; PMC-derived %.2f MB" % (48 * 48 * 128 * 128 / 1e6, traffic["recon_bwd"] / 1e6)]
     json.dump({"config2": traffic, "note": "(2*FETCH_SIZE+WRITE_SIZE)*1024 per launch, " + tag}, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1, sort_keys=True)

@@ -267,13 +267,20 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         for (int i = 0; i < 12; ++i) s_red[tid >> 6][i] = acc[i];
     }
     __syncthreads();
-    if (tid < 12) atomicAdd(a.dTacc + b * 12 + tid, ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid]);
+    if (tid < 12) {
+        // RETURNING atomic: its value only comes back once the add has been performed where agent-scope atomics live, so the
+        // wait below really orders it before this workgroup's ticket
+        const float old = atomicAdd(a.dTacc + b * 12 + tid, ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid]);
+        asm volatile("" :: "v"(old));
+    }
     // ---- publish, take a ticket; the last workgroup of this image finishes the camera chain
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // No agent-scope fences here: a release fence writes back the XCD's whole L2 and an acquire invalidates it, once per
+        // workgroup.  What the last workgroup reads from the others is dTacc only, and that is written with agent-scope
+        // atomics (performed at the memory side, never resident dirty in an L2) that have been waited for (vmcnt) before
+        // the ticket is taken, and read back with agent-scope atomic loads.
         const unsigned prev = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (prev == gridDim.x - 1) ? 1 : 0;
     }
@@ -293,7 +300,6 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
     }
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         float dT[12];
         for (int i = 0; i < 12; ++i) dT[i] = __hip_atomic_load(a.dTacc + b * 12 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float dd, de, da, db[2];

@@ -29,6 +29,8 @@ CONFIGS = {
     # name: (template, B, image_size, ratio)
     "config2": ("smpl_uv_642", 48, 128, 1),
     "config1": ("sphere", 4, 64, 1),
+    "config2x3": ("smpl_uv_642", 144, 128, 1),      # experiment: three config-2 batches in one call
+    "config2x8": ("smpl_uv_642", 384, 128, 1),
     "market": ("smpl_uv_642", 48, 64, 2),
     "config3": ("ellipsoid", 48, 256, 1),
     "config5": ("smpl_uv", 16, 512, 1),

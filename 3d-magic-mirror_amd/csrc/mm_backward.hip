@@ -544,7 +544,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.uvt_offsets = d->uvt_offsets; a.uvt_faces = d->uvt_faces; a.face_order = d->face_order;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures; a.dfxy = w.dfxy; a.dfn = w.dfn;
-    if (hipMemsetAsync(w.tcnt, 0, ((size_t)d->B * w.ntiles + d->B) * sizeof(int), s) != hipSuccess) return MM_ERR_LAUNCH;
+    // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)
     {
         ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
         dim3 grid(a.blocks_per_image * d->B);

@@ -19,6 +19,7 @@ struct VertexFwdArgs {
     float* T;
     float4* geo;
     float* face_normals;
+    int* tcnt; int ntcnt;    // texture-record counters of the backward: cleared here for the first backward after this forward
 };
 
 __device__ inline void block_camera(const float* azim, const float* elev, const float* dist, const float* bias, int b,
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     __shared__ float s_trig[4];
     __shared__ Camera s_cam;
     const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
     if (blockIdx.x == 0 && tid < 12) a.T[b * 12 + tid] = s_cam.T[tid];
     float T[12];
@@ -170,6 +172,7 @@ struct VertexBwdArgs {
     const float* gfn;       // (B,F,3) external gradient of attributes['face_normals'] or NULL
     float* dTacc;           // (B,12) zeroed accumulator
     unsigned* ticket;       // (B) zeroed arrival counter
+    int* tcnt; int ntcnt;   // texture-record counters, consumed by the gather before this kernel: cleared for the next backward
     const float* dl_part;   // (B,blocks,12) partial dL/dlights of the pixel backward
     int blocks_per_image;
     float* grad_lights;
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
     __shared__ float s_red[4][12];
     __shared__ int s_last;
     const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = a.T[b * 12 + i];
@@ -316,6 +320,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.faces = d->faces; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.geo = w.geo; a.face_normals = d->face_normals;
+    a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B;
     dim3 grid((d->F + 255) / 256, d->B);
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
       hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }
@@ -343,6 +348,7 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.dfxy = w.dfxy; a.dfn = w.dfn; a.gfn = g->grad_face_normals;
     a.dTacc = w.dTacc; a.ticket = w.ticket;
+    a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B;
     a.dl_part = w.dl_part; a.blocks_per_image = w.blocks_per_image; a.grad_lights = g->grad_lights;
     a.grad_vertices = g->grad_vertices;
     a.grad_azim = g->grad_azimuths; a.grad_elev = g->grad_elevations; a.grad_dist = g->grad_distances; a.grad_bias = g->grad_biases;

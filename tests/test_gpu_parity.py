@@ -124,6 +124,19 @@ def test_soft_mask_truncation_and_margins_match_oracle(pkg, oracle, knum, boxlen
         _close(datt[k].grad.cpu().numpy(), g_o[k])
 
 
+def test_backward_twice_after_one_forward(pkg):
+    """retain_graph: the backward leaves its scratch counters the way it found them (the library clears them in-kernel)."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 4, 96, seed=21)
+    rgbs, _ = dr.render(no_mask=True, **datt)
+    loss = dr.recon_data(rgbs, gt.to(dev), no_mask=True)
+    loss.backward(retain_graph=True)
+    first = {k: datt[k].grad.clone() for k in LEAVES}
+    loss.backward()
+    for k in LEAVES:
+        _close(datt[k].grad.cpu().numpy(), 2.0 * first[k].cpu().numpy(), 1e-6)
+        assert float(first[k].abs().max()) > 0
+
+
 def test_recon_data_matches_reference_golden(pkg):
     z = np.load(os.path.join(GOLDEN, "losses.npz"))
     dev = torch.device("cuda:0")

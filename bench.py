@@ -180,6 +180,21 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(kernels_us[dom], 3)}
+        # What actually bounds this path is vector-instruction issue, not HBM: a wave64 VALU instruction holds
+        # its SIMD16 for 4 cycles, so one step cannot take less than sum(SQ_INSTS_VALU) * 4 / (1024 SIMDs * 2.4 GHz).  The counts
+        # come from the committed rocprofv3 --pmc pass of this same workload (profiles/valu_latest.json).
+        vpath = os.path.join(ROOT, "profiles", "valu_latest.json")
+        if os.path.exists(vpath):
+            try:
+                insts = json.load(open(vpath)).get(args.config)
+                if insts:
+                    floor_us = sum(insts.values()) * 4.0 / 1024.0 / 2400.0
+                    step_us = elapsed / args.steps * 1e6 / 1.0
+                    roofline["valu_issue"] = {"insts_per_step": int(sum(insts.values())), "floor_us_per_step": round(floor_us, 2),
+                                              "measured_us_per_step": round(step_us, 2), "frac": round(floor_us / step_us, 4),
+                                              "dominant_kernel_frac": round(insts.get(dom, 0) * 4.0 / 1024.0 / 2400.0 / kernels_us[dom], 4)}
+            except Exception:
+                pass
 
     # ---- CPU baseline: the oracle's step (C restatement of the kaolin DIB-R semantics) on the host cores ----------
     cpu = None

@@ -55,6 +55,9 @@ if os.path.exists(pm):
             lines.append("| %s | %.0f | %.0f | %.0f | %.0f | %.0f | %.1f | %.1f | %.2f |" % (
                 k, c.get("SQ_WAVES", 0), c["SQ_INSTS_VALU"], c["SQ_INSTS_VALU"] / max(1, c.get("SQ_WAVES", 1)), c.get("SQ_INSTS_SALU", 0),
                 c.get("SQ_INSTS_LDS", 0), floor, dur[k], floor / dur[k]))
+        json.dump({"config2": {k.replace("_kernel", "").replace("<true>", "").replace("<false>", ""): c["SQ_INSTS_VALU"] for k, c in s.items()
+                               if "SQ_INSTS_VALU" in c and k in dur},
+                   "note": "SQ_INSTS_VALU per launch, " + tag}, open(os.path.join(out, "valu_latest.json"), "w"), indent=1, sort_keys=True)
         lines += ["", "sum of issue floors: %.1f us per step (%.0f images/s at B=48): the ceiling of this instruction mix however well launches overlap" % (
             tot_floor, 48 / (tot_floor * 1e-6))]
     if "recon_bwd" in traffic:

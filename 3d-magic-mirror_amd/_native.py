@@ -41,6 +41,19 @@ class MMReconDesc(ctypes.Structure):
                 ("image_weight", c_f), ("contour", c_f), ("loss", c_p), ("grad_loss", c_p), ("grad_pred", c_p),
                 ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p)]
 
+class MMMeshRegDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("V", c_i), ("F", c_i), ("E", c_i), ("terms", ctypes.c_uint32),
+                ("lap_offsets", c_p), ("lap_cols", c_p), ("lap_vals", c_p), ("lapT_offsets", c_p), ("lapT_cols", c_p), ("lapT_vals", c_p),
+                ("edges", c_p), ("edge2faces", c_p), ("ve_offsets", c_p), ("ve_items", c_p), ("fe_offsets", c_p), ("fe_items", c_p),
+                ("flip_index", c_p), ("flipT_offsets", c_p), ("flipT_items", c_p), ("sign_init", c_p),
+                ("vertices", c_p), ("delta_vertices", c_p), ("face_normals", c_p), ("ratio", c_f), ("temp", c_f), ("eps", c_f),
+                ("losses", c_p), ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
+class MMMeshRegGrads(ctypes.Structure):
+    _fields_ = [("weights", c_p), ("grad_vertices", c_p), ("grad_delta_vertices", c_p), ("grad_face_normals", c_p)]
+
+
 PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "bin", "order")
 UV_TILE = 32
 OPT_STREAMED = 1
@@ -49,6 +62,7 @@ PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",
            "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_uv_tiles", "mm_nearest_neighbour", "mm_status_string", "mm_last_error_detail",
+           "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward",
            "mm_abi_version")
 
 
@@ -79,6 +93,10 @@ def lib():
     L.mm_recon_data_forward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
     L.mm_recon_data_backward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
     L.mm_nearest_neighbour.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]
+    L.mm_mesh_reg_query_workspace.restype = ctypes.c_size_t
+    L.mm_mesh_reg_query_workspace.argtypes = [ctypes.POINTER(MMMeshRegDesc)]
+    L.mm_mesh_reg_forward.argtypes = [ctypes.POINTER(MMMeshRegDesc), c_p]
+    L.mm_mesh_reg_backward.argtypes = [ctypes.POINTER(MMMeshRegDesc), ctypes.POINTER(MMMeshRegGrads), c_p]
     L.mm_build_vertex_corner_csr.argtypes = [c_i, c_i, c_p, c_p, c_p]
     L.mm_build_uv_tiles.argtypes = [c_i, c_p, c_i, c_i, c_p, c_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.mm_status_string.restype = ctypes.c_char_p

@@ -13,6 +13,9 @@ size_t recon_workspace_bytes(const MMReconDesc*);
 int launch_recon_fwd(const MMReconDesc*, hipStream_t);
 int launch_recon_bwd(const MMReconDesc*, hipStream_t);
 int launch_nn(int, int, int, const float*, const float*, float*, int32_t*, hipStream_t);
+size_t reg_workspace_bytes(const MMMeshRegDesc*);
+int launch_reg_fwd(const MMMeshRegDesc*, hipStream_t);
+int launch_reg_bwd(const MMMeshRegDesc*, const MMMeshRegGrads*, hipStream_t);
 }  // namespace mm
 
 static int check_render(const MMRenderDesc* d, bool backward) {
@@ -98,6 +101,49 @@ int mm_nearest_neighbour(int32_t B, int32_t N, int32_t M, const float* x, const 
     if (B <= 0 || N <= 0 || M <= 0) return MM_ERR_BAD_SHAPE;
     mm::clear_stale_error();
     return mm::launch_nn(B, N, M, x, y, dist, idx, (hipStream_t)stream);
+}
+
+static int check_reg(const MMMeshRegDesc* d, bool backward) {
+    if (!d) return MM_ERR_NULL_POINTER;
+    if (d->B <= 0 || d->V <= 0 || d->F <= 0 || d->E < 0) return MM_ERR_BAD_SHAPE;
+    if (d->terms == 0 || d->terms >= (1u << MM_REG_TERMS)) return MM_ERR_BAD_SHAPE;
+    const unsigned need_v = (1u << MM_REG_EDGE) | (1u << MM_REG_DEPTH) | (1u << MM_REG_DEPTHR) | (1u << MM_REG_DEPTHC);
+    const unsigned need_d = (1u << MM_REG_LAPLACIAN) | (1u << MM_REG_DEFORM) | (1u << MM_REG_FLIP);
+    if ((d->terms & need_v) && (!d->vertices || !d->sign_init)) return MM_ERR_NULL_POINTER;
+    if ((d->terms & need_d) && !d->delta_vertices) return MM_ERR_NULL_POINTER;
+    if ((d->terms & (1u << MM_REG_FLAT)) && (!d->face_normals || !d->edge2faces || (backward && (!d->fe_offsets || !d->fe_items)))) return MM_ERR_NULL_POINTER;
+    if ((d->terms & (1u << MM_REG_LAPLACIAN)) && (!d->lap_offsets || !d->lap_cols || !d->lap_vals ||
+                                                   (backward && (!d->lapT_offsets || !d->lapT_cols || !d->lapT_vals)))) return MM_ERR_NULL_POINTER;
+    if ((d->terms & (1u << MM_REG_EDGE)) && (!d->edges || (backward && (!d->ve_offsets || !d->ve_items)))) return MM_ERR_NULL_POINTER;
+    if ((d->terms & (1u << MM_REG_FLIP)) && (!d->flip_index || !d->sign_init || (backward && (!d->flipT_offsets || !d->flipT_items)))) return MM_ERR_NULL_POINTER;
+    if ((d->terms & ((1u << MM_REG_DEPTHR) | (1u << MM_REG_DEPTHC))) && !(d->ratio > 0.f)) return MM_ERR_BAD_SHAPE;
+    if (!backward && !d->losses) return MM_ERR_NULL_POINTER;
+    if (!d->workspace || d->workspace_bytes < mm_mesh_reg_query_workspace(d)) return MM_ERR_WORKSPACE;
+    return MM_OK;
+}
+
+size_t mm_mesh_reg_query_workspace(const MMMeshRegDesc* d) {
+    if (!d || d->B <= 0 || d->V <= 0 || d->E < 0) return 0;
+    return mm::reg_workspace_bytes(d);
+}
+
+int mm_mesh_reg_forward(const MMMeshRegDesc* d, mm_stream_t stream) {
+    const int st = check_reg(d, false);
+    if (st != MM_OK) return st;
+    mm::clear_stale_error();
+    return mm::launch_reg_fwd(d, (hipStream_t)stream);
+}
+
+int mm_mesh_reg_backward(const MMMeshRegDesc* d, const MMMeshRegGrads* g, mm_stream_t stream) {
+    const int st = check_reg(d, true);
+    if (st != MM_OK) return st;
+    if (!g || !g->weights) return MM_ERR_NULL_POINTER;
+    if (!g->grad_vertices && !g->grad_delta_vertices && !g->grad_face_normals) return MM_ERR_NULL_POINTER;
+    if ((g->grad_vertices && (!d->vertices || !d->sign_init)) || (g->grad_delta_vertices && !d->delta_vertices) ||
+        (g->grad_face_normals && !d->face_normals))
+        return MM_ERR_NULL_POINTER;                              // a gradient is only defined for an input that was given
+    mm::clear_stale_error();
+    return mm::launch_reg_bwd(d, g, (hipStream_t)stream);
 }
 
 int mm_build_uv_tiles(int32_t F, const float* fuv, int32_t Ht, int32_t Wt, int32_t* offsets, int32_t* items, int64_t capacity,

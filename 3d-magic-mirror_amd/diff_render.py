@@ -3,8 +3,9 @@
 Same constructor, attributes, method names, argument meaning and return values as the reference class, so a
 ``trainer.py``-style loop can switch with ``from mm_amd import DiffRender``.  ``render`` and ``recon_data`` run the
 hand-written HIP kernels of ``lib/libmm_render.so`` through ``torch.autograd.Function`` wrappers; there is no CPU or
-eager-torch fallback for them.  The mesh regularisers / attribute losses (``recon_att``, ``recon_flip``, ``calc_reg_*``;
-SURVEY.md 8(f) rank 1) are restated in torch ops exactly as the reference computes them.
+eager-torch fallback for them.  The mesh regularisers (``recon_flip``, ``calc_reg_*``) run as one HIP
+launch per direction (``mesh_reg.py``); the attribute losses of ``recon_att`` are small elementwise means in torch ops, its
+chamfer term a HIP nearest-neighbour kernel.
 """
 import ctypes
 import math
@@ -13,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from . import obj_io, template
+from . import mesh_reg, obj_io, template
 
 
 class _RenderFn(torch.autograd.Function):
@@ -272,66 +273,66 @@ class DiffRender(object):
         loss_light = 0.1 * dist(pred_att['lights'], target_att['lights'])
         return loss_cam, loss_shape, loss_texture, loss_light, loss_bias
 
-    # ---- networks.py:392-410 -------------------------------------------------------------------------------------
-    def recon_flip(self, att, L1):
-        Na = att['delta_vertices']
-        Nf = Na.index_select(1, self.flip_index.to(Na.device))
-        Nf[..., 2] *= -1
+    # ---- mesh regularisers (networks.py:392-491): HIP kernels, one launch per direction (mesh_reg.py / csrc/mm_reg.hip) ----
+    def _reg_tables(self, device):
+        key = ("reg", str(device))
+        tab = self._static_cache.get(key)
+        if tab is None:
+            tab = mesh_reg.build_tables(self, device)
+            self._static_cache[key] = tab
+        return tab
+
+    def _reg(self, terms, vertices=None, delta=None, fn=None, temp=2.0, eps=0.001):
+        return mesh_reg.MeshRegFn.apply(self, terms, temp, eps, vertices, delta, fn)
+
+    def recon_flip(self, att, L1):                               # networks.py:392-410
         if L1:
-            loss_norm = torch.abs(Na - Nf)
-        else:
-            loss_norm = (Na - Nf).norm(dim=2)
-        sign_init = self.sign_init.to(Na.device)
-        mask_a = torch.nn.functional.relu(torch.sign(Na[:, :, 2]) * sign_init)
-        mask_f = mask_a.index_select(1, self.flip_index.to(Na.device))
-        loss_norm = loss_norm * mask_f      # L1=True: (B,V,3)*(B,V) raises exactly like the reference (networks.py:409)
-        return torch.mean(loss_norm)
+            # the reference multiplies (B,V,3) by (B,V) here and raises (networks.py:409); pinned in tests/golden/losses.npz
+            raise RuntimeError("The size of tensor a (3) must match the size of tensor b (%d) at non-singleton dimension 2" % self.num_vertices)
+        return self._reg(mesh_reg.mask(mesh_reg.FLIP), delta=att['delta_vertices'])[mesh_reg.FLIP]
 
-    # ---- networks.py:412-451 -------------------------------------------------------------------------------------
-    def calc_reg_loss(self, att):
-        delta_vertices = att['delta_vertices']
-        device = delta_vertices.device
-        L = self.vertices_laplacian_matrix.to(device)
-        edge2faces = self.edge2faces.to(device)
-        face_normals = att['face_normals']
-        nb_vertices = delta_vertices.shape[1]
-        loss_laplacian = torch.mean(torch.matmul(L, delta_vertices) ** 2) * nb_vertices * 3
-        e1 = face_normals[:, edge2faces[:, 0]]
-        e2 = face_normals[:, edge2faces[:, 1]]
-        faces_cos = torch.sum(e1 * e2, dim=2)
-        loss_flat = torch.mean((faces_cos - 1) ** 2) * edge2faces.shape[0]
-        return self.lambda_lpl * loss_laplacian + self.lambda_flat * loss_flat
+    def calc_reg_loss(self, att):                                # networks.py:412-451
+        l = self._reg(mesh_reg.mask(mesh_reg.LAPLACIAN, mesh_reg.FLAT), delta=att['delta_vertices'], fn=att['face_normals'])
+        return self.lambda_lpl * l[mesh_reg.LAPLACIAN] + self.lambda_flat * l[mesh_reg.FLAT]
 
-    # ---- networks.py:453-491 -------------------------------------------------------------------------------------
-    def calc_reg_edge(self, pred):
-        edges = self.edges.to(pred.device)
-        edge_length = torch.norm(pred[:, edges[:, 0]] - pred[:, edges[:, 1]], p=2, dim=2)
-        bias_length = edge_length - torch.mean(edge_length, dim=1, keepdim=True)
-        return 0.1 * torch.mean(torch.norm(bias_length, p=2, dim=1))
+    def calc_reg_edge(self, pred):                               # networks.py:453-461
+        return self._reg(mesh_reg.mask(mesh_reg.EDGE), vertices=pred)[mesh_reg.EDGE]
 
-    def calc_reg_depth(self, pred):
-        return torch.mean(pred[:, :, 2] ** 2)
+    def calc_reg_depth(self, pred):                              # networks.py:463-466
+        return self._reg(mesh_reg.mask(mesh_reg.DEPTH), vertices=pred)[mesh_reg.DEPTH]
 
-    def calc_reg_depthR(self, pred, temp=2, eps=0.001):
-        x = pred[:, :, 0].detach()
-        y = pred[:, :, 1].detach()
-        s = self.sign_init.to(pred.device)
-        w = torch.exp(temp * (x ** 2 + (y / self.ratio) ** 2))
-        loss_depth = (s >= 0) * (pred[:, :, 2] - eps) ** 2 * w + (s < 0) * (pred[:, :, 2] + eps) ** 2 * w
-        return torch.mean(loss_depth)
+    def calc_reg_depthR(self, pred, temp=2, eps=0.001):          # networks.py:468-475
+        return self._reg(mesh_reg.mask(mesh_reg.DEPTHR), vertices=pred, temp=temp, eps=eps)[mesh_reg.DEPTHR]
 
-    def calc_reg_depthC(self, pred, eps=0.001):
-        x = pred[:, :, 0].detach()
-        y = pred[:, :, 1].detach()
-        s = self.sign_init.to(pred.device)
-        w = x ** 2 + (y / self.ratio) ** 2
-        loss_depth = (s >= 0) * (pred[:, :, 2] - eps) ** 2 * w + (s < 0) * (pred[:, :, 2] + eps) ** 2 * w
-        return torch.mean(loss_depth)
+    def calc_reg_depthC(self, pred, eps=0.001):                  # networks.py:477-485
+        return self._reg(mesh_reg.mask(mesh_reg.DEPTHC), vertices=pred, eps=eps)[mesh_reg.DEPTHC]
 
-    def calc_reg_deform(self, pred):
-        batchsize = pred.shape[0]
-        norm = torch.norm(pred.reshape(-1, pred.size(2)), p=2, dim=1).reshape(batchsize, -1)
-        return torch.mean(norm)
+    def calc_reg_deform(self, pred):                             # networks.py:487-491
+        return self._reg(mesh_reg.mask(mesh_reg.DEFORM), delta=pred)[mesh_reg.DEFORM]
+
+    def regularization(self, Ae, Ai, Aire, opt):
+        """trainer.py:54-74 ``regularization(diffRender, Ae, Ai, Aire, opt)`` with every enabled mesh term of an attribute set in
+        ONE launch (plus one for its backward) instead of one call per term: returns (lossR_reg, lossR_flip, lossR_IC)."""
+        M = mesh_reg
+        terms = [M.LAPLACIAN, M.FLAT, M.FLIP]
+        for lam, t in ((opt.lambda_edge, M.EDGE), (opt.lambda_depth, M.DEPTH), (opt.lambda_depthR, M.DEPTHR),
+                       (opt.lambda_depthC, M.DEPTHC), (opt.lambda_deform, M.DEFORM)):
+            if lam > 0:
+                terms.append(t)
+        if opt.flipL1:
+            self.recon_flip(Ae, True)                            # raises, like the reference
+        le, li = [self._reg(M.mask(*terms), vertices=A['vertices'], delta=A['delta_vertices'], fn=A['face_normals'],
+                            temp=opt.temp) for A in (Ae, Ai)]
+        lr = self._reg(M.mask(M.FLIP), delta=Aire['delta_vertices'])
+        lossR_reg = opt.lambda_reg * (self.lambda_lpl * (le[M.LAPLACIAN] + li[M.LAPLACIAN]) + self.lambda_flat * (le[M.FLAT] + li[M.FLAT])) / 2.0
+        lossR_flip = opt.lambda_flipz * (le[M.FLIP] + li[M.FLIP] + lr[M.FLIP]) / 3.0
+        for lam, t in ((opt.lambda_edge, M.EDGE), (opt.lambda_depth, M.DEPTH), (opt.lambda_depthR, M.DEPTHR),
+                       (opt.lambda_depthC, M.DEPTHC), (opt.lambda_deform, M.DEFORM)):
+            if lam > 0:
+                lossR_reg = lossR_reg + lam * (le[t] + li[t]) / 2.0
+        parts = self.recon_att(Aire, deep_copy(Ai, detach=True), L1=opt.L1, chamfer=opt.chamfer, azim=opt.azim)
+        lossR_IC = opt.lambda_ic * (parts[0] + parts[1] + parts[2] + parts[3] + parts[4])
+        return lossR_reg, lossR_flip, lossR_IC
 
 
 def deep_copy(att, index=None, detach=False):

@@ -160,6 +160,52 @@ int mm_nearest_neighbour(int32_t B, int32_t N, int32_t M, const float* x, const 
                          mm_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------------------------------
+ * Mesh regularisers: replaces DiffRender.calc_reg_loss / calc_reg_edge / calc_reg_depth /
+ * calc_reg_depthR / calc_reg_depthC / calc_reg_deform / recon_flip(L1=False) (networks.py:392-491; orchestrated by
+ * trainer.py:54-74), one launch per direction for any subset of the terms.  losses[k] is the reference's value of term k
+ * (calc_reg_loss = lambda_lpl * losses[LAPLACIAN] + lambda_flat * losses[FLAT]; calc_reg_edge = losses[EDGE], which already
+ * carries the reference's 0.1); terms that were not requested read 0.
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum { MM_REG_LAPLACIAN = 0, MM_REG_FLAT = 1, MM_REG_EDGE = 2, MM_REG_DEPTH = 3, MM_REG_DEPTHR = 4, MM_REG_DEPTHC = 5,
+       MM_REG_DEFORM = 6, MM_REG_FLIP = 7, MM_REG_TERMS = 8 };
+
+typedef struct MMMeshRegDesc {
+    int32_t B, V, F, E;         /* batch, template vertices / faces / unique edges */
+    uint32_t terms;             /* bit k set: compute term k */
+    /* static template tables (device).  The (V,V) laplacian (networks.py:249) and its transpose as CSR, diagonal included */
+    const int32_t* lap_offsets;   const int32_t* lap_cols;   const float* lap_vals;
+    const int32_t* lapT_offsets;  const int32_t* lapT_cols;  const float* lapT_vals;    /* backward only */
+    const int32_t* edges;         /* (E,2)  vertex ids                                   (:220-233) */
+    const int32_t* edge2faces;    /* (E,2)  the two faces of every edge                  (:235-246) */
+    const int32_t* ve_offsets;    const int32_t* ve_items;   /* vertex -> edge*2 + end   (backward only) */
+    const int32_t* fe_offsets;    const int32_t* fe_items;   /* face   -> edge*2 + side  (backward only) */
+    const int32_t* flip_index;    /* (V)    mirrored partner of every vertex             (:215-217) */
+    const int32_t* flipT_offsets; const int32_t* flipT_items; /* u -> {v : flip_index[v] == u}  (backward only) */
+    const float* sign_init;       /* (V)    sign of the template's z                     (:213) */
+    /* inputs (device); one may be NULL if no requested term reads it */
+    const float* vertices;        /* (B,V,3)  EDGE, DEPTH, DEPTHR, DEPTHC */
+    const float* delta_vertices;  /* (B,V,3)  LAPLACIAN, DEFORM, FLIP */
+    const float* face_normals;    /* (B,F,3)  FLAT */
+    float ratio, temp, eps;       /* DiffRender.ratio; calc_reg_depthR's temp (2); depthR / depthC eps (0.001) */
+    float* losses;                /* (MM_REG_TERMS) device */
+    void* workspace;              /* >= mm_mesh_reg_query_workspace bytes, 256-byte aligned, ZERO-FILLED by the caller before its
+                                   * first use; the library leaves it ready for the next call.  The backward reads what the
+                                   * forward of the same inputs left in it. */
+    size_t workspace_bytes;
+} MMMeshRegDesc;
+
+typedef struct MMMeshRegGrads {
+    const float* weights;         /* (MM_REG_TERMS) device: dL/d losses[k] */
+    float* grad_vertices;         /* (B,V,3) or NULL; overwritten */
+    float* grad_delta_vertices;   /* (B,V,3) or NULL; overwritten */
+    float* grad_face_normals;     /* (B,F,3) or NULL; overwritten */
+} MMMeshRegGrads;
+
+size_t mm_mesh_reg_query_workspace(const MMMeshRegDesc* desc);
+int mm_mesh_reg_forward(const MMMeshRegDesc* desc, mm_stream_t stream);
+int mm_mesh_reg_backward(const MMMeshRegDesc* desc, const MMMeshRegGrads* grads, mm_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------------------------------
  * Host helpers (no GPU involved)
  * ------------------------------------------------------------------------------------------------------------------ */
 /* Texture-space tiling used by the backward (static per template and texture size).  A face is listed in every tile

@@ -94,7 +94,10 @@ def _att(z, prefix, grad=True):
     return a
 
 
-def test_mirror_losses_match_reference(pkg):
+def test_loss_oracle_and_attribute_losses_match_reference(pkg):
+    """oracle/reg_oracle.py (the checker of the HIP mesh-regulariser kernels) and the mirror's recon_att against outputs and
+    gradients of the reference itself (tests/golden/losses.npz)."""
+    import reg_oracle as R
     z = np.load(os.path.join(GOLDEN, "losses.npz"))
     dr = pkg.DiffRender(os.path.join(TEMPLATES, "sphere.npz"), 64, image_weight=0.1, lambda_lpl=0.1, lambda_flat=0.001)
     dr.sign_init = dr.sign_init.cpu()
@@ -110,21 +113,52 @@ def test_mirror_losses_match_reference(pkg):
             got = np.zeros_like(ref) if g is None else g.numpy()
             np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-7, err_msg=name + " d/d" + k)
 
-    check("calc_reg_loss", dr.calc_reg_loss(A), ("delta_vertices", "face_normals"))
-    check("calc_reg_edge", dr.calc_reg_edge(A["vertices"]), ("delta_vertices",))
-    check("calc_reg_depth", dr.calc_reg_depth(A["vertices"]), ("delta_vertices",))
-    check("calc_reg_depthR", dr.calc_reg_depthR(A["vertices"], temp=2), ("delta_vertices",))
-    check("calc_reg_depthC", dr.calc_reg_depthC(A["vertices"]), ("delta_vertices",))
-    check("calc_reg_deform", dr.calc_reg_deform(A["delta_vertices"]), ("delta_vertices",))
-    check("recon_flip_L10", dr.recon_flip(A, False), ("delta_vertices",))
+    check("calc_reg_loss", R.calc_reg_loss(dr, A), ("delta_vertices", "face_normals"))
+    check("calc_reg_edge", R.calc_reg_edge(dr, A["vertices"]), ("delta_vertices",))
+    check("calc_reg_depth", R.calc_reg_depth(dr, A["vertices"]), ("delta_vertices",))
+    check("calc_reg_depthR", R.calc_reg_depthR(dr, A["vertices"], temp=2), ("delta_vertices",))
+    check("calc_reg_depthC", R.calc_reg_depthC(dr, A["vertices"]), ("delta_vertices",))
+    check("calc_reg_deform", R.calc_reg_deform(dr, A["delta_vertices"]), ("delta_vertices",))
+    check("recon_flip_L10", R.recon_flip(dr, A, False), ("delta_vertices",))
     assert int(z["recon_flip_L1_raises"]) == 1
     with pytest.raises(RuntimeError):                      # the reference broadcasts (B,V,3)*(B,V) here (networks.py:409)
+        R.recon_flip(dr, A, True)
+    with pytest.raises(RuntimeError):                      # ... and so does the product, before touching any tensor
         dr.recon_flip(A, True)
     wrt = ("azimuths", "elevations", "distances", "biases", "delta_vertices", "textures", "lights")
     for L1 in (True, False):
-        parts = dr.recon_att(A, A2, L1=L1, chamfer=False, azim=1)
-        for nm, val in zip(("cam", "shape", "texture", "light", "bias"), parts):
-            check("recon_att_L1%d_%s" % (L1, nm), val, wrt)
+        for parts in (dr.recon_att(A, A2, L1=L1, chamfer=False, azim=1), R.recon_att(A, A2, L1=L1, azim=1)):
+            for nm, val in zip(("cam", "shape", "texture", "light", "bias"), parts):
+                check("recon_att_L1%d_%s" % (L1, nm), val, wrt)
+    # the mesh regularisers are HIP kernels: host tensors are refused, there is no CPU path
+    for call in (lambda: dr.calc_reg_loss(A), lambda: dr.calc_reg_edge(A["vertices"]), lambda: dr.recon_flip(A, False)):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+
+
+def test_mesh_reg_tables(pkg):
+    """Static tables behind mm_mesh_reg_*: CSR laplacian and its transpose reproduce the dense matrix; adjacency lists invert."""
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "smpl_uv_642.npz"), 32)
+    t = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in pkg.mesh_reg.build_tables(dr, torch.device("cpu")).items()}
+    V, F, E = dr.num_vertices, dr.num_faces, t["E"]
+    L = dr.vertices_laplacian_matrix.numpy()
+    for name, M in (("lap", L), ("lapT", L.T)):
+        D = np.zeros_like(L)
+        for v in range(V):
+            s, e = t[name + "_offsets"][v], t[name + "_offsets"][v + 1]
+            D[v, t[name + "_cols"][s:e]] = t[name + "_vals"][s:e]
+        assert np.array_equal(D, M)
+    assert np.allclose(L.sum(1), 0, atol=1e-6) and (np.diag(L) == -1).all()
+    for v in range(0, V, 37):
+        its = t["ve_items"][t["ve_offsets"][v]:t["ve_offsets"][v + 1]]
+        assert all(t["edges"][i >> 1, i & 1] == v for i in its) and len(its) == int((t["edges"] == v).sum())
+    for f in range(0, F, 53):
+        its = t["fe_items"][t["fe_offsets"][f]:t["fe_offsets"][f + 1]]
+        assert all(t["edge2faces"][i >> 1, i & 1] == f for i in its) and len(its) == int((t["edge2faces"] == f).sum())
+    for u in range(V):
+        its = t["flipT_items"][t["flipT_offsets"][u]:t["flipT_offsets"][u + 1]]
+        assert all(t["flip_index"][v] == u for v in its)
+    assert t["flipT_offsets"][-1] == V and t["ve_offsets"][-1] == 2 * E and t["fe_offsets"][-1] == 2 * E
 
 
 def test_deep_copy_and_attributes(pkg):

@@ -50,6 +50,14 @@ class MMMeshRegDesc(ctypes.Structure):
                 ("losses", c_p), ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
 
 
+class MMTexFlowDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("C", c_i), ("H", c_i), ("W", c_i), ("Ho", c_i), ("Wo", c_i), ("image", c_p), ("flow", c_p), ("textures", c_p)]
+
+
+class MMTexFlowGrads(ctypes.Structure):
+    _fields_ = [("grad_textures", c_p), ("grad_flow", c_p), ("grad_image", c_p)]
+
+
 class MMMeshRegGrads(ctypes.Structure):
     _fields_ = [("weights", c_p), ("grad_vertices", c_p), ("grad_delta_vertices", c_p), ("grad_face_normals", c_p)]
 
@@ -62,7 +70,8 @@ PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",
            "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_uv_tiles", "mm_nearest_neighbour", "mm_status_string", "mm_last_error_detail",
-           "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward",
+           "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward", "mm_texture_flow_forward",
+           "mm_texture_flow_backward",
            "mm_abi_version")
 
 
@@ -97,6 +106,8 @@ def lib():
     L.mm_mesh_reg_query_workspace.argtypes = [ctypes.POINTER(MMMeshRegDesc)]
     L.mm_mesh_reg_forward.argtypes = [ctypes.POINTER(MMMeshRegDesc), c_p]
     L.mm_mesh_reg_backward.argtypes = [ctypes.POINTER(MMMeshRegDesc), ctypes.POINTER(MMMeshRegGrads), c_p]
+    L.mm_texture_flow_forward.argtypes = [ctypes.POINTER(MMTexFlowDesc), c_p]
+    L.mm_texture_flow_backward.argtypes = [ctypes.POINTER(MMTexFlowDesc), ctypes.POINTER(MMTexFlowGrads), c_p]
     L.mm_build_vertex_corner_csr.argtypes = [c_i, c_i, c_p, c_p, c_p]
     L.mm_build_uv_tiles.argtypes = [c_i, c_p, c_i, c_i, c_p, c_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.mm_status_string.restype = ctypes.c_char_p

@@ -16,6 +16,8 @@ int launch_nn(int, int, int, const float*, const float*, float*, int32_t*, hipSt
 size_t reg_workspace_bytes(const MMMeshRegDesc*);
 int launch_reg_fwd(const MMMeshRegDesc*, hipStream_t);
 int launch_reg_bwd(const MMMeshRegDesc*, const MMMeshRegGrads*, hipStream_t);
+int launch_texflow_fwd(const MMTexFlowDesc*, hipStream_t);
+int launch_texflow_bwd(const MMTexFlowDesc*, const MMTexFlowGrads*, hipStream_t);
 }  // namespace mm
 
 static int check_render(const MMRenderDesc* d, bool backward) {
@@ -144,6 +146,30 @@ int mm_mesh_reg_backward(const MMMeshRegDesc* d, const MMMeshRegGrads* g, mm_str
         return MM_ERR_NULL_POINTER;                              // a gradient is only defined for an input that was given
     mm::clear_stale_error();
     return mm::launch_reg_bwd(d, g, (hipStream_t)stream);
+}
+
+static int check_texflow(const MMTexFlowDesc* d) {
+    if (!d) return MM_ERR_NULL_POINTER;
+    if (d->B <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0) return MM_ERR_BAD_SHAPE;
+    if (d->B > 65535 || (d->Ho + 3) / 4 > 65535) return MM_ERR_UNSUPPORTED;     // grid y / z limits
+    if (!d->image || !d->flow) return MM_ERR_NULL_POINTER;
+    return MM_OK;
+}
+
+int mm_texture_flow_forward(const MMTexFlowDesc* d, mm_stream_t stream) {
+    const int st = check_texflow(d);
+    if (st != MM_OK) return st;
+    if (!d->textures) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    return mm::launch_texflow_fwd(d, (hipStream_t)stream);
+}
+
+int mm_texture_flow_backward(const MMTexFlowDesc* d, const MMTexFlowGrads* g, mm_stream_t stream) {
+    const int st = check_texflow(d);
+    if (st != MM_OK) return st;
+    if (!g || !g->grad_textures || !g->grad_flow) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    return mm::launch_texflow_bwd(d, g, (hipStream_t)stream);
 }
 
 int mm_build_uv_tiles(int32_t F, const float* fuv, int32_t Ht, int32_t Wt, int32_t* offsets, int32_t* items, int64_t capacity,

@@ -206,6 +206,29 @@ int mm_mesh_reg_forward(const MMMeshRegDesc* desc, mm_stream_t stream);
 int mm_mesh_reg_backward(const MMMeshRegDesc* desc, const MMMeshRegGrads* grads, mm_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------------------------------
+ * Texture-flow sampling: the tail of TextureEncoder.forward (network/model_res.py:597-612, makeup = 0),
+ * i.e. the step that produces the texture the render path consumes:
+ *   textures = cat([t, t.flip(2)], 2),  t = F.grid_sample(image, flow.permute(0,2,3,1), mode='bicubic', align_corners=True)
+ * (zeros padding, ATen's bicubic: A = -0.75).  flow is taken channel-first, exactly as the decoder emits it.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct MMTexFlowDesc {
+    int32_t B, C, H, W;         /* image batch, channels (3), rows, cols */
+    int32_t Ho, Wo;             /* flow / sampled rows, cols; the texture has 2*Ho rows */
+    const float* image;         /* (B,C,H,W) */
+    const float* flow;          /* (B,2,Ho,Wo): x then y, in [-1,1] */
+    float* textures;            /* (B,C,2*Ho,Wo); unused by the backward */
+} MMTexFlowDesc;
+
+typedef struct MMTexFlowGrads {
+    const float* grad_textures; /* (B,C,2*Ho,Wo) */
+    float* grad_flow;           /* (B,2,Ho,Wo); overwritten */
+    float* grad_image;          /* (B,C,H,W) or NULL; overwritten (zero-filled on the stream, then float atomics) */
+} MMTexFlowGrads;
+
+int mm_texture_flow_forward(const MMTexFlowDesc* desc, mm_stream_t stream);
+int mm_texture_flow_backward(const MMTexFlowDesc* desc, const MMTexFlowGrads* grads, mm_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------------------------------
  * Host helpers (no GPU involved)
  * ------------------------------------------------------------------------------------------------------------------ */
 /* Texture-space tiling used by the backward (static per template and texture size).  A face is listed in every tile

@@ -121,7 +121,25 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     TexRecord rec; rec.xy = 0; rec.tx = rec.ty = rec.d0 = rec.d1 = rec.d2 = 0.f;
     int rtile[4] = {-1, -1, -1, -1};
 
-    if (in_img && (hf >= 0 || kNoMask)) {
+    // Tiles without a covered pixel (more than half of them): m = 0 and n = 0 in every lane, so only the background and the two
+    // constant SH bands receive gradient -- none of the uv / bilinear / texel / barycentric work below is needed.
+    const bool any_covered = __ballot(in_img && hf >= 0) != 0;   // wave-uniform
+    if (!any_covered) {
+        if (kNoMask && in_img) {
+            const float* L = a.lights + b * 9;
+            const float coef = MM_SH_C0 * L[0] + (0.f - MM_SH_C6B) * L[6];
+            float dc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float bgv = a.bg[((size_t)b * 3 + c) * hw + pin];
+                const float pre = bgv * coef;
+                const float g = (pre >= 0.f && pre <= 1.f) ? gin[c] : 0.f;      // torch.clamp backward mask
+                dc += g * bgv;
+                a.grad_bg[((size_t)b * 3 + c) * hw + pin] = g * coef;
+            }
+            dl[0] = dc * MM_SH_C0; dl[6] = dc * (0.f - MM_SH_C6B);
+        }
+    } else if (in_img && (hf >= 0 || kNoMask)) {
         // recompute the forward quantities of this pixel (only face_idx and the soft-mask state were saved)
         float w0 = 0.f, w1 = 0.f, w2 = 0.f, nrm = 1.f, m = 0.f, u = 0.f, v = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
         float fu[6] = {0, 0, 0, 0, 0, 0}, n0 = 0.f, n1 = 0.f, n2 = 0.f;
@@ -229,6 +247,7 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         leader[c] = -1; rank[c] = 0; base[c] = 0;
+        if (!any_covered) continue;                              // wave-uniform: nothing to append
         int size = 0;
         unsigned long long pending = __ballot(rtile[c] >= 0);
         while (pending) {
@@ -242,6 +261,7 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+        if (!any_covered) break;
         const int bs = __shfl(base[c], leader[c] < 0 ? lane : leader[c], 64);
         if (rtile[c] >= 0) {
             const int slot = bs + rank[c];
@@ -255,8 +275,10 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     }
 
     // d lights: wave butterfly -> one LDS row per wave -> fixed-order partial of this workgroup (summed by vertex_bwd)
+    if (any_covered) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) dl[i] = wave_sum(dl[i]);
+        for (int i = 0; i < 9; ++i) dl[i] = wave_sum(dl[i]);
+    } else { dl[0] = wave_sum(dl[0]); dl[6] = wave_sum(dl[6]); }     // the other seven are zero
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) s_dl[wave][i] = dl[i];

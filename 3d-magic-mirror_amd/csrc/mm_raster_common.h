@@ -246,42 +246,56 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
 #pragma unroll
         for (int c = 0; c < 4; ++c) gtv[c] = a.gt[((size_t)t.b * 4 + c) * hw + pin];
     }
-    float m = 0.f, u = 0.f, v = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
-    if (h.f >= 0) {
-        const float* fu = a.face_uvs + (size_t)h.f * 6;
-        m = (h.w0 + h.w1) + h.w2;
-        u = (h.w0 * fu[0] + h.w1 * fu[2]) + h.w2 * fu[4];
-        v = (h.w0 * fu[1] + h.w1 * fu[3]) + h.w2 * fu[5];
-        nx = (h.w0 * n0 + h.w1 * n0) + h.w2 * n0;
-        ny = (h.w0 * n1 + h.w1 * n1) + h.w2 * n1;
-        nz = (h.w0 * n2 + h.w1 * n2) + h.w2 * n2;
-    }
-    const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
-    const bool inw = s.x0 < a.Wt && s.y0 < a.Ht, ine = s.x1 < a.Wt && s.y0 < a.Ht;
-    const bool isw = s.x0 < a.Wt && s.y1 < a.Ht, ise = s.x1 < a.Wt && s.y1 < a.Ht;
-    float bnd[9];
-    sh_bands(nx, ny, nz, bnd);
-    const float* L = a.lights + t.b * 9;
-    float coef = 0.f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) coef += bnd[i] * L[i];
+    float nx = 0.f, ny = 0.f, nz = 0.f;
     float out[4];
+    const float* L = a.lights + t.b * 9;
+    if (__ballot(h.f >= 0) == 0) {
+        // No lane of the tile is covered (more than half of all tiles).  The general path below then computes, per lane,
+        //   m = 0, n = 0  ->  coef = C0*L0 + (0 - C6B)*L6   (the other seven bands are products with 0)
+        //   no_mask: (tc*0 + g*(1-0)) * coef = g * coef;   white: (tc*0)*coef + 1*(1-0) = 1        (finite texels / lights)
+        // -- the same roundings without the uv -> bilinear -> twelve-texel chain.
+        const float coef = MM_SH_C0 * L[0] + (0.f - MM_SH_C6B) * L[6];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float* tex = a.textures + ((size_t)t.b * 3 + c) * a.Ht * a.Wt;
-        float tc = 0.f;
-        if (inw) tc += tex[(size_t)s.y0 * a.Wt + s.x0] * s.wnw;
-        if (ine) tc += tex[(size_t)s.y0 * a.Wt + s.x1] * s.wne;
-        if (isw) tc += tex[(size_t)s.y1 * a.Wt + s.x0] * s.wsw;
-        if (ise) tc += tex[(size_t)s.y1 * a.Wt + s.x1] * s.wse;
-        float val;
-        if (kNoMask) {
-            const float g = bgv[c];
-            val = (tc * m + g * (1.f - m)) * coef;
-        } else {
-            val = (tc * m) * coef + 1.f * (1.f - m);
+        for (int c = 0; c < 3; ++c) {
+            const float val = kNoMask ? bgv[c] * coef : 1.f;
+            out[c] = val < 0.f ? 0.f : (val > 1.f ? 1.f : val);
         }
-        out[c] = val < 0.f ? 0.f : (val > 1.f ? 1.f : val);
+    } else {
+        float m = 0.f, u = 0.f, v = 0.f;
+        if (h.f >= 0) {
+            const float* fu = a.face_uvs + (size_t)h.f * 6;
+            m = (h.w0 + h.w1) + h.w2;
+            u = (h.w0 * fu[0] + h.w1 * fu[2]) + h.w2 * fu[4];
+            v = (h.w0 * fu[1] + h.w1 * fu[3]) + h.w2 * fu[5];
+            nx = (h.w0 * n0 + h.w1 * n0) + h.w2 * n0;
+            ny = (h.w0 * n1 + h.w1 * n1) + h.w2 * n1;
+            nz = (h.w0 * n2 + h.w1 * n2) + h.w2 * n2;
+        }
+        const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
+        const bool inw = s.x0 < a.Wt && s.y0 < a.Ht, ine = s.x1 < a.Wt && s.y0 < a.Ht;
+        const bool isw = s.x0 < a.Wt && s.y1 < a.Ht, ise = s.x1 < a.Wt && s.y1 < a.Ht;
+        float bnd[9];
+        sh_bands(nx, ny, nz, bnd);
+        float coef = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) coef += bnd[i] * L[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* tex = a.textures + ((size_t)t.b * 3 + c) * a.Ht * a.Wt;
+            float tc = 0.f;
+            if (inw) tc += tex[(size_t)s.y0 * a.Wt + s.x0] * s.wnw;
+            if (ine) tc += tex[(size_t)s.y0 * a.Wt + s.x1] * s.wne;
+            if (isw) tc += tex[(size_t)s.y1 * a.Wt + s.x0] * s.wsw;
+            if (ise) tc += tex[(size_t)s.y1 * a.Wt + s.x1] * s.wse;
+            float val;
+            if (kNoMask) {
+                const float g = bgv[c];
+                val = (tc * m + g * (1.f - m)) * coef;
+            } else {
+                val = (tc * m) * coef + 1.f * (1.f - m);
+            }
+            out[c] = val < 0.f ? 0.f : (val > 1.f ? 1.f : val);
+        }
     }
     const float keepprod = ss.zeros > 0 ? 0.f : ss.qnz;
     out[3] = (h.f >= 0) ? 1.f : (1.f - keepprod);

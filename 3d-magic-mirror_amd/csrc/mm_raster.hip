@@ -170,12 +170,17 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
     shade_store<kNoMask>(a, t, h, n0, n1, n2, ss);
 }
 
-// Ranks the tile slots (16x16 block * 4 + quadrant) of every image by their soft-mask candidate count, descending
-// (rank by counting, all pairs, in LDS: slots per image <= 1024).  Only the launch ORDER of raster_fwd depends on it.
+// Orders the tile slots (16x16 block * 4 + quadrant) of every image by their soft-mask candidate count, descending: a counting
+// sort in LDS (keys clipped to 1023; slots per image <= 1024), linear in the slots.  Only the launch ORDER of raster_fwd
+// depends on it -- slots with equal counts may come out in any order, no result does.
 __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short* order) {
-    __shared__ __attribute__((aligned(16))) int s_cnt[1024];
-    const int b = blockIdx.x, nslot = 4 * a.blocks_per_image;          // a multiple of 4
-    for (int slot = threadIdx.x; slot < nslot; slot += 256) {
+    __shared__ int s_key[1024];
+    __shared__ int s_start[1024];          // histogram, then the first output position of every key
+    __shared__ int s_wave[4];
+    const int b = blockIdx.x, tid = threadIdx.x, nslot = 4 * a.blocks_per_image;
+    for (int i = tid; i < 1024; i += 256) s_start[i] = 0;
+    __syncthreads();
+    for (int slot = tid; slot < nslot; slot += 256) {
         const int blk = slot >> 2, q = slot & 3;
         const int tx0 = (blk % a.blocks_x) * MM_BLOCK_PX + (q & 1) * MM_TILE, ty0 = (blk / a.blocks_x) * MM_BLOCK_PX + (q >> 1) * MM_TILE;
         int c = 0;
@@ -189,27 +194,25 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
                 for (int k = 0; k < 8; ++k) c += __popcll(r[k]);
             }
         }
-        s_cnt[slot] = c;
+        c = min(c, 1023);
+        s_key[slot] = c;
+        atomicAdd(&s_start[c], 1);
     }
     __syncthreads();
-    for (int slot = threadIdx.x; slot < nslot; slot += 256) {
-        const int c = s_cnt[slot];
-        int rank = 0;
-        for (int j = 0; j < nslot; j += 16) {                      // four 16-byte LDS reads in flight per trip
-            int4 v[4];
+    // exclusive prefix over the keys in DESCENDING order: thread t owns keys 1023 - 4t .. 1020 - 4t
+    int h[4], mine = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (j + 4 * k < nslot) ? *(const int4*)&s_cnt[j + 4 * k] : make_int4(-1, -1, -1, -1);
+    for (int j = 0; j < 4; ++j) { h[j] = s_start[1023 - (4 * tid + j)]; mine += h[j]; }
+    int wtot;
+    int before = wave_prefix_excl(mine, tid & 63, wtot);
+    if ((tid & 63) == 63) s_wave[tid >> 6] = wtot;
+    __syncthreads();
+    for (int w = 0; w < (tid >> 6); ++w) before += s_wave[w];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int jj = j + 4 * k;
-                rank += (v[k].x > c) || (v[k].x == c && jj < slot);
-                rank += (v[k].y > c) || (v[k].y == c && jj + 1 < slot);
-                rank += (v[k].z > c) || (v[k].z == c && jj + 2 < slot);
-                rank += (v[k].w > c) || (v[k].w == c && jj + 3 < slot);
-            }
-        }
-        order[(size_t)b * nslot + rank] = (unsigned short)slot;
-    }
+    for (int j = 0; j < 4; ++j) { s_start[1023 - (4 * tid + j)] = before; before += h[j]; }
+    __syncthreads();
+    for (int slot = tid; slot < nslot; slot += 256)
+        order[(size_t)b * nslot + atomicAdd(&s_start[s_key[slot]], 1)] = (unsigned short)slot;
 }
 
 RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {

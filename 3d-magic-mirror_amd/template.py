@@ -109,3 +109,53 @@ def vertex_corner_adjacency(num_vertices, faces):
     offsets = np.zeros(num_vertices + 1, dtype=np.int32)
     offsets[1:] = np.cumsum(counts)
     return torch.from_numpy(offsets), torch.from_numpy(order)
+
+
+def fuse_template(vertices_init, laplacian, all_vertices, all_delta_vertices, em=1, smooth=0.0, clip=0.05, em_step=1.0,
+                  warm_up=1.0, white=False, cross=False, topK=0.5):
+    """The reference's template EM update: the statements of /root/reference/trainer.py:1019-1097, which
+    live inline in the training loop, as a function.  ``all_vertices`` / ``all_delta_vertices`` are the (N,V,3) predictions of
+    one pass over the training set; returns ``(new_vertices_init (1,V,3), count, whether_cross)`` -- the caller assigns the
+    template (``netE.vertices_init.data``, ``diffRender.vertices_init``) and decays ``em_step`` by 0.99 (:1099).
+
+    Fusion modes (``opt.em``): 1 = mean over all samples; 5 = mean over the ``topK`` fraction with the smallest ||delta||;
+    >= 6 = mean over all samples with ``em - 5`` extra smoothing sweeps.  Modes 2, 3 and 4 cannot complete in the reference as
+    written (its bad-case filter indexes with an (n,1) array, after which their masks no longer match: IndexError / RuntimeError,
+    pinned in tests/golden/template_em.npz); they raise the same exception types here rather than inventing a behaviour.
+    """
+    N, V = all_vertices.shape[0], vertices_init.shape[-2]
+    all_vertices = all_vertices.detach().cpu().float()
+    all_delta = all_delta_vertices.detach().cpu().float()
+    # :1019-1023  samples whose LAST vertex moved by more than 0.4 on average are dropped
+    keep = torch.mean(torch.abs(all_delta)[:, -1], dim=1) <= 0.4
+    kept_delta = all_delta[keep]
+    if em in (2, 3):
+        raise IndexError("template fusion mode %d: the reference's selection mask does not match its filtered tensors (trainer.py:1025-1036)" % em)
+    if em == 4:
+        raise RuntimeError("template fusion mode 4 (DBSCAN): the reference cannot complete this mode (trainer.py:1037-1065)")
+    if em == 5:                                                  # :1066-1072 (needs an unfiltered set, like the reference's .view)
+        if kept_delta.shape[0] != N:
+            raise RuntimeError("shape '[%d, -1]' is invalid for input of size %d" % (N, kept_delta.numel()))
+        order = np.argsort(torch.sum(all_delta.reshape(N, -1) ** 2, dim=1).numpy())
+        pick = torch.from_numpy(order[: int(N * topK)].copy())
+        current, count = torch.sum(all_delta[pick], dim=0), len(pick)
+    else:                                                        # :1073-1075 all average
+        current, count = torch.sum(kept_delta, dim=0), kept_delta.shape[0]
+    old = vertices_init.detach().cpu().float().reshape(1, V, 3)
+    if count <= 1:                                               # :1078 nothing to fuse
+        return old.clone(), count, 0.0
+    last = (current * 1.0 / count).reshape(V, 3)
+    L = laplacian.detach().cpu().float()
+    if smooth > 0:                                               # :1081-1088 move towards the neighbours' mean
+        last = last + torch.matmul(L, last) * smooth
+        if em >= 6:
+            for _ in range(int(em - 5)):
+                last = last + torch.matmul(L, last) * smooth
+    last = torch.clamp(last, min=-clip, max=clip)                # :1089-1090
+    new = old + warm_up * em_step * last                         # :1091
+    if white:
+        new = new - torch.mean(new, dim=1, keepdim=True)         # :1095-1096
+    whether_cross = float(torch.sum(torch.nn.functional.relu(-torch.sign(new[:, :, 2]) * torch.sign(old[:, :, 2]))))   # :1098-1099
+    if whether_cross > 0 and cross:                              # :1101-1102 only update when no point crossed the depth plane
+        new = old.clone()
+    return new, count, whether_cross

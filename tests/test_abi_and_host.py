@@ -172,3 +172,29 @@ def test_deep_copy_and_attributes(pkg):
     assert c["vertices"].shape[0] == 2 and torch.equal(c["lights"][0], att["lights"][2])
     att["bg"] = None
     assert pkg.deep_copy(att)["bg"] is None
+
+
+def test_template_em_update_matches_reference(pkg):
+    """template.fuse_template against the reference's inline EM-update statements executed on the same inputs
+    (tests/golden/template_em.npz, minted by tests/golden/make_golden_em.py)."""
+    z = np.load(os.path.join(GOLDEN, "template_em.npz"))
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "sphere.npz"), 32)
+    av, ad = torch.from_numpy(z["all_vertices"]), torch.from_numpy(z["all_delta_vertices"])
+    ran = 0
+    for em, smooth, cross, white, count in z["cases"]:
+        em, cross, white, count = int(em), int(cross), int(white), int(count)
+        tag = "em%d_s%g_c%d_w%d" % (em, smooth, cross, white)
+        kw = dict(em=em, smooth=float(smooth), clip=0.05, em_step=0.8, warm_up=0.7, white=bool(white), cross=bool(cross), topK=0.5)
+        if count < 0:                                            # the reference itself raises in this mode
+            exc = {"IndexError": IndexError, "RuntimeError": RuntimeError}[str(z["raises_" + tag])]
+            with pytest.raises(exc):
+                pkg.template.fuse_template(dr.vertices_init, dr.vertices_laplacian_matrix, av, ad, **kw)
+            continue
+        new, n, _ = pkg.template.fuse_template(dr.vertices_init, dr.vertices_laplacian_matrix, av, ad, **kw)
+        assert n == count and new.shape == (1, dr.num_vertices, 3)
+        np.testing.assert_allclose(new.numpy(), z["new_" + tag], rtol=0, atol=2e-7)
+        ran += 1
+    assert ran >= 9
+    # the update moved the template, stayed within the clip, and the cross rule can veto it
+    moved = np.abs(z["new_em1_s0_c0_w0"] - dr.vertices_init.numpy()[None]).max()
+    assert 0 < moved <= 0.7 * 0.8 * 0.05 + 1e-7

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             const int ld = __ffsll((unsigned long long)pending) - 1;
             const int tile = __shfl(rtile[c], ld, 64);
             const unsigned long long m = __ballot(rtile[c] == tile);
-            if (rtile[c] == tile) { leader[c] = ld; rank[c] = __popcll(m & ((1ull << lane) - 1ull)); size = __popcll(m); }
+            if (rtile[c] == tile) { leader[c] = ld; rank[c] = ballot_rank(m); size = __popcll(m); }
             pending &= ~m;
         }
         if (leader[c] == lane) base[c] = atomicAdd(a.tcnt + (size_t)b * a.ntiles_ + rtile[c], size);
@@ -350,7 +350,7 @@ __device__ inline int compact4(const bool (&flag)[MM_SWEEP], int lane, unsigned 
 #pragma unroll
     for (int i = 0; i < MM_SWEEP; ++i) {
         const unsigned long long m = __ballot(flag[i]);
-        if (flag[i]) items[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((i << 6) | lane);
+        if (flag[i]) items[base + ballot_rank(m)] = (unsigned short)((i << 6) | lane);
         base += __popcll(m);
     }
     return base;

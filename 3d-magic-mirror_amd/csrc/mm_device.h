@@ -297,6 +297,11 @@ inline int launch_ok(const char* what) {
 // errors left behind by the caller's own earlier runtime calls (e.g. hipEventQuery -> hipErrorNotReady) are not ours
 inline void clear_stale_error() { (void)hipGetLastError(); }
 
+// number of set bits of a ballot below this lane: two v_mbcnt instructions (a 64-bit shift/and/popcount sequence costs ~10x)
+__device__ inline int ballot_rank(uint64_t bal) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

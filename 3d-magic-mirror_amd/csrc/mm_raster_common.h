@@ -73,11 +73,6 @@ __device__ inline void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// number of set bits of a ballot below this lane
-__device__ inline int ballot_rank(uint64_t bal) {
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-}
-
 // 64x64 bit-matrix transpose across the wave: lane i holds row i on entry and column i on exit (6 butterfly stages).
 template <int S>
 __device__ inline uint64_t transpose_stage(uint64_t x, int lane) {

@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One hardware queue per stream: HIP multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and two of the
+# bench's streams landing on one queue serialises their steps.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 

@@ -50,6 +50,19 @@ class MMMeshRegDesc(ctypes.Structure):
                 ("losses", c_p), ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
 
 
+class MMAttributes(ctypes.Structure):
+    _fields_ = [(k, c_p) for k in ("azimuths", "elevations", "distances", "biases", "vertices", "textures", "lights")]
+
+
+class MMAttLossDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("V", c_i), ("Ht", c_i), ("Wt", c_i), ("l1", c_i), ("pred", MMAttributes), ("target", MMAttributes),
+                ("losses", c_p), ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
+class MMAttLossGrads(ctypes.Structure):
+    _fields_ = [("weights", c_p), ("pred", MMAttributes), ("target", MMAttributes)]
+
+
 class MMTexFlowDesc(ctypes.Structure):
     _fields_ = [("B", c_i), ("C", c_i), ("H", c_i), ("W", c_i), ("Ho", c_i), ("Wo", c_i), ("image", c_p), ("flow", c_p), ("textures", c_p)]
 
@@ -71,7 +84,8 @@ PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",
            "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_uv_tiles", "mm_nearest_neighbour", "mm_status_string", "mm_last_error_detail",
            "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward", "mm_texture_flow_forward",
-           "mm_texture_flow_backward",
+           "mm_texture_flow_backward", "mm_attribute_loss_query_workspace", "mm_attribute_loss_forward",
+           "mm_attribute_loss_backward",
            "mm_abi_version")
 
 
@@ -106,6 +120,10 @@ def lib():
     L.mm_mesh_reg_query_workspace.argtypes = [ctypes.POINTER(MMMeshRegDesc)]
     L.mm_mesh_reg_forward.argtypes = [ctypes.POINTER(MMMeshRegDesc), c_p]
     L.mm_mesh_reg_backward.argtypes = [ctypes.POINTER(MMMeshRegDesc), ctypes.POINTER(MMMeshRegGrads), c_p]
+    L.mm_attribute_loss_query_workspace.restype = ctypes.c_size_t
+    L.mm_attribute_loss_query_workspace.argtypes = [ctypes.POINTER(MMAttLossDesc)]
+    L.mm_attribute_loss_forward.argtypes = [ctypes.POINTER(MMAttLossDesc), c_p]
+    L.mm_attribute_loss_backward.argtypes = [ctypes.POINTER(MMAttLossDesc), ctypes.POINTER(MMAttLossGrads), c_p]
     L.mm_texture_flow_forward.argtypes = [ctypes.POINTER(MMTexFlowDesc), c_p]
     L.mm_texture_flow_backward.argtypes = [ctypes.POINTER(MMTexFlowDesc), ctypes.POINTER(MMTexFlowGrads), c_p]
     L.mm_build_vertex_corner_csr.argtypes = [c_i, c_i, c_p, c_p, c_p]

@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "lib", "libmm_render.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 EXACT = ["-ffp-contract=off"]
 RELAXED = ["-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
-SOURCES = {"mm_abi.hip": EXACT, "mm_reg.hip": EXACT, "mm_texflow.hip": EXACT, "mm_vertex.hip": EXACT, "mm_raster.hip": EXACT, "mm_raster_resident.hip": EXACT,
+SOURCES = {"mm_abi.hip": EXACT, "mm_reg.hip": EXACT, "mm_texflow.hip": EXACT, "mm_attloss.hip": EXACT, "mm_vertex.hip": EXACT, "mm_raster.hip": EXACT, "mm_raster_resident.hip": EXACT,
            "mm_backward.hip": RELAXED, "mm_loss.hip": EXACT, "mm_nn.hip": EXACT}
 HEADERS = ["mm_device.h", "mm_raster_common.h", os.path.join("..", "..", "include", "mm_render.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -16,6 +16,9 @@ int launch_nn(int, int, int, const float*, const float*, float*, int32_t*, hipSt
 size_t reg_workspace_bytes(const MMMeshRegDesc*);
 int launch_reg_fwd(const MMMeshRegDesc*, hipStream_t);
 int launch_reg_bwd(const MMMeshRegDesc*, const MMMeshRegGrads*, hipStream_t);
+size_t att_workspace_bytes(const MMAttLossDesc*);
+int launch_att_fwd(const MMAttLossDesc*, hipStream_t);
+int launch_att_bwd(const MMAttLossDesc*, const MMAttLossGrads*, hipStream_t);
 int launch_texflow_fwd(const MMTexFlowDesc*, hipStream_t);
 int launch_texflow_bwd(const MMTexFlowDesc*, const MMTexFlowGrads*, hipStream_t);
 }  // namespace mm
@@ -146,6 +149,37 @@ int mm_mesh_reg_backward(const MMMeshRegDesc* d, const MMMeshRegGrads* g, mm_str
         return MM_ERR_NULL_POINTER;                              // a gradient is only defined for an input that was given
     mm::clear_stale_error();
     return mm::launch_reg_bwd(d, g, (hipStream_t)stream);
+}
+
+static int check_att(const MMAttLossDesc* d) {
+    if (!d) return MM_ERR_NULL_POINTER;
+    if (d->B <= 0 || d->V <= 0 || d->Ht <= 0 || d->Wt <= 0) return MM_ERR_BAD_SHAPE;
+    const MMAttributes* two[2] = {&d->pred, &d->target};
+    for (const MMAttributes* m : two)
+        if (!m->azimuths || !m->elevations || !m->distances || !m->biases || !m->vertices || !m->textures || !m->lights) return MM_ERR_NULL_POINTER;
+    if (!d->workspace || d->workspace_bytes < mm_attribute_loss_query_workspace(d)) return MM_ERR_WORKSPACE;
+    return MM_OK;
+}
+
+size_t mm_attribute_loss_query_workspace(const MMAttLossDesc* d) {
+    if (!d || d->B <= 0 || d->Ht <= 0 || d->Wt <= 0) return 0;
+    return mm::att_workspace_bytes(d);
+}
+
+int mm_attribute_loss_forward(const MMAttLossDesc* d, mm_stream_t stream) {
+    const int st = check_att(d);
+    if (st != MM_OK) return st;
+    if (!d->losses) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    return mm::launch_att_fwd(d, (hipStream_t)stream);
+}
+
+int mm_attribute_loss_backward(const MMAttLossDesc* d, const MMAttLossGrads* g, mm_stream_t stream) {
+    const int st = check_att(d);
+    if (st != MM_OK) return st;
+    if (!g || !g->weights) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    return mm::launch_att_bwd(d, g, (hipStream_t)stream);
 }
 
 static int check_texflow(const MMTexFlowDesc* d) {

@@ -4,8 +4,8 @@ Same constructor, attributes, method names, argument meaning and return values a
 ``trainer.py``-style loop can switch with ``from mm_amd import DiffRender``.  ``render`` and ``recon_data`` run the
 hand-written HIP kernels of ``lib/libmm_render.so`` through ``torch.autograd.Function`` wrappers; there is no CPU or
 eager-torch fallback for them.  The mesh regularisers (``recon_flip``, ``calc_reg_*``) run as one HIP
-launch per direction (``mesh_reg.py``); the attribute losses of ``recon_att`` are small elementwise means in torch ops, its
-chamfer term a HIP nearest-neighbour kernel.
+launch per direction (``mesh_reg.py``), and so do the attribute losses of ``recon_att`` (``att_loss.py``); its chamfer term is
+a HIP nearest-neighbour kernel.
 """
 import ctypes
 import math
@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from . import mesh_reg, obj_io, template
+from . import att_loss, mesh_reg, obj_io, template
 
 
 class _RenderFn(torch.autograd.Function):
@@ -252,26 +252,17 @@ class DiffRender(object):
         loss = _ReconFn.apply(pred_data, gt_data, self.image_weight, contour)
         return loss
 
-    # ---- networks.py:326-362 (torch restatement; chamfer: SURVEY 8(f) rank 2) -------------------------------------
+    # ---- networks.py:326-362: seven means in one HIP launch per direction (att_loss.py / csrc/mm_attloss.hip); the chamfer
+    # variant of the shape term is a HIP nearest-neighbour search + a differentiable gather ----------
     def recon_att(self, pred_att, target_att, L1=False, chamfer=False, azim=1):
-        def angle2xy(angle):
-            angle = angle * math.pi / 180.0
-            return torch.stack([torch.cos(angle), torch.sin(angle)], 1)
-
-        dist = (lambda a, b: torch.abs(a - b).mean()) if L1 else (lambda a, b: torch.pow(a - b, 2).mean())
-        loss_azim = dist(angle2xy(pred_att['azimuths']), angle2xy(target_att['azimuths']))
-        loss_elev = dist(angle2xy(pred_att['elevations']), angle2xy(target_att['elevations']))
-        loss_dist = dist(pred_att['distances'], target_att['distances'])
-        loss_bias = dist(pred_att['biases'], target_att['biases'])
-        loss_cam = azim * loss_azim + loss_elev + loss_dist
+        l = att_loss.attribute_losses(pred_att, target_att, L1)
+        loss_cam = azim * l[att_loss.AZIM] + l[att_loss.ELEV] + l[att_loss.DIST]
         if chamfer:
             from .chamfer import chamfer_distance
             loss_shape, _ = chamfer_distance(pred_att['vertices'], target_att['vertices'])
         else:
-            loss_shape = dist(pred_att['vertices'], target_att['vertices'])
-        loss_texture = dist(pred_att['textures'], target_att['textures'])
-        loss_light = 0.1 * dist(pred_att['lights'], target_att['lights'])
-        return loss_cam, loss_shape, loss_texture, loss_light, loss_bias
+            loss_shape = l[att_loss.SHAPE]
+        return loss_cam, loss_shape, l[att_loss.TEXTURE], 0.1 * l[att_loss.LIGHT], l[att_loss.BIAS]
 
     # ---- mesh regularisers (networks.py:392-491): HIP kernels, one launch per direction (mesh_reg.py / csrc/mm_reg.hip) ----
     def _reg_tables(self, device):

@@ -206,6 +206,41 @@ int mm_mesh_reg_forward(const MMMeshRegDesc* desc, mm_stream_t stream);
 int mm_mesh_reg_backward(const MMMeshRegDesc* desc, const MMMeshRegGrads* grads, mm_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------------------------------
+ * Attribute-reconstruction losses: replaces the seven means of DiffRender.recon_att
+ * (networks.py:326-362; the chamfer variant of the shape term goes through mm_nearest_neighbour instead).
+ * losses = { azim, elev, dist, bias, shape, texture, light }: mean |a-b| (l1 = 1) or mean (a-b)^2 (l1 = 0) over all
+ * elements, azimuths / elevations through angle2xy (cos, sin of the angle in degrees).  The reference composes
+ * loss_cam = azim * losses[0] + losses[1] + losses[2], loss_light = 0.1 * losses[6].
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct MMAttributes {     /* device pointers; in MMAttLossGrads any may be NULL (= that gradient is not wanted) */
+    float* azimuths;              /* (B) degrees */
+    float* elevations;            /* (B) degrees */
+    float* distances;             /* (B) */
+    float* biases;                /* (B,2) */
+    float* vertices;              /* (B,V,3) */
+    float* textures;              /* (B,3,Ht,Wt) */
+    float* lights;                /* (B,9) */
+} MMAttributes;
+
+typedef struct MMAttLossDesc {
+    int32_t B, V, Ht, Wt;
+    int32_t l1;                   /* 1: mean |a-b| (opt.L1), 0: mean (a-b)^2 */
+    MMAttributes pred, target;    /* read only; all seven required */
+    float* losses;                /* (7) device */
+    void* workspace;              /* >= mm_attribute_loss_query_workspace bytes, 256-byte aligned, ZERO-FILLED before its first use */
+    size_t workspace_bytes;
+} MMAttLossDesc;
+
+typedef struct MMAttLossGrads {
+    const float* weights;         /* (7) device: dL/d losses[k] */
+    MMAttributes pred, target;    /* outputs, overwritten; NULL members are skipped */
+} MMAttLossGrads;
+
+size_t mm_attribute_loss_query_workspace(const MMAttLossDesc* desc);
+int mm_attribute_loss_forward(const MMAttLossDesc* desc, mm_stream_t stream);
+int mm_attribute_loss_backward(const MMAttLossDesc* desc, const MMAttLossGrads* grads, mm_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------------------------------
  * Texture-flow sampling: the tail of TextureEncoder.forward (network/model_res.py:597-612, makeup = 0),
  * i.e. the step that produces the texture the render path consumes:
  *   textures = cat([t, t.flip(2)], 2),  t = F.grid_sample(image, flow.permute(0,2,3,1), mode='bicubic', align_corners=True)

@@ -95,8 +95,8 @@ def _att(z, prefix, grad=True):
 
 
 def test_loss_oracle_and_attribute_losses_match_reference(pkg):
-    """oracle/reg_oracle.py (the checker of the HIP mesh-regulariser kernels) and the mirror's recon_att against outputs and
-    gradients of the reference itself (tests/golden/losses.npz)."""
+    """oracle/reg_oracle.py (the checker of the HIP mesh-regulariser and attribute-loss kernels) against outputs and gradients of
+    the reference itself (tests/golden/losses.npz)."""
     import reg_oracle as R
     z = np.load(os.path.join(GOLDEN, "losses.npz"))
     dr = pkg.DiffRender(os.path.join(TEMPLATES, "sphere.npz"), 64, image_weight=0.1, lambda_lpl=0.1, lambda_flat=0.001)
@@ -127,11 +127,12 @@ def test_loss_oracle_and_attribute_losses_match_reference(pkg):
         dr.recon_flip(A, True)
     wrt = ("azimuths", "elevations", "distances", "biases", "delta_vertices", "textures", "lights")
     for L1 in (True, False):
-        for parts in (dr.recon_att(A, A2, L1=L1, chamfer=False, azim=1), R.recon_att(A, A2, L1=L1, azim=1)):
-            for nm, val in zip(("cam", "shape", "texture", "light", "bias"), parts):
-                check("recon_att_L1%d_%s" % (L1, nm), val, wrt)
+        parts = R.recon_att(A, A2, L1=L1, azim=1)
+        for nm, val in zip(("cam", "shape", "texture", "light", "bias"), parts):
+            check("recon_att_L1%d_%s" % (L1, nm), val, wrt)
     # the mesh regularisers are HIP kernels: host tensors are refused, there is no CPU path
-    for call in (lambda: dr.calc_reg_loss(A), lambda: dr.calc_reg_edge(A["vertices"]), lambda: dr.recon_flip(A, False)):
+    for call in (lambda: dr.calc_reg_loss(A), lambda: dr.calc_reg_edge(A["vertices"]), lambda: dr.recon_flip(A, False),
+                 lambda: dr.recon_att(A, A2)):
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             call()
 

@@ -140,3 +140,54 @@ def test_mesh_reg_abi_validation(pkg):
     assert N.lib().mm_mesh_reg_forward(ctypes.byref(d), None) == -1                 # DEPTH needs vertices: MM_ERR_NULL_POINTER
     d.terms = 1 << 9
     assert N.lib().mm_mesh_reg_forward(ctypes.byref(d), None) == -2
+
+
+def _att_sets(z, dev):
+    keys = ("delta_vertices", "azimuths", "elevations", "distances", "biases", "textures", "lights")
+    A = {k: torch.from_numpy(z["A_" + k]).clone().to(dev).requires_grad_(True) for k in keys}
+    A2 = {k: torch.from_numpy(z["A2_" + k]).clone().to(dev) for k in keys}
+    return A, A2
+
+
+def test_recon_att_matches_reference_golden(pkg):
+    """DiffRender.recon_att (mm_attribute_loss_*) against the reference's own values and gradients, L1 and L2."""
+    z = np.load(os.path.join(GOLDEN, "losses.npz"))
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "sphere.npz"), 64)
+    wrt = ("azimuths", "elevations", "distances", "biases", "delta_vertices", "textures", "lights")
+    for L1 in (True, False):
+        A, A2 = _att_sets(z, DEV)
+        A["vertices"] = dr.vertices_init[None].to(DEV) + A["delta_vertices"]
+        A2["vertices"] = dr.vertices_init[None].to(DEV) + A2["delta_vertices"]
+        parts = dr.recon_att(A, A2, L1=L1, chamfer=False, azim=1)
+        for nm, val in zip(("cam", "shape", "texture", "light", "bias"), parts):
+            name = "recon_att_L1%d_%s" % (L1, nm)
+            np.testing.assert_allclose(float(val), float(z[name]), rtol=2e-5, atol=1e-7)
+            grads = torch.autograd.grad(val, [A[k] for k in wrt], allow_unused=True, retain_graph=True)
+            for k, g in zip(wrt, grads):
+                ref = z[name + "__d_" + k]
+                got = np.zeros_like(ref) if g is None else g.cpu().numpy()
+                np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-7, err_msg=name + " d/d" + k)
+
+
+@pytest.mark.parametrize("B,S,L1,seed", [(48, 128, True, 0), (5, 32, False, 1)])
+def test_recon_att_matches_oracle_both_sides(pkg, B, S, L1, seed):
+    """Full-size textures, gradients to BOTH attribute sets, against the fp64 oracle."""
+    import reg_oracle as R
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "smpl_uv_642.npz"), S)
+    sets = []
+    for s in (seed, seed + 10):
+        att, _ = pkg.synthetic.synthetic_batch(dr.vertices_init, B, S, S, seed=s)
+        sets.append({k: att[k] for k in ("azimuths", "elevations", "distances", "biases", "vertices", "textures", "lights")})
+    dev_sets = [{k: v.clone().to(DEV).requires_grad_(True) for k, v in s.items()} for s in sets]
+    host_sets = [{k: v.clone().double().requires_grad_(True) for k, v in s.items()} for s in sets]
+    got = dr.recon_att(dev_sets[0], dev_sets[1], L1=L1, chamfer=False, azim=0.7)
+    ref = R.recon_att(host_sets[0], host_sets[1], L1=L1, azim=0.7)
+    wts = (1.0, 0.5, 2.0, 3.0, 0.25)
+    for a, b in zip(got, ref):
+        assert abs(float(a) - float(b)) <= 2e-5 * max(1.0, abs(float(b)))
+    sum(w * a for w, a in zip(wts, got)).backward()
+    sum(w * b for w, b in zip(wts, ref)).backward()
+    for d, h in zip(dev_sets, host_sets):
+        for k in d:
+            scale = max(float(h[k].grad.abs().max()), 1e-12)
+            assert float((d[k].grad.cpu().double() - h[k].grad).abs().max()) <= 2e-4 * scale + 1e-10, k

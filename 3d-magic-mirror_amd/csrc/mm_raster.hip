@@ -44,11 +44,14 @@ __device__ inline TileCtx make_tile(const RasterArgs& a) {
     // they must not start last.  Workgroup i -> image i % B (XCD i % 8 = image % 8 when 8 | B), rank i / B.
     if (a.order) {
         t.b = blockIdx.x % a.B;
-        const int slot = a.order[(size_t)t.b * 4 * a.blocks_per_image + blockIdx.x / a.B];
+        const unsigned e = a.order[(size_t)t.b * 4 * a.blocks_per_image + blockIdx.x / a.B];
+        const int slot = (int)(e & 0x7FFFu);
+        t.empty = (e >> 15) != 0;                                // the order kernel counted no candidate at all for this tile
         blk = slot >> 2; t.wave = slot & 3;
     } else {
         map_block(blockIdx.x >> 2, a.B, a.blocks_per_image, t.b, blk);
         t.wave = blockIdx.x & 3;
+        t.empty = false;
     }
     t.blk = blk;
     t.lane = threadIdx.x & 63;
@@ -138,14 +141,15 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
     WaveStage* st = &s_stage;
 
     Hit h;
-    raster_pixels(a, t, st, h);
+    if (t.empty) { h.f = -1; h.w0 = h.w1 = h.w2 = 0.f; }       // wave-uniform: more than half of all tiles
+    else raster_pixels(a, t, st, h);
 
     // K3: soft silhouette for the lanes no front face covers.  prod(1-p) is order-free, so it is accumulated per pixel
     // as an integer sum of log2(1-p) in 2^-32 fixed point (exact, commutative LDS adds) plus a count of exact zeros.
     float qnz = 1.f;
     int zeros = 0, lastf = 0x7FFFFFFF;
     const bool open = t.in_img && h.f < 0;
-    if (__ballot(open)) {
+    if (!t.empty && __ballot(open)) {
         int cnt = 0;
         const float s2 = a.sigmainv / (a.mult * a.mult);
         st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0;
@@ -172,7 +176,8 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
 
 // Orders the tile slots (16x16 block * 4 + quadrant) of every image by their soft-mask candidate count, descending: a counting
 // sort in LDS (keys clipped to 1023; slots per image <= 1024), linear in the slots.  Only the launch ORDER of raster_fwd
-// depends on it -- slots with equal counts may come out in any order, no result does.
+// depends on it -- slots with equal counts may come out in any order, no result does.  Bit 15 of an entry marks a tile that no
+// face can touch (count 0: the silhouette mask is a superset of the colour mask), which raster_fwd then never walks.
 __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short* order) {
     __shared__ int s_key[1024];
     __shared__ int s_start[1024];          // histogram, then the first output position of every key
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
     for (int j = 0; j < 4; ++j) { s_start[1023 - (4 * tid + j)] = before; before += h[j]; }
     __syncthreads();
     for (int slot = tid; slot < nslot; slot += 256)
-        order[(size_t)b * nslot + atomicAdd(&s_start[s_key[slot]], 1)] = (unsigned short)slot;
+        order[(size_t)b * nslot + atomicAdd(&s_start[s_key[slot]], 1)] = (unsigned short)(slot | (s_key[slot] == 0 ? 0x8000 : 0));
 }
 
 RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {

@@ -42,6 +42,7 @@ struct RasterArgs {
 struct TileCtx {
     int b, blk, px, py, tx0, ty0, lane, wave;   // wave = quadrant of the 16x16 block `blk`
     bool in_img;
+    bool empty;                             // no face can touch the tile (known from the order kernel): nothing to walk
     float x0, y0;
     float xs[MM_TILE], ys[MM_TILE];         // pixel-centre columns / rows of the tile (same in every lane)
     const uint64_t* mask;                   // streamed: this wave's bin row (soft candidates): `words` 64-bit words
@@ -51,6 +52,12 @@ struct TileCtx {
 __device__ inline void tile_pixels(const RasterArgs& a, TileCtx& t) {
     t.px = t.tx0 + (t.lane & 7); t.py = t.ty0 + (t.lane >> 3);
     t.in_img = t.px < a.W && t.py < a.H;
+    if (t.empty) {                                               // wave-uniform: an empty tile never looks at pixel centres
+        t.x0 = t.y0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MM_TILE; ++i) { t.xs[i] = 0.f; t.ys[i] = 0.f; }
+        return;
+    }
     t.x0 = pixel_x(t.px, a.W, a.mult); t.y0 = pixel_y(t.py, a.H, a.mult);
 #pragma unroll
     for (int i = 0; i < MM_TILE; ++i) { t.xs[i] = pixel_x(t.tx0 + i, a.W, a.mult); t.ys[i] = pixel_y(t.ty0 + i, a.H, a.mult); }

@@ -27,6 +27,7 @@ static int check_render(const MMRenderDesc* d, bool backward) {
     if (!d) return MM_ERR_NULL_POINTER;
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->V <= 0 || d->F <= 0 || d->Ht <= 0 || d->Wt <= 0) return MM_ERR_BAD_SHAPE;
     if (d->knum <= 0) return MM_ERR_UNSUPPORTED;
+    if (d->H > 65535 || d->W > 65535) return MM_ERR_UNSUPPORTED;                 // pixel boxes are packed in 16 + 16 bits
     if (!d->faces || !d->face_uvs || !d->vertices || !d->textures || !d->lights || !d->azimuths || !d->elevations ||
         !d->distances || !d->biases || !d->rgba || !d->face_idx || !d->face_normals)
         return MM_ERR_NULL_POINTER;

@@ -304,17 +304,16 @@ __device__ inline float group16_sum(float v) {
 
 struct FaceBox { float4 p0, p1; float xmin, ymin, xmax, ymax; int px0, py0, bw, npx; float inv_bw; };
 
-__device__ inline FaceBox face_box(const BwdArgs& a, size_t o, float pad) {
+__device__ inline FaceBox face_box(const BwdArgs& a, size_t o) {
     FaceBox fb;
     fb.p0 = a.geo[o * 3 + 0]; fb.p1 = a.geo[o * 3 + 1];
+    const float4 g2 = a.geo[o * 3 + 2];                           // z, w: the inflated pixel box, packed by the vertex stage
     fb.xmin = fminf(fminf(fb.p0.x, fb.p0.z), fb.p1.x); fb.ymin = fminf(fminf(fb.p0.y, fb.p0.w), fb.p1.y);
     fb.xmax = fmaxf(fmaxf(fb.p0.x, fb.p0.z), fb.p1.x); fb.ymax = fmaxf(fmaxf(fb.p0.y, fb.p0.w), fb.p1.y);
-    int px1, py1;
-    pixel_range(fb.xmin - pad, fb.xmax + pad, a.mult, a.W, false, fb.px0, px1);
-    pixel_range(fb.ymin - pad, fb.ymax + pad, a.mult, a.H, true, fb.py0, py1);
-    fb.bw = px1 - fb.px0 + 1;
-    const int bh = py1 - fb.py0 + 1;
-    fb.npx = (fb.bw > 0 && bh > 0) ? fb.bw * bh : 0;
+    const unsigned org = __float_as_uint(g2.z), ext = __float_as_uint(g2.w);
+    fb.px0 = (int)(org & 0xFFFFu); fb.py0 = (int)(org >> 16);
+    fb.bw = (int)(ext & 0xFFFFu);
+    fb.npx = fb.bw * (int)(ext >> 16);
     fb.inv_bw = 1.f / (float)(fb.bw > 0 ? fb.bw : 1);
     return fb;
 }
@@ -332,8 +331,6 @@ __device__ inline void box_pixel(int idx, int px0, int py0, int bw, float inv_bw
 struct __attribute__((aligned(16))) FaceSlot {
     float4 p0, p1;                   // ax,ay,bx,by | cx,cy,az,bz  (multiplier units)
     float box[4];                    // xmin, ymin, xmax, ymax
-    float fu[6];                     // corner uvs
-    float n[3];                      // unit normal
     int px0, py0, bw, f;
     float inv_bw;
     float acc[9];                    // dL/d(ax,ay,bx,by,cx,cy), dL/d(n)
@@ -438,17 +435,12 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     const int f = a.face_order ? a.face_order[rk] : rk;
     const size_t o = (size_t)b * a.F + f, hw = (size_t)a.H * a.W;
     const float s2 = a.mult * a.mult;
-    FaceBox fb = face_box(a, o, a.infl);
+    FaceBox fb = face_box(a, o);
     if (!live) fb.npx = 0;
     if (sl == 0) {
         FaceSlot& fs = st->slot[grp];
         fs.p0 = fb.p0; fs.p1 = fb.p1; fs.box[0] = fb.xmin; fs.box[1] = fb.ymin; fs.box[2] = fb.xmax; fs.box[3] = fb.ymax;
         fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f;
-        const float* fu = a.face_uvs + (size_t)f * 6;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) fs.fu[i] = fu[i];
-        const float* nn = a.fn + o * 3;
-        fs.n[0] = nn[0]; fs.n[1] = nn[1]; fs.n[2] = nn[2];
     }
     if (sl < 9) st->slot[grp].acc[sl] = 0.f;
     int nmax = fb.npx;

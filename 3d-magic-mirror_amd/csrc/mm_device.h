@@ -47,7 +47,8 @@ struct TexSpill { TexRecord r; int tile; int pad; };
 // ---- workspace carving (all offsets multiples of 256 bytes) ---------------------------------------------------------
 struct Workspace {
     float* T;              // (B,12)     camera transform [R;t], row-major (4,3)
-    float4* geo;           // (B,F,3)    {ax,ay,bx,by} {cx,cy,az,bz} {cz, unit normal z, 0, 0}; xy in multiplier units
+    float4* geo;           // (B,F,3)    {ax,ay,bx,by} {cx,cy,az,bz} {cz, unit normal z, box origin, box extent}; xy in multiplier
+                           //            units; box = inflated pixel box px0 | py0 << 16, w | h << 16 (as int bits)
     uint64_t* binmask;     // (B,nbins,ceil(F/64)) bit f: the box of face f, inflated by the soft-mask margin, may touch the bin
     uint64_t* binmask_hard;// (B,nbins,ceil(F/64)) bit f: face f is front facing and its box may touch the bin
     float* softq;          // (B,H,W)    soft-mask product state of uncovered pixels: +prod(1-p) if no factor is 0,

@@ -12,7 +12,7 @@ namespace mm {
 
 struct VertexFwdArgs {
     int B, V, F, H, W;
-    float proj0, proj1, proj2, mult;
+    float proj0, proj1, proj2, mult, infl;
     const int32_t* faces;
     const float* vertices;
     const float *azim, *elev, *dist, *bias;
@@ -68,7 +68,15 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     const size_t o = (size_t)b * a.F + f;
     a.geo[o * 3 + 0] = make_float4(ax, ay, bx, by);
     a.geo[o * 3 + 1] = make_float4(cx, cy, A.z, Bv.z);
-    a.geo[o * 3 + 2] = make_float4(C.z, nz, 0.f, 0.f);
+    // the pixel box of the face inflated by the soft-mask margin (conservative, see pixel_range), packed for the backward's
+    // face sweep: x = px0 | py0 << 16, y = width | height << 16 (0 x 0 if it misses the image)
+    int bx0, bx1, by0, by1;
+    pixel_range(fminf(fminf(ax, bx), cx) - a.infl, fmaxf(fmaxf(ax, bx), cx) + a.infl, a.mult, a.W, false, bx0, bx1);
+    pixel_range(fminf(fminf(ay, by), cy) - a.infl, fmaxf(fmaxf(ay, by), cy) + a.infl, a.mult, a.H, true, by0, by1);
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    const bool hit = bw > 0 && bh > 0;
+    a.geo[o * 3 + 2] = make_float4(C.z, nz, __uint_as_float(hit ? ((unsigned)bx0 | ((unsigned)by0 << 16)) : 0u),
+                                     __uint_as_float(hit ? ((unsigned)bw | ((unsigned)bh << 16)) : 0u));
     a.face_normals[o * 3 + 0] = nx; a.face_normals[o * 3 + 1] = ny; a.face_normals[o * 3 + 2] = nz;
 
 }
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
 int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     VertexFwdArgs a;
     a.B = d->B; a.V = d->V; a.F = d->F; a.H = d->H; a.W = d->W;
-    a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2]; a.mult = d->multiplier;
+    a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2]; a.mult = d->multiplier; a.infl = d->boxlen * d->multiplier;
     a.faces = d->faces; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.geo = w.geo; a.face_normals = d->face_normals;

@@ -491,7 +491,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
                 float d = seg_dist2(x0, y0, p0.x, p0.y, p0.z, p0.w, ty);
                 const float d1 = seg_dist2(x0, y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
                 const float d2 = seg_dist2(x0, y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
-                const float p = expf(-((d / s2) * a.sigmainv));
+                const float p = __builtin_amdgcn_exp2f(-(d * (a.sigmainv / s2)) * 1.4426950408889634f);
                 const float q = 1.f - p;
                 const float qnz = fabsf(sq);
                 const bool onezero = sq < 0.f;

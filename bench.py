@@ -7,8 +7,8 @@
 One "step" = one pass of the hot path over one batch: mm_render_forward -> mm_recon_data_forward ->
 mm_recon_data_backward -> mm_render_backward (gradients to vertices, textures, lights, bg, distances, elevations,
 azimuths, biases), inputs resident in HBM.  Every step does all of that work on a full B=48 batch; successive steps are
-independent (the reference's trainer issues 3-4 independent renders per iteration, trainer.py:276,345,347,367) and are
-enqueued round-robin on --streams HIP streams (default 3) so that one step's long-tailed kernels overlap the next step's;
+independent (the reference's trainer issues four independent renders per iteration, trainer.py:276,345,347,367) and are
+enqueued round-robin on --streams HIP streams (default 4, one hardware queue each) so that the steps' kernels overlap;
 "value_one_stream" is the same loop on a single stream.  Workload at every N: BASELINE config 2 (template smpl_uv_642, B=48 per
 GPU, 128x128, texture 256x128, no_mask).  The batch shards across ranks with no data-path collective (weak scaling).
 Prints ONE JSON line on rank 0.
@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--config", default="config2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="eager", choices=["hipgraph", "eager", "torch"],
                     help="hipgraph: whole step replayed as one HIP graph; eager: 4 ABI calls per step; torch: DiffRender autograd API")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="successive (independent) steps are enqueued round-robin on this many HIP streams, each with its own buffers")
     ap.add_argument("--unfused", action="store_true", help="recon_data as its own three launches instead of folded into the render kernels")
     ap.add_argument("--resident", action="store_true", help="opt into the LDS-resident forward kernel (MM_OPT_RESIDENT)")

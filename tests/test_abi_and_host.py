@@ -199,3 +199,27 @@ def test_template_em_update_matches_reference(pkg):
     # the update moved the template, stayed within the clip, and the cross rule can veto it
     moved = np.abs(z["new_em1_s0_c0_w0"] - dr.vertices_init.numpy()[None]).max()
     assert 0 < moved <= 0.7 * 0.8 * 0.05 + 1e-7
+
+
+def test_next_row_entry_points_validate_before_any_gpu_work(pkg):
+    """mm_mesh_reg_*, mm_attribute_loss_*, mm_texture_flow_*: argument validation happens on the host (no GPU here)."""
+    N = pkg._native
+    L = N.lib()
+    d = N.MMMeshRegDesc()
+    assert L.mm_mesh_reg_forward(ctypes.byref(d), None) == -2                       # MM_ERR_BAD_SHAPE
+    d.B, d.V, d.F, d.E, d.terms = 2, 10, 12, 20, 1 << 3
+    assert L.mm_mesh_reg_query_workspace(ctypes.byref(d)) % 256 == 0 and L.mm_mesh_reg_query_workspace(ctypes.byref(d)) > 0
+    assert L.mm_mesh_reg_forward(ctypes.byref(d), None) == -1                       # DEPTH needs vertices
+    d.terms = 1 << 9
+    assert L.mm_mesh_reg_forward(ctypes.byref(d), None) == -2
+    a = N.MMAttLossDesc()
+    assert L.mm_attribute_loss_forward(ctypes.byref(a), None) == -2
+    a.B, a.V, a.Ht, a.Wt = 2, 10, 8, 4
+    assert L.mm_attribute_loss_query_workspace(ctypes.byref(a)) % 256 == 0
+    assert L.mm_attribute_loss_forward(ctypes.byref(a), None) == -1
+    t = N.MMTexFlowDesc()
+    assert L.mm_texture_flow_forward(ctypes.byref(t), None) == -2
+    t.B, t.C, t.H, t.W, t.Ho, t.Wo = 1, 3, 8, 8, 8, 8
+    assert L.mm_texture_flow_forward(ctypes.byref(t), None) == -1
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.sample_texture(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))

@@ -294,7 +294,9 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 //    issued together (these loops are latency-bound: a dependent HBM/L2 load per step).
 // ---------------------------------------------------------------------------------------------------------------------
 #define MM_TS MM_UV_TILE
-#define MM_SWEEP 8              // pixels per lane per trip: 128-pixel boxes (nearly every face) finish in one trip
+#define MM_SWEEP 16             // pixels per lane per trip
+#define MM_FL 8                 // lanes per face: a trip covers MM_FL * MM_SWEEP = 64 pixels of each of the wave's faces
+#define MM_FPW (64 / MM_FL)     // faces per wave
 
 __device__ inline float group16_sum(float v) {
 #pragma unroll
@@ -337,7 +339,7 @@ struct __attribute__((aligned(16))) FaceSlot {
 };
 
 struct __attribute__((aligned(16))) SweepStage {
-    FaceSlot slot[4];
+    FaceSlot slot[MM_FPW];
     unsigned short items[MM_SWEEP * 64];   // (sweep slot << 6) | lane
 };
 
@@ -363,9 +365,9 @@ __device__ inline void wave_sync_lds() {
 // its position in the box walk)
 __device__ inline void item_pixel(const SweepStage* st, unsigned it, int base, int& g, int& px, int& py) {
     const int l = it & 63, i = it >> 6;
-    g = l >> 4;
+    g = l / MM_FL;
     const FaceSlot& fs = st->slot[g];
-    box_pixel(base + i * 16 + (l & 15), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
+    box_pixel(base + i * MM_FL + (l % MM_FL), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
 }
 
 __device__ inline void tex_accumulate(const BwdArgs& a, float (*s_acc)[MM_TS * MM_TS], const TexRecord& rc, int tx0, int ty0) {
@@ -425,9 +427,9 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, float (
 //     ballot-compacted per wave (four faces) and finished by all 64 lanes into per-face LDS accumulators; one plain store
 //     per face at the end.
 __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage* s_stage) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4, sl = lane & 15;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / MM_FL, sl = lane % MM_FL;
     SweepStage* st = &s_stage[wave];
-    const long long gid = (long long)block * 16 + (threadIdx.x >> 4);
+    const long long gid = (long long)block * (4 * MM_FPW) + threadIdx.x / MM_FL;
     const bool live = gid < (long long)a.B * a.F;
     // group g -> image g % B, face rank g / B: the four groups of a wave sweep faces of the same rank (similar box sizes)
     // in different images, and the ranks with the biggest boxes start first
@@ -442,16 +444,17 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
         fs.p0 = fb.p0; fs.p1 = fb.p1; fs.box[0] = fb.xmin; fs.box[1] = fb.ymin; fs.box[2] = fb.xmax; fs.box[3] = fb.ymax;
         fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f;
     }
-    if (sl < 9) st->slot[grp].acc[sl] = 0.f;
+    for (int k = sl; k < 9; k += MM_FL) st->slot[grp].acc[k] = 0.f;
     int nmax = fb.npx;
-    nmax = max(nmax, __shfl_xor(nmax, 16, 64)); nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+#pragma unroll
+    for (int o = MM_FL; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
     wave_sync_lds();
 
-    for (int base = 0; base < nmax; base += 16 * MM_SWEEP) {
+    for (int base = 0; base < nmax; base += MM_FL * MM_SWEEP) {
         bool own[MM_SWEEP], opn[MM_SWEEP];
 #pragma unroll
         for (int i = 0; i < MM_SWEEP; ++i) {
-            const int idx = base + i * 16 + sl;
+            const int idx = base + i * MM_FL + sl;
             int px, py;
             box_pixel(idx, fb.px0, fb.py0, fb.bw, fb.inv_bw, px, py);
             const int fi = idx < fb.npx ? a.face_idx[(size_t)b * hw + (size_t)py * a.W + px] : -2;
@@ -468,7 +471,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             int g, px, py;
             item_pixel(st, st->items[j], base, g, px, py);
             FaceSlot& fs = st->slot[g];
-            const int bb = (int)(((long long)block * 16 + wave * 4 + g) % a.B);
+            const int bb = (int)(((long long)block * (4 * MM_FPW) + wave * MM_FPW + g) % a.B);
             const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
             // issue every load of the item first; which ones matter depends on the pixel's owner
             const int fi = a.face_idx[pix];
@@ -520,9 +523,11 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
         }
         wave_sync_lds();
     }
-    if (live && sl < 9) {
-        const float v = st->slot[grp].acc[sl];
-        if (sl < 6) a.dfxy[o * 6 + sl] = v; else a.dfn[o * 3 + (sl - 6)] = v;
+    if (live) {
+        for (int k = sl; k < 9; k += MM_FL) {
+            const float v = st->slot[grp].acc[k];
+            if (k < 6) a.dfxy[o * 6 + k] = v; else a.dfn[o * 3 + (k - 6)] = v;
+        }
     }
 }
 
@@ -569,7 +574,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     {
         ProfScope p(d->prof_events, MM_PROF_GATHER_BWD, s);
         const int ntex = a.ntx * a.nty * d->B;
-        const unsigned nface = (unsigned)(((long long)d->B * d->F + 15) / 16);
+        const unsigned nface = (unsigned)(((long long)d->B * d->F + 4 * MM_FPW - 1) / (4 * MM_FPW));
         hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex);
     }
     return launch_ok("raster_bwd");

@@ -32,8 +32,7 @@ static int check_render(const MMRenderDesc* d, bool backward) {
         !d->distances || !d->biases || !d->rgba || !d->face_idx || !d->face_normals)
         return MM_ERR_NULL_POINTER;
     if (d->no_mask && !d->bg) return MM_ERR_NULL_POINTER;
-    if (backward && (!d->vc_offsets || !d->vc_items || !d->uvt_offsets || !d->uvt_faces)) return MM_ERR_NULL_POINTER;
-    if (backward && d->uvt_size != MM_UV_TILE) return MM_ERR_UNSUPPORTED;
+    if (backward && (!d->vc_offsets || !d->vc_items)) return MM_ERR_NULL_POINTER;
     if (!d->workspace || d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_WORKSPACE;
     return MM_OK;
 }

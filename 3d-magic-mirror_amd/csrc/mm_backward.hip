@@ -8,11 +8,11 @@
 //   1. pixel_bwd   pixel-major, one lane per pixel: re-shades the pixel, writes dL/dbg, reduces dL/dlights per
 //                  workgroup (plain stores of partials), and leaves for every covered pixel the nine numbers the gather
 //                  needs: d/d(texture sample rgb), d/d(mask), d/d(u,v), d/d(normal).
-//   2a. texture_gather  one workgroup per (image, 32x32-texel texture tile), the tile's accumulators in LDS.  The faces
-//                  that can sample the tile are a STATIC list (mm_build_uv_tiles).  16 lanes sweep each face's screen box;
-//                  the pixels it owns add their bilinear footprint to the LDS tile (LDS float adds).  The tile is then
-//                  written once with plain stores: no zero-fill pass over grad_textures.
-//   2b. face_gather  16 lanes per (image, face) sweep the face's inflated screen box: pixels it owns give the K2
+//   2a. texture_gather  one workgroup per (image, 32x32-texel texture tile), the tile's accumulators in LDS: it streams the
+//                  RECORD list the pixel pass appended for the tile (one record per covered pixel and tile under its bilinear
+//                  footprint; slots handed out by one returning atomic per wave and tile), adds each footprint to the LDS
+//                  tile (LDS float adds) and writes the tile once with plain stores: no zero-fill pass over grad_textures.
+//   2b. face_gather  8 lanes per (image, face) sweep the face's inflated screen box: pixels it owns give the K2
 //                  barycentric gradient, uncovered pixels that hold the face among their first knum soft-mask faces give
 //                  K4.  dL/d(face xy) and dL/d(face normal) are written once per face with plain stores.
 #include "mm_device.h"
@@ -41,7 +41,6 @@ struct BwdArgs {
     const float* gt; const float4* lpart; const float* rgba; const float* grad_loss; float* loss; float image_weight;
     float* ltot;                                                 // (B,2) per image {sum|pi-gi|, IoU}
     // gather
-    const int32_t* uvt_offsets; const int32_t* uvt_faces;
     const int32_t* face_order;
     int ntx, nty;
     float* grad_textures;
@@ -290,19 +289,13 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 2. gathers.  Both sweep a face's screen box with 16 lanes, four pixels per lane per trip with the loads of a trip
+// 2. gathers.  The face gather sweeps a face's screen box with MM_FL lanes, MM_SWEEP pixels per lane per trip with the loads of a trip
 //    issued together (these loops are latency-bound: a dependent HBM/L2 load per step).
 // ---------------------------------------------------------------------------------------------------------------------
 #define MM_TS MM_UV_TILE
 #define MM_SWEEP 16             // pixels per lane per trip
 #define MM_FL 8                 // lanes per face: a trip covers MM_FL * MM_SWEEP = 64 pixels of each of the wave's faces
 #define MM_FPW (64 / MM_FL)     // faces per wave
-
-__device__ inline float group16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
-    return v;
-}
 
 struct FaceBox { float4 p0, p1; float xmin, ymin, xmax, ymax; int px0, py0, bw, npx; float inv_bw; };
 
@@ -422,7 +415,7 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, float (
     }
 }
 
-// 2b. per-face gradients: 16 lanes per (image, face) sweep the face's inflated box; pixels it owns give the K2 barycentric
+// 2b. per-face gradients: MM_FL lanes per (image, face) sweep the face's inflated box; pixels it owns give the K2 barycentric
 //     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The two kinds of hits are
 //     ballot-compacted per wave (four faces) and finished by all 64 lanes into per-face LDS accumulators; one plain store
 //     per face at the end.
@@ -431,7 +424,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     SweepStage* st = &s_stage[wave];
     const long long gid = (long long)block * (4 * MM_FPW) + threadIdx.x / MM_FL;
     const bool live = gid < (long long)a.B * a.F;
-    // group g -> image g % B, face rank g / B: the four groups of a wave sweep faces of the same rank (similar box sizes)
+    // group g -> image g % B, face rank g / B: the eight groups of a wave sweep faces of the same rank (similar box sizes)
     // in different images, and the ranks with the biggest boxes start first
     const int b = live ? (int)(gid % a.B) : 0, rk = live ? (int)(gid / a.B) : 0;
     const int f = a.face_order ? a.face_order[rk] : rk;
@@ -560,7 +553,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;
     a.gt = d->fused_gt; a.lpart = w.lpart; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
     a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
-    a.uvt_offsets = d->uvt_offsets; a.uvt_faces = d->uvt_faces; a.face_order = d->face_order;
+    a.face_order = d->face_order;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures; a.dfxy = w.dfxy; a.dfn = w.dfn;
     // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)

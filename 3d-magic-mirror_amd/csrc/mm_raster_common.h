@@ -174,15 +174,6 @@ __device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* s
         atomicMax(&st->key[l], depth_key(z0, __float_as_int(p2.z)));
 }
 
-// closest of the three edge segments: squared distance (multiplier units) and type = edge*3 + region
-__device__ inline float tri_dist2(float x0, float y0, const float4& p0, const float4& p1, int& ty) {
-    int r;
-    float d = seg_dist2(x0, y0, p0.x, p0.y, p0.z, p0.w, ty);
-    const float d1 = seg_dist2(x0, y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
-    const float d2 = seg_dist2(x0, y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
-    return d;
-}
-
 // The silhouette is held to 1e-4, not to the bit (only face_idx is), and its pair evaluations are most of the forward's
 // instructions: they use the hardware reciprocal / exp2 / log2 (about 1 ulp each) instead of the IEEE sequences.
 __device__ inline float seg_dist2_fast(float px, float py, float ux, float uy, float vx, float vy) {

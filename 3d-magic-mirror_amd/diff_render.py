@@ -223,8 +223,6 @@ class DiffRender(object):
         d.vertices, d.textures, d.lights, d.bg = N.ptr(vertices), N.ptr(textures), N.ptr(lights), N.ptr(bg)
         d.azimuths, d.elevations, d.distances, d.biases = N.ptr(azimuths), N.ptr(elevations), N.ptr(distances), N.ptr(biases)
         d.rgba, d.face_idx, d.face_normals, d.imnormal = N.ptr(rgba), N.ptr(face_idx), N.ptr(fn), N.ptr(imn)
-        uo, uf = self._uv_tiles(vertices.device, d.Ht, d.Wt)
-        d.uvt_offsets, d.uvt_faces, d.uvt_size = N.ptr(uo), N.ptr(uf), N.UV_TILE
         d.face_order = N.ptr(st["face_order"])
         d.options = self.options
         return d

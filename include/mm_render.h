@@ -61,9 +61,9 @@ typedef struct MMRenderDesc {
     const float* face_uvs;      /* (F,3,2) raw OBJ uv of every corner (networks.py:196-202) */
     const int32_t* vc_offsets;  /* (V+1) CSR: vertex -> incident corners ...        (backward only; may be NULL forward) */
     const int32_t* vc_items;    /* (3F)  ... each item = face*3 + corner, ascending (backward only) */
-    const int32_t* uvt_offsets; /* (ntiles+1) CSR: texture tile -> faces that may sample it   (backward only; mm_build_uv_tiles) */
-    const int32_t* uvt_faces;   /* face id, bit 31 set on the face's primary tile              (backward only) */
-    int32_t uvt_size;           /* texture tile edge in texels (MM_UV_TILE)                    (backward only) */
+    const int32_t* uvt_offsets; /* reserved, may be NULL: static texture tile -> faces lists (mm_build_uv_tiles).  The texture */
+    const int32_t* uvt_faces;   /*   gradient is gathered from per-tile RECORD lists written by the pixel backward instead, so   */
+    int32_t uvt_size;           /*   these are no longer read; kept so that the struct layout stays stable                      */
     const int32_t* face_order;  /* (F) optional: faces sorted by decreasing template area; only the ORDER in which the
                                  *     backward visits faces depends on it (big screen boxes first); NULL = index order */
     /* per-sample attributes (device), the 'attributes' dict of networks.py:259-270 */

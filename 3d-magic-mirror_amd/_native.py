@@ -143,6 +143,15 @@ def check(status, what):
                                                             " [" + detail + "]" if detail else ""))
 
 
+def as_f32(t, dev):
+    """``t`` detached as a dense fp32 tensor on ``dev``; the common case (already so) costs one attribute test each."""
+    if t is None:
+        return None
+    if t.dtype is torch.float32 and t.device == dev and t.is_contiguous():
+        return t.detach()
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
 def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 

@@ -24,7 +24,7 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, dr, no_mask, want_imnormal, vertices, textures, lights, bg, azimuths, elevations, distances, biases):
         N.require_device(vertices, textures, lights, bg, azimuths, elevations, distances, biases)
         dev = azimuths.device
-        f32 = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        f32 = lambda t: N.as_f32(t, dev)
         vertices, textures, lights, bg = f32(vertices), f32(textures), f32(lights), f32(bg)
         azimuths, elevations, distances, biases = f32(azimuths).reshape(-1), f32(elevations).reshape(-1), f32(distances).reshape(-1), f32(biases)
         B = azimuths.shape[0]

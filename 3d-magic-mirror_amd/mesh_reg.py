@@ -70,7 +70,7 @@ class MeshRegFn(torch.autograd.Function):
         given = [t for t in (vertices, delta, fn) if t is not None]
         N.require_device(*given)
         dev = given[0].device
-        f32 = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        f32 = lambda t: N.as_f32(t, dev)
         vertices, delta, fn = f32(vertices), f32(delta), f32(fn)
         B = given[0].shape[0]
         for t, n in ((vertices, dr.num_vertices), (delta, dr.num_vertices), (fn, dr.num_faces)):

@@ -38,6 +38,9 @@ def _close(got, ref, tol=1e-4):
     ("sphere", 2, 50, 1, True, 4),          # ragged: not a multiple of the 16x16 block
     ("smpl_uv", 2, 96, 1, True, 5),         # 13 776 faces: 216 mask words (multi-group walk), 16-px screen bins
     ("sphere2", 2, 40, 1, False, 6),        # 5 120 faces, white background
+    ("smpl_uv_642", 48, 128, 1, True, 0),   # BASELINE config 2 at FULL size: the bench's batch, pixel for pixel
+    ("smpl_uv_642", 48, 64, 2, True, 7),    # BASELINE config 4 (Market 128x64) at full size
+    ("ellipsoid", 6, 256, 1, True, 8),      # BASELINE config 3 resolution (256x256, 16-px bins, 1024 tiles per image)
 ])
 def test_render_loss_backward_matches_oracle(pkg, oracle, name, B, S, ratio, no_mask, seed):
     dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, ratio=ratio, seed=seed, no_mask=no_mask)
@@ -217,7 +220,8 @@ def test_error_behaviour(pkg):
         dr.render(**{k: v for k, v in datt.items() if k != "lights"})
 
 
-@pytest.mark.parametrize("name,B,S,seed", [("sphere", 4, 64, 0), ("smpl_uv_642", 3, 50, 7)])
+@pytest.mark.parametrize("name,B,S,seed", [("sphere", 4, 64, 0), ("smpl_uv_642", 3, 50, 7),
+                                           ("smpl_uv_642", 48, 128, 0)])        # the last one IS the bench step
 def test_fused_step_matches_oracle_and_unfused(pkg, oracle, name, B, S, seed):
     """RenderLossStep: recon_data folded into the render kernels (MMRenderDesc.fused_*) vs the four-call sequence vs oracle."""
     import importlib

@@ -87,12 +87,24 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
             st->ids[pos++] = (unsigned short)(t.lane * 64 + bit);
         }
         wave_lds_sync();
+        // batches of 64; the face records of batch k+1 are requested before batch k is evaluated (a tile with hundreds of
+        // candidates would otherwise pay a dependent trip to memory per batch)
+        float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+        int nf = 0;
+        auto fetch = [&](int k0) {
+            if (k0 + t.lane < total) {
+                nf = wbase * 64 + st->ids[k0 + t.lane];
+                n0 = geo[(size_t)nf * 3 + 0]; n1 = geo[(size_t)nf * 3 + 1]; n2 = geo[(size_t)nf * 3 + 2];
+            }
+        };
+        fetch(0);
         for (int k0 = 0; k0 < total; k0 += 64) {
             const int n = min(64, total - k0);
+            const float4 g0 = n0, g1 = n1, g2 = n2;
+            const int f = nf;
+            if (k0 + 64 < total) fetch(k0 + 64);
             uint64_t mc = 0;                                     // candidate-major: lane j = candidate j, bit p = pixel p
             if (t.lane < n) {
-                const int f = wbase * 64 + st->ids[k0 + t.lane];
-                const float4 g0 = geo[(size_t)f * 3 + 0], g1 = geo[(size_t)f * 3 + 1], g2 = geo[(size_t)f * 3 + 2];
                 st->p0[t.lane] = g0; st->p1[t.lane] = g1;
                 st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), __int_as_float(f));   // cz, nz, rank, face id
                 const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);

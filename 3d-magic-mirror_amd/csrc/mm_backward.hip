@@ -527,8 +527,11 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
 // One launch for both gathers: they only depend on the pixel pass, and each is latency-bound with a long tail, so their
 // workgroups are interleaved in a single grid (texture tiles first: they are the heavier ones).
 __global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
-    __shared__ float s_acc[3][MM_TS * MM_TS];
-    __shared__ SweepStage s_stage[4];
+    // the two kinds of workgroup never coexist in one workgroup: their LDS is overlaid (more workgroups per CU)
+    constexpr size_t kLds = sizeof(float) * 3 * MM_TS * MM_TS > sizeof(SweepStage) * 4 ? sizeof(float) * 3 * MM_TS * MM_TS : sizeof(SweepStage) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLds];
+    float (*s_acc)[MM_TS * MM_TS] = reinterpret_cast<float (*)[MM_TS * MM_TS]>(s_raw);
+    SweepStage* s_stage = reinterpret_cast<SweepStage*>(s_raw);
     if (a.gt && a.loss && blockIdx.x == 0 && threadIdx.x < 64) {  // fused recon_data value: fixed-order sum over images
         float l1 = 0.f, iou = 0.f;
         for (int bb = threadIdx.x; bb < a.B; bb += 64) { l1 += a.ltot[bb * 2]; iou += a.ltot[bb * 2 + 1]; }

@@ -422,11 +422,13 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, float (
 __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage* s_stage) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / MM_FL, sl = lane % MM_FL;
     SweepStage* st = &s_stage[wave];
-    const long long gid = (long long)block * (4 * MM_FPW) + threadIdx.x / MM_FL;
-    const bool live = gid < (long long)a.B * a.F;
-    // group g -> image g % B, face rank g / B: the eight groups of a wave sweep faces of the same rank (similar box sizes)
-    // in different images, and the ranks with the biggest boxes start first
-    const int b = live ? (int)(gid % a.B) : 0, rk = live ? (int)(gid / a.B) : 0;
+    // a wave sweeps MM_FPW faces of consecutive area rank of ONE image (same camera: similar box sizes, so its groups finish
+    // together); waves walk the images round-robin and the ranks with the biggest boxes start first
+    const long long wid = (long long)block * 4 + wave;            // wave index over (rank octet, image)
+    const int b = (int)(wid % a.B);
+    const int rk_raw = (int)(wid / a.B) * MM_FPW + grp;
+    const bool live = rk_raw < a.F;
+    const int rk = live ? rk_raw : 0;
     const int f = a.face_order ? a.face_order[rk] : rk;
     const size_t o = (size_t)b * a.F + f, hw = (size_t)a.H * a.W;
     const float s2 = a.mult * a.mult;
@@ -464,7 +466,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             int g, px, py;
             item_pixel(st, st->items[j], base, g, px, py);
             FaceSlot& fs = st->slot[g];
-            const int bb = (int)(((long long)block * (4 * MM_FPW) + wave * MM_FPW + g) % a.B);
+            const int bb = b;                                    // every group of the wave sweeps the same image
             const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
             // issue every load of the item first; which ones matter depends on the pixel's owner
             const int fi = a.face_idx[pix];
@@ -570,7 +572,8 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     {
         ProfScope p(d->prof_events, MM_PROF_GATHER_BWD, s);
         const int ntex = a.ntx * a.nty * d->B;
-        const unsigned nface = (unsigned)(((long long)d->B * d->F + 4 * MM_FPW - 1) / (4 * MM_FPW));
+        const long long nwaves = (long long)d->B * ((d->F + MM_FPW - 1) / MM_FPW);   // (rank octet, image)
+        const unsigned nface = (unsigned)((nwaves + 3) / 4);
         hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex);
     }
     return launch_ok("raster_bwd");

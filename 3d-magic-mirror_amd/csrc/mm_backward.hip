@@ -17,6 +17,9 @@
 //                  K4.  dL/d(face xy) and dL/d(face normal) are written once per face with plain stores.
 #include "mm_device.h"
 
+MM_TIMELINE_STORAGE(pixel_bwd)
+MM_TIMELINE_STORAGE(gather_bwd)
+
 namespace mm {
 
 struct BwdArgs {
@@ -53,6 +56,7 @@ struct BwdArgs {
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool kNoMask>
 __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
+    MM_TIMELINE_BEGIN();
     __shared__ float s_dl[MM_BLOCK_WAVES][9];
     int b, blk;
     map_block(blockIdx.x, a.B, a.blocks_per_image, b, blk);
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     if (threadIdx.x < 9)
         a.dl_part[((size_t)b * a.blocks_per_image + blk) * 12 + threadIdx.x] =
             ((s_dl[0][threadIdx.x] + s_dl[1][threadIdx.x]) + s_dl[2][threadIdx.x]) + s_dl[3][threadIdx.x];
+    MM_TIMELINE_END(pixel_bwd);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -529,6 +534,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
 // One launch for both gathers: they only depend on the pixel pass, and each is latency-bound with a long tail, so their
 // workgroups are interleaved in a single grid (texture tiles first: they are the heavier ones).
 __global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
+    MM_TIMELINE_BEGIN();
     // the two kinds of workgroup never coexist in one workgroup: their LDS is overlaid (more workgroups per CU)
     constexpr size_t kLds = sizeof(float) * 3 * MM_TS * MM_TS > sizeof(SweepStage) * 4 ? sizeof(float) * 3 * MM_TS * MM_TS : sizeof(SweepStage) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLds];
@@ -543,6 +549,7 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
     }
     if ((int)blockIdx.x < ntex) texture_gather_block(a, blockIdx.x, s_acc);
     else face_gather_block(a, blockIdx.x - ntex, s_stage);
+    MM_TIMELINE_END(gather_bwd);
 }
 
 int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {

@@ -286,6 +286,25 @@ struct ProfScope {
     ~ProfScope() { if (ev) (void)hipEventRecord((hipEvent_t)ev[2 * slot + 1], s); }
 };
 
+// -DMM_TIMELINE (debug builds, profiles/tools/timeline.py): wall-clock begin / end of every workgroup of a kernel, 100 MHz ticks
+// comparable across CUs.  MM_TIMELINE_STORAGE(name) in the kernel's translation unit defines the buffer and its C getter
+// mm_debug_timeline_<name>(out[MM_TIMELINE_MAX][2]).  Everything compiles to nothing otherwise.
+#ifdef MM_TIMELINE
+#define MM_TIMELINE_MAX 16384
+#define MM_TIMELINE_STORAGE(name)                                                                                         \
+    namespace mm { __device__ unsigned long long g_tl_##name[MM_TIMELINE_MAX][2]; }                                          \
+    extern "C" int mm_debug_timeline_##name(unsigned long long* out) {                                                       \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm::g_tl_##name), sizeof(unsigned long long) * MM_TIMELINE_MAX * 2) == hipSuccess ? 0 : -1; \
+    }
+#define MM_TIMELINE_BEGIN() const unsigned long long tl_begin_ = wall_clock64()
+#define MM_TIMELINE_END(name) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < MM_TIMELINE_MAX) {                 \
+    mm::g_tl_##name[blockIdx.x][0] = tl_begin_; mm::g_tl_##name[blockIdx.x][1] = wall_clock64(); } } while (0)
+#else
+#define MM_TIMELINE_STORAGE(name)
+#define MM_TIMELINE_BEGIN() do { } while (0)
+#define MM_TIMELINE_END(name) do { } while (0)
+#endif
+
 // launch check shared by every launcher: the HIP error (if any) is kept per host thread for mm_last_error_detail()
 struct LaunchError { hipError_t code; const char* what; };
 inline LaunchError& last_launch_error() { static thread_local LaunchError e = {hipSuccess, ""}; return e; }

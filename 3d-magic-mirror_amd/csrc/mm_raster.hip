@@ -22,6 +22,8 @@
 //     critical path is pairs/64 evaluations, not its busiest pixel, and results do not depend on evaluation order.
 #include "mm_raster_common.h"
 
+MM_TIMELINE_STORAGE(raster_fwd)
+
 namespace mm {
 
 // per-wave LDS staging: 64 candidates as three float4 rows + the id list of one mask group
@@ -148,6 +150,7 @@ __device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, Wave
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool kNoMask>
 __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
+    MM_TIMELINE_BEGIN();
     __shared__ WaveStage s_stage;
     const TileCtx t = make_tile(a);
     WaveStage* st = &s_stage;
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
     }
     const SoftState ss = {qnz, zeros, lastf};
     shade_store<kNoMask>(a, t, h, n0, n1, n2, ss);
+    MM_TIMELINE_END(raster_fwd);
 }
 
 // Orders the tile slots (16x16 block * 4 + quadrant) of every image by their soft-mask candidate count, descending: a counting

@@ -128,8 +128,10 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
 __device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h) {
     st->key[t.lane] = 0ull;
     wave_lds_sync();
-    for_each_batch<true, false>(a, t, st, [&](int n, uint64_t mc) {
-        pair_parallel(t, st, mc, [&](int j, int l, bool live) { hard_pair(a, t, st, j, l, live); });   // candidate j, pixel l
+    // pixel-major like the silhouette pass: a pixel lies in few front-face boxes (a face's box can hold the whole tile), so
+    // the per-lane loop that lays out the pairs is short
+    for_each_batch<true, true>(a, t, st, [&](int n, uint64_t pm) {
+        pair_parallel(t, st, pm, [&](int l, int j, bool live) { hard_pair(a, t, st, j, l, live); });   // pixel l, candidate j
         return true;
     });
     wave_lds_sync();

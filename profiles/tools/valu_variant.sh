@@ -2,7 +2,7 @@
 # SQ_INSTS_VALU / SQ_WAVES of every kernel for an alternative build (MM_DBG_LIB=...), forward only matters for the raster variants
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
-  rm -rf /tmp/pv; MM_DBG_LIB=/root/repo/3d-magic-mirror_amd/lib/libmm_var$v.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d /tmp/pv -o p -- python /root/repo/profiles/tools/kernel_times.py > /tmp/pv.log 2>&1
+  rm -rf /tmp/pv; MM_DBG_LIB=/root/repo/3d-magic-mirror_amd/lib/libmm_var$v.so timeout 90 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d /tmp/pv -o p -- python /root/repo/profiles/tools/kernel_times.py > /tmp/pv.log 2>&1
   python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -49,8 +49,7 @@ struct Workspace {
     float* T;              // (B,12)     camera transform [R;t], row-major (4,3)
     float4* geo;           // (B,F,3)    {ax,ay,bx,by} {cx,cy,az,bz} {cz, unit normal z, box origin, box extent}; xy in multiplier
                            //            units; box = inflated pixel box px0 | py0 << 16, w | h << 16 (as int bits)
-    uint64_t* binmask;     // (B,nbins,ceil(F/64)) bit f: the box of face f, inflated by the soft-mask margin, may touch the bin
-    uint64_t* binmask_hard;// (B,nbins,ceil(F/64)) bit f: face f is front facing and its box may touch the bin
+    uint64_t* binmask;     // (B,nbins,ceil(F/64)) bit f: the pixel box of face f, inflated by the soft-mask margin, touches the bin
     float* softq;          // (B,H,W)    soft-mask product state of uncovered pixels: +prod(1-p) if no factor is 0,
                            //            -prod(non-zero factors) if exactly one factor is 0, 0 if two or more are
     float* dfxy;           // (B,F,3,2)  backward accumulator: dL/d face_vertices_image (unscaled NDC)
@@ -89,7 +88,6 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.T = (float*)(p + o);          o += align256((size_t)B * 12 * sizeof(float));
     w.geo = (float4*)(p + o);       o += align256((size_t)B * F * 3 * sizeof(float4));
     w.binmask = (uint64_t*)(p + o); o += align256(w.binmask_bytes);
-    w.binmask_hard = (uint64_t*)(p + o); o += align256(w.binmask_bytes);
     w.softq = (float*)(p + o);      o += align256((size_t)B * H * W * sizeof(float));
     w.dfxy = (float*)(p + o);       o += align256((size_t)B * F * 6 * sizeof(float));
     w.dfn = (float*)(p + o);        o += align256((size_t)B * F * 3 * sizeof(float));
@@ -320,6 +318,27 @@ inline void clear_stale_error() { (void)hipGetLastError(); }
 // number of set bits of a ballot below this lane: two v_mbcnt instructions (a 64-bit shift/and/popcount sequence costs ~10x)
 __device__ inline int ballot_rank(uint64_t bal) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+}
+
+// 64x64 bit-matrix transpose across the wave: lane i holds row i on entry and column i on exit (6 butterfly stages).
+template <int S>
+__device__ inline uint64_t transpose_stage(uint64_t x, int lane) {
+    // m: bit positions whose index has bit S clear
+    constexpr uint64_t m = S == 32 ? 0x00000000FFFFFFFFull : S == 16 ? 0x0000FFFF0000FFFFull : S == 8 ? 0x00FF00FF00FF00FFull
+                         : S == 4 ? 0x0F0F0F0F0F0F0F0Full : S == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+    const unsigned lo = __shfl_xor((unsigned)x, S, 64), hi = __shfl_xor((unsigned)(x >> 32), S, 64);
+    const uint64_t y = ((uint64_t)hi << 32) | lo;
+    return (lane & S) ? (((y >> S) & m) | (x & ~m)) : ((x & m) | ((y & m) << S));
+}
+
+__device__ inline uint64_t wave_transpose64(uint64_t x, int lane) {
+    x = transpose_stage<32>(x, lane);
+    x = transpose_stage<16>(x, lane);
+    x = transpose_stage<8>(x, lane);
+    x = transpose_stage<4>(x, lane);
+    x = transpose_stage<2>(x, lane);
+    x = transpose_stage<1>(x, lane);
+    return x;
 }
 
 __device__ inline float wave_sum(float v) {

@@ -8,14 +8,14 @@
 // and their backward kernels (K2, K4, grid_sampler backward, SH backward).
 //
 // Design (not kaolin's pixel-major brute force over all faces):
-//   * a wave owns an 8x8 pixel tile, one lane per pixel; a 256-thread workgroup is 2x2 such tiles (16x16 px).
-//   * the bin kernel left, per screen bin, bit-per-face masks of the faces whose box may touch it (front faces for
-//     colour, inflated boxes of all faces for the silhouette).  The wave loads its bin's mask words coalesced, turns the
-//     set bits into an ORDERED candidate list with popcount + wave prefix sum (face order = bit order, which the soft
-//     mask's "first knum faces" rule needs) and stages 64 candidates at a time in LDS (struct-of-arrays float4 rows).
-//   * per batch, lane j tests candidate j's box against the tile's 8 pixel columns and 8 rows (separable closed-box
-//     test, the same float comparisons as a per-pixel test) -> a 64-bit pixel mask per candidate; a 6-stage wave
-//     butterfly transposes that 64x64 bit matrix when the per-pixel view is needed.
+//   * a wave owns an 8x8 pixel tile, one lane per pixel (one wave per workgroup).
+//   * the bin kernel left, per screen bin, a bit-per-face mask of the faces whose pixel box, inflated by the silhouette
+//     margin, touches it.  The wave loads its bin's mask words coalesced, turns the set bits into an ORDERED candidate
+//     list with popcount + wave prefix sum (face order = bit order, which the soft mask's "first knum faces" rule needs)
+//     and stages 64 candidates at a time in LDS (struct-of-arrays float4 rows) -- ONE walk serves colour and silhouette.
+//   * per batch, lane j tests candidate j's box (front faces) and inflated box (all faces) against the tile's 8 pixel
+//     columns and 8 rows (separable closed-box test, the same float comparisons as a per-pixel test) -> two 64-bit pixel
+//     masks per candidate; a 6-stage wave butterfly transposes each 64x64 bit matrix to the per-pixel view.
 //   * the (pixel, candidate) pairs of the batch are then evaluated 64 at a time by whichever lane and combined with
 //     exact, commutative LDS atomics: 64-bit max of (orderable z, ~face id) for colour -- argmax over (z, -index) is
 //     exactly kaolin's "strict z > best in index order" -- and an integer sum of log2(1-p) for the silhouette.  A wave's
@@ -64,22 +64,20 @@ __device__ inline TileCtx make_tile(const RasterArgs& a) {
     // tiles never straddle bins (bin edge is 8, 16 or 32); a tile fully outside the image borrows the last bin
     const int binx = min(tx0 >> a.bin_shift, a.nbx - 1), biny = min(ty0 >> a.bin_shift, a.nby - 1);
     const size_t mrow = ((size_t)t.b * a.nbx * a.nby + (size_t)biny * a.nbx + binx) * a.words;
-    t.mask = a.binmask + mrow; t.mask_hard = a.binmask_hard + mrow;
+    t.mask = a.binmask + mrow;
     return t;
 }
 
 // Walk the bin's candidates in face order, 64 at a time.  For every batch the candidates are staged in st->p0/p1/p2[0..n)
-// and body(n, m) receives the hit masks of the batch -- kHard: front faces whose box contains the pixel; else: all faces whose
-// inflated box contains it -- either candidate-major (lane j = candidate j, bit p = pixel p) or, with kTranspose,
-// pixel-major (this lane's pixel, bit j = candidate j).  body returns false to stop (wave-uniform).
-template <bool kHard, bool kTranspose, class Body>
-__device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, Body&& body) {
+// and body(n, ph, ps) receives the batch's two hit matrices pixel-major (this lane's pixel, bit j = candidate j):
+//   ph  front faces whose box contains the pixel (colour);   ps  all faces whose inflated box contains it (silhouette;
+//   0 when want_soft() -- wave-uniform, asked once per batch -- says no pixel can take another silhouette face).
+template <class WantSoft, class Body>
+__device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, WantSoft&& want_soft, Body&& body) {
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
-    const uint64_t* mask = kHard ? t.mask_hard : t.mask;
-    const float pad = kHard ? 0.f : a.infl;
     for (int wbase = 0; wbase < a.words; wbase += MM_GROUP_WORDS) {
         uint64_t w = 0;
-        if (t.lane < MM_GROUP_WORDS && wbase + t.lane < a.words) w = mask[wbase + t.lane];
+        if (t.lane < MM_GROUP_WORDS && wbase + t.lane < a.words) w = t.mask[wbase + t.lane];
         int total;
         int pos = wave_prefix_excl(__popcll(w), t.lane, total);
         if (total == 0) continue;
@@ -105,37 +103,26 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
             const float4 g0 = n0, g1 = n1, g2 = n2;
             const int f = nf;
             if (k0 + 64 < total) fetch(k0 + 64);
-            uint64_t mc = 0;                                     // candidate-major: lane j = candidate j, bit p = pixel p
+            const bool soft = want_soft();
+            uint64_t mh = 0, ms = 0;                             // candidate-major: lane j = candidate j, bit p = pixel p
             if (t.lane < n) {
                 st->p0[t.lane] = g0; st->p1[t.lane] = g1;
                 st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), __int_as_float(f));   // cz, nz, rank, face id
                 const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
                 const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
-                if (!kHard || g2.y >= 0.f) mc = box_pixels(t, xmin - pad, ymin - pad, xmax + pad, ymax + pad);
+                if (g2.y >= 0.f) mh = box_pixels(t, xmin - 0.f, ymin - 0.f, xmax + 0.f, ymax + 0.f);
+                if (soft) ms = box_pixels(t, xmin - a.infl, ymin - a.infl, xmax + a.infl, ymax + a.infl);
             }
-            const uint64_t m = kTranspose ? wave_transpose64(mc, t.lane) : mc;
+            const uint64_t ph = __ballot(mh != 0) ? wave_transpose64(mh, t.lane) : 0ull;
+            const uint64_t ps = __ballot(ms != 0) ? wave_transpose64(ms, t.lane) : 0ull;
             wave_lds_sync();
-            const bool go = body(n, m);
+            body(n, ph, ps);
             wave_lds_sync();
-            if (!go) return;
         }
     }
 }
 
-// K1: nearest front face per pixel.  kaolin walks faces in index order and keeps strict z > best, i.e. the winner is
-// argmax over (z, -index); that maximum is taken here with a 64-bit LDS atomic max per (pixel, face) pair, which is
-// exact and order-free.  NaN and -inf depths never win, as in the reference.
-__device__ inline void raster_pixels(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h) {
-    st->key[t.lane] = 0ull;
-    wave_lds_sync();
-    // pixel-major like the silhouette pass: a pixel lies in few front-face boxes (a face's box can hold the whole tile), so
-    // the per-lane loop that lays out the pairs is short
-    for_each_batch<true, true>(a, t, st, [&](int n, uint64_t pm) {
-        pair_parallel(t, st, pm, [&](int l, int j, bool live) { hard_pair(a, t, st, j, l, live); });   // pixel l, candidate j
-        return true;
-    });
-    wave_lds_sync();
-    const unsigned long long k = st->key[t.lane];
+__device__ inline void winner(const RasterArgs& a, const TileCtx& t, unsigned long long k, Hit& h) {
     h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
     if (k != 0ull) {                                             // barycentrics of the winner (same expressions, same values)
         h.f = depth_key_rank(k);
@@ -158,27 +145,36 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
     WaveStage* st = &s_stage;
 
     Hit h;
-    if (t.empty) { h.f = -1; h.w0 = h.w1 = h.w2 = 0.f; }       // wave-uniform: more than half of all tiles
-    else raster_pixels(a, t, st, h);
-
-    // K3: soft silhouette for the lanes no front face covers.  prod(1-p) is order-free, so it is accumulated per pixel
-    // as an integer sum of log2(1-p) in 2^-32 fixed point (exact, commutative LDS adds) plus a count of exact zeros.
+    h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
     float qnz = 1.f;
     int zeros = 0, lastf = 0x7FFFFFFF;
-    const bool open = t.in_img && h.f < 0;
-    if (!t.empty && __ballot(open)) {
-        int cnt = 0;
-        const float s2 = a.sigmainv / (a.mult * a.mult);
-        st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0;
+    if (!t.empty) {                                              // wave-uniform: more than half of all tiles are empty
+        // ONE walk over the tile's candidates serves both rules.
+        // K1, nearest front face per pixel: kaolin walks faces in index order and keeps strict z > best, i.e. the winner is
+        // argmax over (z, -index); that maximum is taken with a 64-bit LDS atomic max per (pixel, face) pair, which is exact
+        // and order-free.  NaN and -inf depths never win, as in the reference.
+        // K3, soft silhouette of the pixels no front face covers: prod(1-p) over the pixel's first knum nearby faces is
+        // accumulated as an integer sum of log2(1-p) in 2^-32 fixed point (exact, commutative LDS adds) plus a count of exact
+        // zeros.  A pixel takes silhouette faces while no face of the batches SO FAR covers it: for a pixel that stays
+        // uncovered that is every batch, in order -- exactly the two-pass result; whatever a pixel gathered before a later
+        // batch covered it is never looked at.
+        st->key[t.lane] = 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0;
         wave_lds_sync();
-        for_each_batch<false, true>(a, t, st, [&](int n, uint64_t sm) {
-            sm = soft_take(sm, open, a.knum - cnt);              // pixel-major: the first knum hits of this pixel, in order
+        const float s2 = a.sigmainv / (a.mult * a.mult);
+        int cnt = 0;
+        bool open = t.in_img;
+        for_each_batch(a, t, st, [&]() { return __ballot(open && cnt < a.knum) != 0; }, [&](int n, uint64_t ph, uint64_t ps) {
+            if (__ballot(ph != 0)) {
+                pair_parallel(t, st, ph, [&](int l, int j, bool live) { hard_pair(a, t, st, j, l, live); });   // pixel l, candidate j
+                open = t.in_img && st->key[t.lane] == 0ull;
+            }
+            const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
             cnt += __popcll(sm);
             if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].w);   // knum-th face taken
-            pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, s2, l, j, live); });   // pixel l, candidate j
-            return __ballot(open && cnt < a.knum) != 0;          // every open lane already holds knum faces: stop
+            if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, s2, l, j, live); });
         });
         wave_lds_sync();
+        winner(a, t, st->key[t.lane], h);
         zeros = st->zeros[t.lane];
         qnz = exp2f((float)((double)st->logsum[t.lane] * (1.0 / 4294967296.0)));
     }
@@ -195,7 +191,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
 // Orders the tile slots (16x16 block * 4 + quadrant) of every image by their soft-mask candidate count, descending: a counting
 // sort in LDS (keys clipped to 1023; slots per image <= 1024), linear in the slots.  Only the launch ORDER of raster_fwd
 // depends on it -- slots with equal counts may come out in any order, no result does.  Bit 15 of an entry marks a tile that no
-// face can touch (count 0: the silhouette mask is a superset of the colour mask), which raster_fwd then never walks.
+// face can touch (count 0), which raster_fwd then never walks.
 __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short* order) {
     __shared__ int s_key[1024];
     __shared__ int s_start[1024];          // histogram, then the first output position of every key
@@ -245,7 +241,7 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.blocks_per_image = w.blocks_per_image;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
-    a.geo = w.geo; a.binmask = w.binmask; a.binmask_hard = w.binmask_hard; a.softq = w.softq; a.lastf = w.lastf; a.gt = d->fused_gt; a.lpart = w.lpart;
+    a.geo = w.geo; a.binmask = w.binmask; a.softq = w.softq; a.lastf = w.lastf; a.gt = d->fused_gt; a.lpart = w.lpart;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     a.V = d->V; a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2];

@@ -14,8 +14,7 @@ struct RasterArgs {
     int bin_shift, nbx, nby, words;
     float mult, eps, sigmainv, infl;        // infl = boxlen * multiplier
     const float4* geo;
-    const uint64_t* binmask;                // soft candidates (inflated boxes, all faces)
-    const uint64_t* binmask_hard;           // colour candidates (front faces)
+    const uint64_t* binmask;                // candidates per bin: faces whose inflated pixel box touches it
     const float* face_uvs;
     const float* fn;                        // (B,F,3) unit normals
     const float* textures;
@@ -45,8 +44,7 @@ struct TileCtx {
     bool empty;                             // no face can touch the tile (known from the order kernel): nothing to walk
     float x0, y0;
     float xs[MM_TILE], ys[MM_TILE];         // pixel-centre columns / rows of the tile (same in every lane)
-    const uint64_t* mask;                   // streamed: this wave's bin row (soft candidates): `words` 64-bit words
-    const uint64_t* mask_hard;              // streamed: same bin, colour candidates
+    const uint64_t* mask;                   // streamed: this wave's bin row of candidate bits: `words` 64-bit words
 };
 
 __device__ inline void tile_pixels(const RasterArgs& a, TileCtx& t) {
@@ -78,27 +76,6 @@ __device__ inline void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// 64x64 bit-matrix transpose across the wave: lane i holds row i on entry and column i on exit (6 butterfly stages).
-template <int S>
-__device__ inline uint64_t transpose_stage(uint64_t x, int lane) {
-    // m: bit positions whose index has bit S clear
-    constexpr uint64_t m = S == 32 ? 0x00000000FFFFFFFFull : S == 16 ? 0x0000FFFF0000FFFFull : S == 8 ? 0x00FF00FF00FF00FFull
-                         : S == 4 ? 0x0F0F0F0F0F0F0F0Full : S == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
-    const unsigned lo = __shfl_xor((unsigned)x, S, 64), hi = __shfl_xor((unsigned)(x >> 32), S, 64);
-    const uint64_t y = ((uint64_t)hi << 32) | lo;
-    return (lane & S) ? (((y >> S) & m) | (x & ~m)) : ((x & m) | ((y & m) << S));
-}
-
-__device__ inline uint64_t wave_transpose64(uint64_t x, int lane) {
-    x = transpose_stage<32>(x, lane);
-    x = transpose_stage<16>(x, lane);
-    x = transpose_stage<8>(x, lane);
-    x = transpose_stage<4>(x, lane);
-    x = transpose_stage<2>(x, lane);
-    x = transpose_stage<1>(x, lane);
-    return x;
 }
 
 // box-vs-tile for ONE candidate (this lane's): bit (r*8+c) set iff pixel (row r, column c) of the tile passes the

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(MM_RES_WAVES * 64) void raster_fwd_resident_kernel(
         if (bx < a.blocks_x && by < blocks_y) {                  // else: beyond the image's last 16x16 block, nothing to write
             t.blk = by * a.blocks_x + bx;
             t.wave = ((t.ty0 / MM_TILE) & 1) * 2 + ((t.tx0 / MM_TILE) & 1);
-            t.mask = nullptr; t.mask_hard = nullptr;
+            t.mask = nullptr;
             t.empty = false;
             tile_pixels(a, t);
             render_tile<kNoMask>(a, t, st, L, nr, ti MM_PROF_PASS);

@@ -82,87 +82,54 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
 }
 
 // ---- screen binning ---------------------------------------------------------------------------------------------------
-// One wave per (image, mask word = 64 faces, one of `parts` slices of the image's REGIONS of 4x4 bins): every lane loads its
-// face once, then for each region of the slice tests the box against the region (wave-wide reject: most region/word pairs
-// are empty and only get their zeros stored) and, if some lane touches it, against the region's 4 bin columns and 4 bin
-// rows (closed-box test on the pixel-centre extent of each bin, computed with the same monotone formula as the pixel
-// centres, so it is exactly conservative); 16 ballots per kind turn the lanes' 4x4 coverage into the 16 bins' mask words.
-// Plain stores, every word written: no atomics and no zero-fill.
+// One wave per (image, mask word = 64 faces, one of `parts` slices of the image's BLOCKS of 8x8 bins): every lane takes the
+// pixel box of its face (inflated by the soft-mask margin, conservative: packed by the vertex stage) and turns it into bin
+// column / row ranges.  Per block the lane's coverage is a 64-bit row-major bit matrix (rows x columns outer product); one
+// wave transpose turns the 64 faces' coverage words into the 64 bins' mask words, stored plainly -- every word of every
+// bin is written (blocks no face touches skip the transpose): no atomics and no zero-fill.  The raster kernel re-tests
+// every (pixel, face) pair exactly, so a conservative mask changes no result.
 struct BinArgs {
-    int B, F, H, W, bin_shift, nbx, nby, words, parts;
-    float mult, infl;
+    int B, F, bin_shift, nbx, nby, words, parts;
     const float4* geo;
-    uint64_t* soft;
-    uint64_t* hard;
+    uint64_t* mask;
 };
 
 __global__ __launch_bounds__(256) void bin_kernel(BinArgs a) {
     const int lane = threadIdx.x & 63;
-    const int rx = (a.nbx + 3) >> 2, ry = (a.nby + 3) >> 2;
+    const int sbx = (a.nbx + 7) >> 3, sby = (a.nby + 7) >> 3;
     const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gw >= (long long)a.B * a.words * a.parts) return;
     const int part = (int)(gw % a.parts);
     const int bc = (int)(gw / a.parts);
     const int c = bc % a.words, b = bc / a.words;
     const int f = c * 64 + lane;
-    const bool on = f < a.F;
-    float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
-    bool front = false;
-    if (on) {
-        const float4* geo = a.geo + ((size_t)b * a.F + f) * 3;
-        const float4 g0 = geo[0], g1 = geo[1];
-        front = geo[2].y >= 0.f;                                  // colour only sees front faces (a8)
-        xmin = fminf(fminf(g0.x, g0.z), g1.x); ymin = fminf(fminf(g0.y, g0.w), g1.y);
-        xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x); ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
+    int c0 = 0, c1 = -1, r0 = 0, r1 = -1;                         // bin columns / rows the box touches (none)
+    if (f < a.F) {
+        const float4 g2 = a.geo[((size_t)b * a.F + f) * 3 + 2];
+        const unsigned org = __float_as_uint(g2.z), ext = __float_as_uint(g2.w);
+        const int bw = (int)(ext & 0xFFFFu), bh = (int)(ext >> 16);
+        if (bw > 0 && bh > 0) {
+            const int px0 = (int)(org & 0xFFFFu), py0 = (int)(org >> 16);
+            c0 = px0 >> a.bin_shift; c1 = (px0 + bw - 1) >> a.bin_shift;
+            r0 = py0 >> a.bin_shift; r1 = (py0 + bh - 1) >> a.bin_shift;
+        }
     }
-    const float sxmin = xmin - a.infl, sxmax = xmax + a.infl, symin = ymin - a.infl, symax = ymax + a.infl;
-    const int i4 = lane & 3, k4 = (lane >> 2) & 3;
-    for (int r = part; r < rx * ry; r += a.parts) {
-        const int bx0 = (r % rx) * 4, by0 = (r / rx) * 4;
-        // pixel-centre extent of the whole region
-        const float rxlo = pixel_x(bx0 << a.bin_shift, a.W, a.mult), rxhi = pixel_x(min(((bx0 + 4) << a.bin_shift) - 1, a.W - 1), a.W, a.mult);
-        const float ryhi = pixel_y(by0 << a.bin_shift, a.H, a.mult), rylo = pixel_y(min(((by0 + 4) << a.bin_shift) - 1, a.H - 1), a.H, a.mult);
-        const bool touch = on && !(sxmax < rxlo || sxmin > rxhi) && !(symax < rylo || symin > ryhi);
-        uint64_t ms = 0, mh = 0;
-        if (__ballot(touch)) {
-            unsigned cols = 0, rows = 0, colh = 0, rowh = 0;
+    for (int s = part; s < sbx * sby; s += a.parts) {
+        const int bx0 = (s % sbx) * 8, by0 = (s / sbx) * 8;
+        const int clo = max(c0 - bx0, 0), chi = min(c1 - bx0, 7), rlo = max(r0 - by0, 0), rhi = min(r1 - by0, 7);
+        const unsigned col = chi >= clo ? ((2u << chi) - (1u << clo)) : 0u;       // bits clo..chi
+        const unsigned row = rhi >= rlo ? ((2u << rhi) - (1u << rlo)) : 0u;
+        unsigned lo = 0, hi = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // pixel-centre extent of bin column / row i of this region
-                const int px0 = (bx0 + i) << a.bin_shift, px1 = min(((bx0 + i + 1) << a.bin_shift) - 1, a.W - 1);
-                const int py0 = (by0 + i) << a.bin_shift, py1 = min(((by0 + i + 1) << a.bin_shift) - 1, a.H - 1);
-                const float xlo = pixel_x(px0, a.W, a.mult), xhi = pixel_x(px1, a.W, a.mult);
-                const float yhi = pixel_y(py0, a.H, a.mult), ylo = pixel_y(py1, a.H, a.mult);
-                cols |= (unsigned)(!(sxmax < xlo || sxmin > xhi)) << i;
-                rows |= (unsigned)(!(symax < ylo || symin > yhi)) << i;
-                colh |= (unsigned)(!(xmax < xlo || xmin > xhi)) << i;
-                rowh |= (unsigned)(!(ymax < ylo || ymin > yhi)) << i;
-            }
-            unsigned cs = 0, ch = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                cs |= ((rows >> k) & 1u) ? (cols << (4 * k)) : 0u;
-                ch |= ((rowh >> k) & 1u) ? (colh << (4 * k)) : 0u;
-            }
-            if (!on) cs = 0;
-            if (!on || !front) ch = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint64_t s1 = __ballot((cs >> j) & 1u);
-                if (lane == j) ms = s1;
-            }
-            if (__ballot(ch != 0)) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint64_t h1 = __ballot((ch >> j) & 1u);
-                    if (lane == j) mh = h1;
-                }
-            }
+        for (int r = 0; r < 4; ++r) {
+            lo |= ((row >> r) & 1u) ? (col << (8 * r)) : 0u;
+            hi |= ((row >> (r + 4)) & 1u) ? (col << (8 * r)) : 0u;
         }
-        if (lane < 16 && (bx0 + i4) < a.nbx && (by0 + k4) < a.nby) {
-            const size_t row = ((size_t)b * a.nbx * a.nby + (size_t)(by0 + k4) * a.nbx + (bx0 + i4)) * a.words;
-            a.soft[row + c] = ms; a.hard[row + c] = mh;
-        }
+        const uint64_t cov = ((uint64_t)hi << 32) | lo;           // bit (r*8+c): this face touches bin (by0+r, bx0+c)
+        uint64_t word = 0;
+        if (__ballot(cov != 0)) word = wave_transpose64(cov, lane);               // lane j: bit i = face c*64+i touches bin j
+        const int bx = bx0 + (lane & 7), by = by0 + (lane >> 3);
+        if (bx < a.nbx && by < a.nby) a.mask[((size_t)b * a.nbx * a.nby + (size_t)by * a.nbx + bx) * a.words + c] = word;
     }
 }
 
@@ -337,11 +304,10 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
 
 int launch_bin(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     BinArgs a;
-    a.B = d->B; a.F = d->F; a.H = d->H; a.W = d->W; a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
-    a.mult = d->multiplier; a.infl = d->boxlen * d->multiplier;
-    a.geo = w.geo; a.soft = w.binmask; a.hard = w.binmask_hard;
-    const int regions = ((w.nbx + 3) / 4) * ((w.nby + 3) / 4);
-    a.parts = regions >= 16 ? 4 : (regions >= 4 ? 2 : 1);        // waves per (image, word): enough of them to fill the chip
+    a.B = d->B; a.F = d->F; a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
+    a.geo = w.geo; a.mask = w.binmask;
+    const int blocks = ((w.nbx + 7) / 8) * ((w.nby + 7) / 8);
+    a.parts = blocks >= 4 ? 4 : blocks;                           // waves per (image, word): enough of them to fill the chip
     const long long waves = (long long)d->B * w.words * a.parts;
     { ProfScope ps(d->prof_events, MM_PROF_BIN, s);
       hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); }

@@ -42,7 +42,7 @@ struct BwdArgs {
     int* tcnt; TexRecord* trec; TexSpill* tspill; int ntiles_;
     // fused recon_data (gt == nullptr: off)
     const float* gt; const float4* lpart; const float* rgba; const float* grad_loss; float* loss; float image_weight;
-    float* ltot;                                                 // (B,2) per image {sum|pi-gi|, IoU}
+    float* ltot;                                                 // (B,4) per image {sum|pi-gi|, IoU, sum p*g, sum p+g-p*g + 1e-10}
     // gather
     const int32_t* face_order;
     int ntx, nty;
@@ -54,6 +54,25 @@ struct BwdArgs {
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. pixel-major pass
 // ---------------------------------------------------------------------------------------------------------------------
+// fused recon_data: the totals of every image = fixed-order sum of the partials its raster waves left (one workgroup per
+// image; the pixel pass needs them in every workgroup, the loss value is summed over images by the gather launch)
+__global__ __launch_bounds__(256) void loss_totals_kernel(BwdArgs a) {
+    __shared__ float s_tot[MM_BLOCK_WAVES][3];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nparts = 4 * a.blocks_per_image;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int k = threadIdx.x; k < nparts; k += 256) { const float4 q = a.lpart[(size_t)b * nparts + k]; t0 += q.x; t1 += q.y; t2 += q.z; }
+    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+    if (lane == 0) { s_tot[wave][0] = t0; s_tot[wave][1] = t1; s_tot[wave][2] = t2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l1 = ((s_tot[0][0] + s_tot[1][0]) + s_tot[2][0]) + s_tot[3][0];
+        const float up = ((s_tot[0][1] + s_tot[1][1]) + s_tot[2][1]) + s_tot[3][1];
+        const float U = (((s_tot[0][2] + s_tot[1][2]) + s_tot[2][2]) + s_tot[3][2]) + 1e-10f;
+        *(float4*)(a.ltot + b * 4) = make_float4(l1, up / U, up, U);
+    }
+}
+
 template <bool kNoMask>
 __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     MM_TIMELINE_BEGIN();
@@ -75,17 +94,8 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int hf = -1;
     if (a.gt) {
-        // fused recon_data backward (Appendix A.4): totals of this image = fixed-order sum of its raster-workgroup partials
-        __shared__ float s_tot[MM_BLOCK_WAVES][4];
-        __shared__ float s_loss[MM_BLOCK_WAVES][3];
-        const int nparts = 4 * a.blocks_per_image;
-        float t1 = 0.f, t2 = 0.f;
-        for (int k = threadIdx.x; k < nparts; k += 256) { const float4 q = a.lpart[(size_t)b * nparts + k]; t1 += q.y; t2 += q.z; }
-        t1 = wave_sum(t1); t2 = wave_sum(t2);
-        if (lane == 0) { s_tot[wave][0] = t1; s_tot[wave][1] = t2; }
-        __syncthreads();
-        const float up = ((s_tot[0][0] + s_tot[1][0]) + s_tot[2][0]) + s_tot[3][0];
-        const float U = (((s_tot[0][1] + s_tot[1][1]) + s_tot[2][1]) + s_tot[3][1]) + 1e-10f;
+        // fused recon_data backward (Appendix A.4); the image's totals come from loss_totals_kernel
+        const float up = a.ltot[b * 4 + 2], U = a.ltot[b * 4 + 3];
         const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
         const float cnt = (float)a.B * 3.f * (float)a.H * (float)a.W;
         if (in_img) {
@@ -103,17 +113,6 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
                 gq[c] = gs * a.image_weight * sg * gm / cnt;
             }
             g4 = make_float4(gq[0], gq[1], gq[2], gs * (-(1.f / (float)a.B) * (gm / U - up * (1.f - gm) / (U * U))));
-        }
-        if (a.loss && blk == 0) {                                 // this image's loss terms, summed over images by the gather launch
-            float t0 = 0.f;
-            for (int k = threadIdx.x; k < nparts; k += 256) t0 += a.lpart[(size_t)b * nparts + k].x;
-            t0 = wave_sum(t0);
-            if (lane == 0) s_loss[wave][0] = t0;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                a.ltot[b * 2 + 0] = ((s_loss[0][0] + s_loss[1][0]) + s_loss[2][0]) + s_loss[3][0];
-                a.ltot[b * 2 + 1] = up / U;
-            }
         }
     } else if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
     const float gin[3] = {g4.x, g4.y, g4.z};
@@ -542,7 +541,7 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
     SweepStage* s_stage = reinterpret_cast<SweepStage*>(s_raw);
     if (a.gt && a.loss && blockIdx.x == 0 && threadIdx.x < 64) {  // fused recon_data value: fixed-order sum over images
         float l1 = 0.f, iou = 0.f;
-        for (int bb = threadIdx.x; bb < a.B; bb += 64) { l1 += a.ltot[bb * 2]; iou += a.ltot[bb * 2 + 1]; }
+        for (int bb = threadIdx.x; bb < a.B; bb += 64) { l1 += a.ltot[bb * 4]; iou += a.ltot[bb * 4 + 1]; }
         l1 = wave_sum(l1); iou = wave_sum(iou);
         if (threadIdx.x == 0)
             a.loss[0] = a.image_weight * (l1 / ((float)a.B * 3.f * (float)a.H * (float)a.W)) + 1.f * (1.f - iou / (float)a.B);
@@ -571,6 +570,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)
     {
         ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
+        if (a.gt) hipLaunchKernelGGL(loss_totals_kernel, dim3(d->B), dim3(256), 0, s, a);
         dim3 grid(a.blocks_per_image * d->B);
         if (d->no_mask) hipLaunchKernelGGL(pixel_bwd_kernel<true>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(pixel_bwd_kernel<false>, grid, dim3(256), 0, s, a);

@@ -63,7 +63,7 @@ struct Workspace {
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
-    float* ltot;           // (B,2)       fused loss: per image {sum|pi-gi|, IoU}
+    float* ltot;           // (B,4)       fused loss: per image {sum|pi-gi|, IoU, sum p*g, sum p+g-p*g + 1e-10}
     float4* lpart;         // (B,4*blocks) fused loss: per raster workgroup {sum|pi-gi|, sum p*g, sum p+g-p*g, 0}
     int* tcnt;             // (B,ntiles)+(B) records appended per texture tile, then per-image spill counts (zeroed every backward)
     TexRecord* trec;       // (B,ntiles,MM_TREC_CAP)
@@ -100,7 +100,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
     w.lpart = (float4*)(p + o);     o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(float4));
-    w.ltot = (float*)(p + o);       o += align256((size_t)B * 2 * sizeof(float));
+    w.ltot = (float*)(p + o);       o += align256((size_t)B * 4 * sizeof(float));
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
     w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + B) * sizeof(int));

@@ -5,8 +5,8 @@ dev = torch.device("cuda:0")
 dr = pkg.DiffRender("/root/repo/tests/golden/templates/smpl_uv_642.npz", 128, emit_imnormal=False)
 att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, 48, 128, 128)
 datt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}; gtd = gt.to(dev)
-for ns in (1, 3, 6):
-    steps = [stepmod.RenderLossStep(dr, datt, gtd) for _ in range(ns)]
+for ns in (1, 4, 8):
+    steps = [stepmod.RenderLossStep(dr, datt, gtd, fused=True) for _ in range(ns)]
     streams = [torch.cuda.Stream(dev) for _ in steps]
     for i in range(30): steps[i % ns].run(streams[i % ns])
     torch.cuda.synchronize()

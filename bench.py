@@ -48,7 +48,7 @@ def algorithmic_bytes(kernel, B, F, V, HW, T):
         "raster_fwd": 52 * F + 12 * T + 20 * HW,
         "recon_partial": 32 * HW,
         "recon_bwd": 48 * HW,
-        "bin": 48 * F,
+        "bin": 16 * F,
         "order": 0,
         "pixel_bwd": 52 * F + 12 * T + 20 * HW,
         "gather_bwd": 36 * F + 12 * T,

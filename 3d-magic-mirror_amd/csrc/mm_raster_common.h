@@ -115,12 +115,18 @@ __device__ inline void pair_parallel(const TileCtx& t, Stage* st, uint64_t m, Ev
             ++k;
         }
         wave_lds_sync();
-        for (int p = t.lane; p < lim; p += 128) {                // two independent pairs per trip: ILP for a lone wave
-            const unsigned pr0 = st->pairs[p];
-            const bool two = p + 64 < lim;
-            const unsigned pr1 = two ? st->pairs[p + 64] : pr0;
-            eval((int)(pr0 >> 8), (int)(pr0 & 255u), true);
-            eval((int)(pr1 >> 8), (int)(pr1 & 255u), two);
+        if (lim <= 64) {                                         // wave-uniform: one pair per lane at most, no dummy second evaluation
+            const bool live = t.lane < lim;
+            const unsigned pr = st->pairs[live ? t.lane : 0];
+            eval((int)(pr >> 8), (int)(pr & 255u), live);
+        } else {
+            for (int p = t.lane; p < lim; p += 128) {            // two independent pairs per trip: ILP for a lone wave
+                const unsigned pr0 = st->pairs[p];
+                const bool two = p + 64 < lim;
+                const unsigned pr1 = two ? st->pairs[p + 64] : pr0;
+                eval((int)(pr0 >> 8), (int)(pr0 & 255u), true);
+                if (__ballot(two)) eval((int)(pr1 >> 8), (int)(pr1 & 255u), two);   // wave-uniform
+            }
         }
         wave_lds_sync();
     }

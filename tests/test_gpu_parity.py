@@ -201,6 +201,36 @@ def test_gradients_reach_all_inputs_at_headline_size(pkg):
     assert float((datt["textures"].grad != 0).float().mean()) < 0.9
 
 
+def test_stress_size_batch_independence_and_one_image_against_oracle(pkg, oracle):
+    """BASELINE config 5 (smpl_uv: 13 776 faces, B=16, 512x512, texture 1024x512) at FULL size.  Size-independent property: an
+    image's result does not depend on the batch it is rendered in (bitwise in the forward, to rounding in the backward, whose
+    LDS float adds are unordered) -- so the oracle run of ONE image of the batch vouches for the whole batch."""
+    B, S, k = 16, 512, 5
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv", B, S, seed=12, imn=False)
+    rgbs, out = dr.render(no_mask=True, **datt)
+    fidx = dr.last_face_idx.clone()
+    dr.recon_data(rgbs, gt.to(dev), no_mask=True).backward()
+    cov = (fidx >= 0).float().mean().item()
+    assert 0.05 < cov < 0.6 and bool((rgbs[:, 3][fidx >= 0] == 1).all())
+    # image k alone
+    one = {kk: (v[k:k + 1].detach().clone().requires_grad_(kk in LEAVES) if torch.is_tensor(v) else v) for kk, v in datt.items()}
+    r1, o1 = dr.render(no_mask=True, **one)
+    assert torch.equal(dr.last_face_idx[0], fidx[k]) and torch.equal(r1[0], rgbs[k].detach())
+    # recon_data means over the batch: the full batch's gradient of image k is 1/B of the single-image gradient for the L1 term
+    # and for the IoU term alike (both are means of per-image terms)
+    dr.recon_data(r1, gt[k:k + 1].to(dev), no_mask=True).backward()
+    for kk in LEAVES:
+        _close(datt[kk].grad[k].cpu().numpy() * B, one[kk].grad[0].cpu().numpy(), 2e-5)
+    # the oracle on that one image
+    inp1 = {kk: (v[k:k + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for kk, v in inp.items()}
+    rgba_o, fidx_o, _, _ = oracle.render_forward(inp1, H, W, True, proj)
+    assert np.array_equal(dr.last_face_idx[0].cpu().numpy(), fidx_o[0])
+    _close(r1[0].detach().permute(1, 2, 0).cpu().numpy(), rgba_o[0])
+    loss_o, g_o = oracle.step(inp1, gt[k:k + 1].numpy(), H, W, True, proj, image_weight=dr.image_weight)
+    for kk in LEAVES:
+        _close(one[kk].grad.cpu().numpy(), g_o[kk])
+
+
 def test_error_behaviour(pkg):
     dev = torch.device("cuda:0")
     dr = pkg.DiffRender(os.path.join(TEMPLATES, "sphere.npz"), 32)

@@ -6,7 +6,6 @@
 namespace mm {
 int launch_vertex_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_vertex_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
-int launch_bin(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_raster_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_raster_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
 size_t recon_workspace_bytes(const MMReconDesc*);

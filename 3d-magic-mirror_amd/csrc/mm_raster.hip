@@ -250,12 +250,8 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     return a;
 }
 
-int launch_bin(const MMRenderDesc* d, const Workspace& w, hipStream_t s);
-
 int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     if (resident_path(d)) return launch_raster_fwd_resident(d, w, s);
-    const int st = launch_bin(d, w, s);
-    if (st != MM_OK) return st;
     RasterArgs a = make_raster_args(d, w);
     dim3 grid(a.blocks_per_image * d->B * 4);
     a.order = nullptr;

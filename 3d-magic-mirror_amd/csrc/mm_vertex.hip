@@ -2,13 +2,16 @@
 //
 // Forward  (replaces smr_utils camera math + kaolin prepare_vertices + face_normals, networks.py:278-295):
 //   one thread per (image, face): camera transform (built once per workgroup), 3 vertex transforms, perspective
-//   divide, x multiplier, bbox, unit normal, front-facing bit.  Writes the packed face records the pixel stage
-//   streams (bbox | geo) plus attributes['face_normals'].
+//   divide, x multiplier, inflated pixel box, unit normal.  Writes the packed face records the pixel stage streams plus
+//   attributes['face_normals'], and -- the 64 faces of a wave being exactly one word of the screen-bin candidate mask --
+//   that mask: per block of 8x8 bins one wave transpose of the lanes' coverage bits (no separate binning pass).
 // Backward (reverse of the above): one workgroup per image walks the static vertex->corner CSR, so per-vertex
 //   gradients are gathered in a fixed order (no atomics), reduces dT in LDS and finishes with the camera chain.
 #include "mm_device.h"
 
 namespace mm {
+
+bool resident_path(const MMRenderDesc* d);
 
 struct VertexFwdArgs {
     int B, V, F, H, W;
@@ -20,6 +23,8 @@ struct VertexFwdArgs {
     float4* geo;
     float* face_normals;
     int* tcnt; int ntcnt;    // texture-record counters of the backward: cleared here for the first backward after this forward
+    int bin_shift, nbx, nby, words;
+    uint64_t* mask;          // (B,nbins,words) screen-bin candidate mask, written here (nullptr: not wanted)
 };
 
 __device__ inline void block_camera(const float* azim, const float* elev, const float* dist, const float* bias, int b,
@@ -47,7 +52,8 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     for (int i = 0; i < 12; ++i) T[i] = s_cam.T[i];
 
     const int f = blockIdx.x * 256 + tid;
-    if (f >= a.F) return;
+    int bx0 = 0, by0 = 0, bw = 0, bh = 0;                         // inflated pixel box of this lane's face (none)
+    if (f < a.F) {
     const int i0 = a.faces[f * 3 + 0], i1 = a.faces[f * 3 + 1], i2 = a.faces[f * 3 + 2];
     const float* vb = a.vertices + (size_t)b * a.V * 3;
     const Float3 A = to_camera(vb + (size_t)i0 * 3, T);
@@ -70,53 +76,33 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     a.geo[o * 3 + 1] = make_float4(cx, cy, A.z, Bv.z);
     // the pixel box of the face inflated by the soft-mask margin (conservative, see pixel_range), packed for the backward's
     // face sweep: x = px0 | py0 << 16, y = width | height << 16 (0 x 0 if it misses the image)
-    int bx0, bx1, by0, by1;
+    int bx1, by1;
     pixel_range(fminf(fminf(ax, bx), cx) - a.infl, fmaxf(fmaxf(ax, bx), cx) + a.infl, a.mult, a.W, false, bx0, bx1);
     pixel_range(fminf(fminf(ay, by), cy) - a.infl, fmaxf(fmaxf(ay, by), cy) + a.infl, a.mult, a.H, true, by0, by1);
-    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    bw = bx1 - bx0 + 1; bh = by1 - by0 + 1;
     const bool hit = bw > 0 && bh > 0;
     a.geo[o * 3 + 2] = make_float4(C.z, nz, __uint_as_float(hit ? ((unsigned)bx0 | ((unsigned)by0 << 16)) : 0u),
                                      __uint_as_float(hit ? ((unsigned)bw | ((unsigned)bh << 16)) : 0u));
     a.face_normals[o * 3 + 0] = nx; a.face_normals[o * 3 + 1] = ny; a.face_normals[o * 3 + 2] = nz;
-
-}
-
-// ---- screen binning ---------------------------------------------------------------------------------------------------
-// One wave per (image, mask word = 64 faces, one of `parts` slices of the image's BLOCKS of 8x8 bins): every lane takes the
-// pixel box of its face (inflated by the soft-mask margin, conservative: packed by the vertex stage) and turns it into bin
-// column / row ranges.  Per block the lane's coverage is a 64-bit row-major bit matrix (rows x columns outer product); one
-// wave transpose turns the 64 faces' coverage words into the 64 bins' mask words, stored plainly -- every word of every
-// bin is written (blocks no face touches skip the transpose): no atomics and no zero-fill.  The raster kernel re-tests
-// every (pixel, face) pair exactly, so a conservative mask changes no result.
-struct BinArgs {
-    int B, F, bin_shift, nbx, nby, words, parts;
-    const float4* geo;
-    uint64_t* mask;
-};
-
-__global__ __launch_bounds__(256) void bin_kernel(BinArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int sbx = (a.nbx + 7) >> 3, sby = (a.nby + 7) >> 3;
-    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gw >= (long long)a.B * a.words * a.parts) return;
-    const int part = (int)(gw % a.parts);
-    const int bc = (int)(gw / a.parts);
-    const int c = bc % a.words, b = bc / a.words;
-    const int f = c * 64 + lane;
-    int c0 = 0, c1 = -1, r0 = 0, r1 = -1;                         // bin columns / rows the box touches (none)
-    if (f < a.F) {
-        const float4 g2 = a.geo[((size_t)b * a.F + f) * 3 + 2];
-        const unsigned org = __float_as_uint(g2.z), ext = __float_as_uint(g2.w);
-        const int bw = (int)(ext & 0xFFFFu), bh = (int)(ext >> 16);
-        if (bw > 0 && bh > 0) {
-            const int px0 = (int)(org & 0xFFFFu), py0 = (int)(org >> 16);
-            c0 = px0 >> a.bin_shift; c1 = (px0 + bw - 1) >> a.bin_shift;
-            r0 = py0 >> a.bin_shift; r1 = (py0 + bh - 1) >> a.bin_shift;
-        }
     }
-    for (int s = part; s < sbx * sby; s += a.parts) {
-        const int bx0 = (s % sbx) * 8, by0 = (s / sbx) * 8;
-        const int clo = max(c0 - bx0, 0), chi = min(c1 - bx0, 7), rlo = max(r0 - by0, 0), rhi = min(r1 - by0, 7);
+
+    // ---- screen binning: this wave's 64 faces are exactly mask word c ---------------------------------------------------
+    // A lane turns its face's pixel box (inflated by the soft-mask margin, conservative) into bin column / row ranges.  Per
+    // block of 8x8 bins the lane's coverage is a 64-bit row-major bit matrix (rows x columns outer product); ONE wave
+    // transpose turns the 64 faces' coverage words into the 64 bins' mask words, stored plainly -- every word of every bin is
+    // written (blocks no face touches skip the transpose): no atomics, no zero-fill, no second pass over the face records.
+    // The raster kernel re-tests every (pixel, face) pair exactly, so a conservative mask changes no result.
+    const int c = blockIdx.x * 4 + (tid >> 6), lane = tid & 63;
+    if (a.mask == nullptr || c >= a.words) return;
+    int c0 = 0, c1 = -1, r0 = 0, r1 = -1;                         // bin columns / rows the box touches (none)
+    if (bw > 0 && bh > 0) {
+        c0 = bx0 >> a.bin_shift; c1 = (bx0 + bw - 1) >> a.bin_shift;
+        r0 = by0 >> a.bin_shift; r1 = (by0 + bh - 1) >> a.bin_shift;
+    }
+    const int sbx = (a.nbx + 7) >> 3, sby = (a.nby + 7) >> 3;
+    for (int s = 0; s < sbx * sby; ++s) {
+        const int kx0 = (s % sbx) * 8, ky0 = (s / sbx) * 8;
+        const int clo = max(c0 - kx0, 0), chi = min(c1 - kx0, 7), rlo = max(r0 - ky0, 0), rhi = min(r1 - ky0, 7);
         const unsigned col = chi >= clo ? ((2u << chi) - (1u << clo)) : 0u;       // bits clo..chi
         const unsigned row = rhi >= rlo ? ((2u << rhi) - (1u << rlo)) : 0u;
         unsigned lo = 0, hi = 0;
@@ -125,11 +111,11 @@ __global__ __launch_bounds__(256) void bin_kernel(BinArgs a) {
             lo |= ((row >> r) & 1u) ? (col << (8 * r)) : 0u;
             hi |= ((row >> (r + 4)) & 1u) ? (col << (8 * r)) : 0u;
         }
-        const uint64_t cov = ((uint64_t)hi << 32) | lo;           // bit (r*8+c): this face touches bin (by0+r, bx0+c)
+        const uint64_t cov = ((uint64_t)hi << 32) | lo;           // bit (r*8+c): this face touches bin (ky0+r, kx0+c)
         uint64_t word = 0;
         if (__ballot(cov != 0)) word = wave_transpose64(cov, lane);               // lane j: bit i = face c*64+i touches bin j
-        const int bx = bx0 + (lane & 7), by = by0 + (lane >> 3);
-        if (bx < a.nbx && by < a.nby) a.mask[((size_t)b * a.nbx * a.nby + (size_t)by * a.nbx + bx) * a.words + c] = word;
+        const int kx = kx0 + (lane & 7), ky = ky0 + (lane >> 3);
+        if (kx < a.nbx && ky < a.nby) a.mask[((size_t)b * a.nbx * a.nby + (size_t)ky * a.nbx + kx) * a.words + c] = word;
     }
 }
 
@@ -296,22 +282,12 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.geo = w.geo; a.face_normals = d->face_normals;
     a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B;
+    a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
+    a.mask = resident_path(d) ? nullptr : w.binmask;            // the LDS-resident forward builds its own lists
     dim3 grid((d->F + 255) / 256, d->B);
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
       hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }
     return launch_ok("vertex_fwd");
-}
-
-int launch_bin(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
-    BinArgs a;
-    a.B = d->B; a.F = d->F; a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
-    a.geo = w.geo; a.mask = w.binmask;
-    const int blocks = ((w.nbx + 7) / 8) * ((w.nby + 7) / 8);
-    a.parts = blocks >= 4 ? 4 : blocks;                           // waves per (image, word): enough of them to fill the chip
-    const long long waves = (long long)d->B * w.words * a.parts;
-    { ProfScope ps(d->prof_events, MM_PROF_BIN, s);
-      hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); }
-    return launch_ok("bin");
 }
 
 int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {

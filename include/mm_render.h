@@ -104,7 +104,7 @@ enum { MM_OPT_STREAMED = 1,         /* force the streamed kernels */
        MM_OPT_RESIDENT = 2 };       /* use the resident kernel when the template fits (else streamed) */
 
 enum { MM_PROF_VERTEX_FWD = 0, MM_PROF_RASTER_FWD = 1, MM_PROF_PIXEL_BWD = 2, MM_PROF_GATHER_BWD = 3, MM_PROF_VERTEX_BWD = 4,
-       MM_PROF_BIN = 5, MM_PROF_ORDER = 6, MM_PROF_RENDER_SLOTS = 7 };
+       MM_PROF_BIN = 5 /* unused: binning is part of the vertex stage */, MM_PROF_ORDER = 6, MM_PROF_RENDER_SLOTS = 7 };
 enum { MM_PROF_RECON_PARTIAL = 0, MM_PROF_RECON_FINAL = 1, MM_PROF_RECON_BWD = 2, MM_PROF_RECON_CONTOUR = 3,
        MM_PROF_RECON_SLOTS = 4 };
 

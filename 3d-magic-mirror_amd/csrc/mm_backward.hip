@@ -41,8 +41,8 @@ struct BwdArgs {
     float* dTacc; unsigned* ticket;
     int* tcnt; TexRecord* trec; TexSpill* tspill; int ntiles_;
     // fused recon_data (gt == nullptr: off)
-    const float* gt; const float4* lpart; const float* rgba; const float* grad_loss; float* loss; float image_weight;
-    float* ltot;                                                 // (B,4) per image {sum|pi-gi|, IoU, sum p*g, sum p+g-p*g + 1e-10}
+    const float* gt; const float* rgba; const float* grad_loss; float* loss; float image_weight;
+    const long long* ltot;                                       // (B,MM_LSUB,4) fused loss sums of the raster waves (fixed point)
     // gather
     const int32_t* face_order;
     int ntx, nty;
@@ -54,25 +54,6 @@ struct BwdArgs {
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. pixel-major pass
 // ---------------------------------------------------------------------------------------------------------------------
-// fused recon_data: the totals of every image = fixed-order sum of the partials its raster waves left (one workgroup per
-// image; the pixel pass needs them in every workgroup, the loss value is summed over images by the gather launch)
-__global__ __launch_bounds__(256) void loss_totals_kernel(BwdArgs a) {
-    __shared__ float s_tot[MM_BLOCK_WAVES][3];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nparts = 4 * a.blocks_per_image;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-    for (int k = threadIdx.x; k < nparts; k += 256) { const float4 q = a.lpart[(size_t)b * nparts + k]; t0 += q.x; t1 += q.y; t2 += q.z; }
-    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
-    if (lane == 0) { s_tot[wave][0] = t0; s_tot[wave][1] = t1; s_tot[wave][2] = t2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float l1 = ((s_tot[0][0] + s_tot[1][0]) + s_tot[2][0]) + s_tot[3][0];
-        const float up = ((s_tot[0][1] + s_tot[1][1]) + s_tot[2][1]) + s_tot[3][1];
-        const float U = (((s_tot[0][2] + s_tot[1][2]) + s_tot[2][2]) + s_tot[3][2]) + 1e-10f;
-        *(float4*)(a.ltot + b * 4) = make_float4(l1, up / U, up, U);
-    }
-}
-
 template <bool kNoMask>
 __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     MM_TIMELINE_BEGIN();
@@ -94,8 +75,10 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int hf = -1;
     if (a.gt) {
-        // fused recon_data backward (Appendix A.4); the image's totals come from loss_totals_kernel
-        const float up = a.ltot[b * 4 + 2], U = a.ltot[b * 4 + 3];
+        // fused recon_data backward (Appendix A.4); the image's totals are exact integer sums left by its raster waves
+        float l1s, up, un;
+        loss_totals(a.ltot, b, l1s, up, un);
+        const float U = un + 1e-10f;
         const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
         const float cnt = (float)a.B * 3.f * (float)a.H * (float)a.W;
         if (in_img) {
@@ -541,7 +524,7 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
     SweepStage* s_stage = reinterpret_cast<SweepStage*>(s_raw);
     if (a.gt && a.loss && blockIdx.x == 0 && threadIdx.x < 64) {  // fused recon_data value: fixed-order sum over images
         float l1 = 0.f, iou = 0.f;
-        for (int bb = threadIdx.x; bb < a.B; bb += 64) { l1 += a.ltot[bb * 4]; iou += a.ltot[bb * 4 + 1]; }
+        for (int bb = threadIdx.x; bb < a.B; bb += 64) { float s0, s1, s2; loss_totals(a.ltot, bb, s0, s1, s2); l1 += s0; iou += s1 / (s2 + 1e-10f); }
         l1 = wave_sum(l1); iou = wave_sum(iou);
         if (threadIdx.x == 0)
             a.loss[0] = a.image_weight * (l1 / ((float)a.B * 3.f * (float)a.H * (float)a.W)) + 1.f * (1.f - iou / (float)a.B);
@@ -562,7 +545,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.gp0 = w.gp0; a.gp1 = w.gp1; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.dTacc = w.dTacc; a.ticket = w.ticket;
     a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;
-    a.gt = d->fused_gt; a.lpart = w.lpart; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
+    a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
     a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
     a.face_order = d->face_order;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
@@ -570,7 +553,6 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)
     {
         ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
-        if (a.gt) hipLaunchKernelGGL(loss_totals_kernel, dim3(d->B), dim3(256), 0, s, a);
         dim3 grid(a.blocks_per_image * d->B);
         if (d->no_mask) hipLaunchKernelGGL(pixel_bwd_kernel<true>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(pixel_bwd_kernel<false>, grid, dim3(256), 0, s, a);

@@ -15,6 +15,7 @@
 #define MM_TILE 8             // a wave owns an 8x8 pixel tile, one lane per pixel
 #define MM_BLOCK_PX 16        // a 256-thread workgroup renders a 16x16 pixel block: 2x2 wave tiles
 #define MM_BLOCK_WAVES 4
+#define MM_LSUB 8             // sub-accumulators per image for the fused loss sums (one 32-byte row each: spreads same-address atomics)
 #define MM_GROUP_WORDS 16     // bin-mask words (of 64 faces) expanded per step: 1024 faces -> 2 KiB of uint16 ids per wave
 
 namespace mm {
@@ -63,8 +64,8 @@ struct Workspace {
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
-    float* ltot;           // (B,4)       fused loss: per image {sum|pi-gi|, IoU, sum p*g, sum p+g-p*g + 1e-10}
-    float4* lpart;         // (B,4*blocks) fused loss: per raster workgroup {sum|pi-gi|, sum p*g, sum p+g-p*g, 0}
+    long long* ltot;       // (B,MM_LSUB,4) fused loss: per image {sum|pi-gi|, sum p*g, sum p+g-p*g, -} in 2^-32 fixed point, spread over
+                           //            MM_LSUB sub-accumulators (64-bit integer atomics of the raster waves: exact, order-free); zeroed by vertex_fwd
     int* tcnt;             // (B,ntiles)+(B) records appended per texture tile, then per-image spill counts (zeroed every backward)
     TexRecord* trec;       // (B,ntiles,MM_TREC_CAP)
     TexSpill* tspill;      // (B,4*H*W)   records of tiles whose list is full (worst case: every pixel, 2x2 tiles)
@@ -99,8 +100,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.gp2 = (float*)(p + o);        o += align256((size_t)B * H * W * sizeof(float));
     w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
-    w.lpart = (float4*)(p + o);     o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(float4));
-    w.ltot = (float*)(p + o);       o += align256((size_t)B * 4 * sizeof(float));
+    w.ltot = (long long*)(p + o);   o += align256((size_t)B * MM_LSUB * 4 * sizeof(long long));
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
     w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + B) * sizeof(int));
@@ -339,6 +339,14 @@ __device__ inline uint64_t wave_transpose64(uint64_t x, int lane) {
     x = transpose_stage<2>(x, lane);
     x = transpose_stage<1>(x, lane);
     return x;
+}
+
+// fused recon_data totals of image b: {sum|pi-gi|, sum p*g, sum p+g-p*g} (exact integer sums of the raster waves' partials)
+__device__ inline void loss_totals(const long long* ltot, int b, float& l1, float& up, float& un) {
+    long long s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int k = 0; k < MM_LSUB; ++k) { const long long* r = ltot + ((size_t)b * MM_LSUB + k) * 4; s0 += r[0]; s1 += r[1]; s2 += r[2]; }
+    l1 = (float)((double)s0 * (1.0 / 4294967296.0)); up = (float)((double)s1 * (1.0 / 4294967296.0)); un = (float)((double)s2 * (1.0 / 4294967296.0));
 }
 
 __device__ inline float wave_sum(float v) {

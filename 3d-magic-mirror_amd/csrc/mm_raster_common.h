@@ -22,7 +22,7 @@ struct RasterArgs {
     const float* bg;
     float* softq;
     int* lastf;
-    const float* gt; float4* lpart;          // fused recon_data partial sums (gt == nullptr: off)
+    const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     // resident kernel only
     int V, regions_x, regions_per_image;
@@ -295,7 +295,12 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
             up = out[3] * gm; down = (out[3] + gm) - up;
         }
         l1 = wave_sum(l1); up = wave_sum(up); down = wave_sum(down);
-        if (t.lane == 0) a.lpart[((size_t)t.b * a.blocks_per_image + t.blk) * 4 + t.wave] = make_float4(l1, up, down, 0.f);
+        if (t.lane == 0) {                                       // exact in 2^-32 fixed point; integer adds commute: deterministic totals
+            unsigned long long* row = (unsigned long long*)(a.ltot + ((size_t)t.b * MM_LSUB + ((t.blk * 4 + t.wave) & (MM_LSUB - 1))) * 4);
+            atomicAdd(row + 0, (unsigned long long)(long long)((double)l1 * 4294967296.0));
+            if (up != 0.f) atomicAdd(row + 1, (unsigned long long)(long long)((double)up * 4294967296.0));
+            if (down != 0.f) atomicAdd(row + 2, (unsigned long long)(long long)((double)down * 4294967296.0));
+        }
     }
 }
 

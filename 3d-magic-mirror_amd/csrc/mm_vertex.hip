@@ -23,6 +23,7 @@ struct VertexFwdArgs {
     float4* geo;
     float* face_normals;
     int* tcnt; int ntcnt;    // texture-record counters of the backward: cleared here for the first backward after this forward
+    long long* ltot; int nltot;   // fused-loss sums of the raster waves: cleared here
     int bin_shift, nbx, nby, words;
     uint64_t* mask;          // (B,nbins,words) screen-bin candidate mask, written here (nullptr: not wanted)
 };
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     __shared__ Camera s_cam;
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nltot; i += gridDim.x * gridDim.y * 256) a.ltot[i] = 0;
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
     if (blockIdx.x == 0 && tid < 12) a.T[b * 12 + tid] = s_cam.T[tid];
     float T[12];
@@ -282,6 +284,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.geo = w.geo; a.face_normals = d->face_normals;
     a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B;
+    a.ltot = w.ltot; a.nltot = d->B * MM_LSUB * 4;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mask = resident_path(d) ? nullptr : w.binmask;            // the LDS-resident forward builds its own lists
     dim3 grid((d->F + 255) / 256, d->B);

@@ -346,7 +346,7 @@ __device__ inline void loss_totals(const long long* ltot, int b, float& l1, floa
     long long s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
     for (int k = 0; k < MM_LSUB; ++k) { const long long* r = ltot + ((size_t)b * MM_LSUB + k) * 4; s0 += r[0]; s1 += r[1]; s2 += r[2]; }
-    l1 = (float)((double)s0 * (1.0 / 4294967296.0)); up = (float)((double)s1 * (1.0 / 4294967296.0)); un = (float)((double)s2 * (1.0 / 4294967296.0));
+    l1 = (float)s0 * (1.f / 4294967296.f); up = (float)s1 * (1.f / 4294967296.f); un = (float)s2 * (1.f / 4294967296.f);   // one rounding each
 }
 
 __device__ inline float wave_sum(float v) {

@@ -201,6 +201,12 @@ __device__ inline uint64_t soft_take(uint64_t sm, bool open, int room) {
     return sm;
 }
 
+// x >= 0 (a sum of at most 64 terms of size <= 3) as 32.32 fixed point, exactly: integer part and 32 fraction bits
+__device__ inline unsigned long long fixed32(float x) {
+    const unsigned hi = (unsigned)x;
+    return ((unsigned long long)hi << 32) | (unsigned)((x - (float)hi) * 4294967296.f);
+}
+
 struct SoftState { float qnz; int zeros, lastf; };
 
 // ---- shading (a9-a11), stores, fused recon_data partial sums.  Uncovered pixels carry zero features exactly like kaolin's
@@ -297,9 +303,9 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
         l1 = wave_sum(l1); up = wave_sum(up); down = wave_sum(down);
         if (t.lane == 0) {                                       // exact in 2^-32 fixed point; integer adds commute: deterministic totals
             unsigned long long* row = (unsigned long long*)(a.ltot + ((size_t)t.b * MM_LSUB + ((t.blk * 4 + t.wave) & (MM_LSUB - 1))) * 4);
-            atomicAdd(row + 0, (unsigned long long)(long long)((double)l1 * 4294967296.0));
-            if (up != 0.f) atomicAdd(row + 1, (unsigned long long)(long long)((double)up * 4294967296.0));
-            if (down != 0.f) atomicAdd(row + 2, (unsigned long long)(long long)((double)down * 4294967296.0));
+            atomicAdd(row + 0, fixed32(l1));
+            if (up != 0.f) atomicAdd(row + 1, fixed32(up));
+            if (down != 0.f) atomicAdd(row + 2, fixed32(down));
         }
     }
 }

@@ -280,8 +280,12 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 //    issued together (these loops are latency-bound: a dependent HBM/L2 load per step).
 // ---------------------------------------------------------------------------------------------------------------------
 #define MM_TS MM_UV_TILE
+#ifndef MM_SWEEP
 #define MM_SWEEP 16             // pixels per lane per trip
-#define MM_FL 8                 // lanes per face: a trip covers MM_FL * MM_SWEEP = 64 pixels of each of the wave's faces
+#endif
+#ifndef MM_FL
+#define MM_FL 8                 // lanes per face: a trip covers MM_FL * MM_SWEEP pixels of each of the wave's faces
+#endif
 #define MM_FPW (64 / MM_FL)     // faces per wave
 
 struct FaceBox { float4 p0, p1; float xmin, ymin, xmax, ymax; int px0, py0, bw, npx; float inv_bw; };

@@ -20,6 +20,19 @@
 MM_TIMELINE_STORAGE(pixel_bwd)
 MM_TIMELINE_STORAGE(gather_bwd)
 
+// -DMM_GATHER_PROF: per-wave cycle totals of the face sweep's phases (debug builds only; profiles/tools/gather_prof.py)
+#ifdef MM_GATHER_PROF
+namespace mm { __device__ unsigned long long g_gprof[16384][8]; }
+extern "C" int mm_debug_gather_prof(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm::g_gprof), sizeof(unsigned long long) * 16384 * 8) == hipSuccess ? 0 : -1;
+}
+#define GP_T(x) __builtin_amdgcn_s_waitcnt(0); const unsigned long long x = clock64()   /* everything issued so far has completed */
+#define GP_ACC(i, a, b) gp[i] += (b) - (a)
+#else
+#define GP_T(x) do { } while (0)
+#define GP_ACC(i, a, b) do { } while (0)
+#endif
+
 namespace mm {
 
 struct BwdArgs {
@@ -415,6 +428,10 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     SweepStage* st = &s_stage[wave];
     // a wave sweeps MM_FPW faces of consecutive area rank of ONE image (same camera: similar box sizes, so its groups finish
     // together); waves walk the images round-robin and the ranks with the biggest boxes start first
+#ifdef MM_GATHER_PROF
+    unsigned long long gp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    GP_T(t_begin);
     const long long wid = (long long)block * 4 + wave;            // wave index over (rank octet, image)
     const int b = (int)(wid % a.B);
     const int rk_raw = (int)(wid / a.B) * MM_FPW + grp;
@@ -435,8 +452,10 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
 #pragma unroll
     for (int o = MM_FL; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
     wave_sync_lds();
+    GP_T(t_setup); GP_ACC(0, t_begin, t_setup);
 
     for (int base = 0; base < nmax; base += MM_FL * MM_SWEEP) {
+        GP_T(t0);
         bool own[MM_SWEEP], opn[MM_SWEEP];
 #pragma unroll
         for (int i = 0; i < MM_SWEEP; ++i) {
@@ -451,8 +470,13 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
         bool hit[MM_SWEEP];
 #pragma unroll
         for (int i = 0; i < MM_SWEEP; ++i) hit[i] = own[i] || opn[i];
+        GP_T(t1); GP_ACC(1, t0, t1);                             // sweep: box walk + face_idx loads
         const int n = compact4(hit, lane, st->items);
         wave_sync_lds();
+        GP_T(t2); GP_ACC(2, t1, t2);                             // compaction
+#ifdef MM_GATHER_PROF
+        gp[4] += n; gp[5] += 1;
+#endif
         for (int j = lane; j < n; j += 64) {
             int g, px, py;
             item_pixel(st, st->items[j], base, g, px, py);
@@ -508,6 +532,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             }
         }
         wave_sync_lds();
+        GP_T(t3); GP_ACC(3, t2, t3);                             // items
     }
     if (live) {
         for (int k = sl; k < 9; k += MM_FL) {
@@ -515,6 +540,11 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             if (k < 6) a.dfxy[o * 6 + k] = v; else a.dfn[o * 3 + (k - 6)] = v;
         }
     }
+#ifdef MM_GATHER_PROF
+    GP_T(t_end);
+    gp[6] = t_end - t_begin; gp[7] = nmax;
+    if (lane == 0 && wid < 16384) for (int k = 0; k < 8; ++k) g_gprof[wid][k] = gp[k];
+#endif
 }
 
 // One launch for both gathers: they only depend on the pixel pass, and each is latency-bound with a long tail, so their

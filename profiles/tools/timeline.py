@@ -33,3 +33,10 @@ for name in ("raster_fwd", "pixel_bwd", "gather_bwd"):
     print("   running at t: " + "  ".join("%.0fus:%d" % (q, int(((s <= q) & (e > q)).sum())) for q in qs))
     late = np.argsort(-e)[:5]
     print("   last finishers (index, start, end): " + ", ".join("(%d, %.1f, %.1f)" % (int(i), s[i], e[i]) for i in late))
+    if name == "gather_bwd":                                     # kind split: texture tiles come first in the grid (ntex = tiles x images)
+        ntex = ((256 + 31) // 32) * ((128 + 31) // 32) * 48
+        idx = np.nonzero(np.frombuffer(out, dtype=np.uint64).reshape(MAXB, 2)[:, 1] > 0)[0]
+        for kind, sel in (("texture tiles", idx < ntex), ("face sweeps", idx >= ntex)):
+            print("   %s: %d workgroups, start p50 %.1f p90 %.1f last %.1f | duration mean %.1f p90 %.1f max %.1f | end p50 %.1f p90 %.1f p99 %.1f last %.1f" % (
+                kind, sel.sum(), np.median(s[sel]), np.percentile(s[sel], 90), s[sel].max(), d[sel].mean(), np.percentile(d[sel], 90), d[sel].max(),
+                np.median(e[sel]), np.percentile(e[sel], 90), np.percentile(e[sel], 99), e[sel].max()))

@@ -301,6 +301,21 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 #endif
 #define MM_FPW (64 / MM_FL)     // faces per wave
 
+// squared distance from p to segment u-v by clamped projection: t in [0,1] is where the nearest point lies, q = p - nearest.
+// With t clamped, d(d^2)/du = -2 (1-t) q and d(d^2)/dv = -2 t q hold in all three regions of kaolin's case split (t = 0: the
+// nearest point is u, t = 1: it is v).  Hardware reciprocal: the backward is held to 1e-4, not to the bit.
+struct SegHit { float d2, t, qx, qy; };
+__device__ inline SegHit seg_nearest(float px, float py, float ux, float uy, float vx, float vy) {
+    const float ex = vx - ux, ey = vy - uy, rx = px - ux, ry = py - uy;
+    const float len2 = ex * ex + ey * ey;
+    float t = (len2 > 0.f) ? (rx * ex + ry * ey) * __builtin_amdgcn_rcpf(len2) : 0.f;
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    SegHit h;
+    h.t = t; h.qx = rx - t * ex; h.qy = ry - t * ey;
+    h.d2 = h.qx * h.qx + h.qy * h.qy;
+    return h;
+}
+
 struct FaceBox { float4 p0, p1; float xmin, ymin, xmax, ymax; int px0, py0, bw, npx; float inv_bw; };
 
 __device__ inline FaceBox face_box(const BwdArgs& a, size_t o) {
@@ -500,34 +515,24 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= lf &&
                 !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl)) {
                 const float4 p0 = fs.p0, p1 = fs.p1;
-                int r, ty;
-                float d = seg_dist2(x0, y0, p0.x, p0.y, p0.z, p0.w, ty);
-                const float d1 = seg_dist2(x0, y0, p0.z, p0.w, p1.x, p1.y, r); if (d1 < d) { d = d1; ty = 3 + r; }
-                const float d2 = seg_dist2(x0, y0, p1.x, p1.y, p0.x, p0.y, r); if (d2 < d) { d = d2; ty = 6 + r; }
-                const float p = __builtin_amdgcn_exp2f(-(d * (a.sigmainv / s2)) * 1.4426950408889634f);
+                SegHit h = seg_nearest(x0, y0, p0.x, p0.y, p0.z, p0.w);       // edge 0: corner a -> b
+                int e = 0;
+                const SegHit h1 = seg_nearest(x0, y0, p0.z, p0.w, p1.x, p1.y); // edge 1: b -> c
+                if (h1.d2 < h.d2) { h = h1; e = 1; }
+                const SegHit h2 = seg_nearest(x0, y0, p1.x, p1.y, p0.x, p0.y); // edge 2: c -> a
+                if (h2.d2 < h.d2) { h = h2; e = 2; }
+                const float p = __builtin_amdgcn_exp2f(-(h.d2 * (a.sigmainv / s2)) * 1.4426950408889634f);
                 const float q = 1.f - p;
                 const float qnz = fabsf(sq);
                 const bool onezero = sq < 0.f;
-                const float excl = (q != 0.f) ? (onezero ? 0.f : qnz / q) : (onezero ? qnz : 0.f);
-                const float gd = ga * excl * (-(p * a.sigmainv) / s2);
+                const float excl = (q != 0.f) ? (onezero ? 0.f : qnz * __builtin_amdgcn_rcpf(q)) : (onezero ? qnz : 0.f);
+                const float gd = ga * excl * (-(p * a.sigmainv) / s2) * a.mult;
                 if (gd != 0.f) {
-                    const int e = ty / 3, reg = ty - e * 3;
-                    const float ux = e == 0 ? p0.x : (e == 1 ? p0.z : p1.x), uy = e == 0 ? p0.y : (e == 1 ? p0.w : p1.y);
-                    const float wx = e == 0 ? p0.z : (e == 1 ? p1.x : p0.x), wy = e == 0 ? p0.w : (e == 1 ? p1.y : p0.y);
-                    float dux = 0.f, duy = 0.f, dvx = 0.f, dvy = 0.f;
-                    if (reg == 0) { dux = -2.f * (x0 - ux); duy = -2.f * (y0 - uy); }
-                    else if (reg == 2) { dvx = -2.f * (x0 - wx); dvy = -2.f * (y0 - wy); }
-                    else {
-                        const float ex = wx - ux, ey = wy - uy, rx = x0 - ux, ry = y0 - uy;
-                        const float tt = (rx * ex + ry * ey) / (ex * ex + ey * ey);
-                        const float qx = x0 - (ux + tt * ex), qy = y0 - (uy + tt * ey);
-                        dux = -2.f * (1.f - tt) * qx; duy = -2.f * (1.f - tt) * qy;
-                        dvx = -2.f * tt * qx; dvy = -2.f * tt * qy;
-                    }
                     // edge e runs from corner e to corner (e+1)%3
                     const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;
-                    atomicAdd(&fs.acc[iu], gd * dux * a.mult); atomicAdd(&fs.acc[iu + 1], gd * duy * a.mult);
-                    atomicAdd(&fs.acc[iv], gd * dvx * a.mult); atomicAdd(&fs.acc[iv + 1], gd * dvy * a.mult);
+                    const float cu = -2.f * (1.f - h.t) * gd, cv = -2.f * h.t * gd;
+                    atomicAdd(&fs.acc[iu], cu * h.qx); atomicAdd(&fs.acc[iu + 1], cu * h.qy);
+                    atomicAdd(&fs.acc[iv], cv * h.qx); atomicAdd(&fs.acc[iv + 1], cv * h.qy);
                 }
             }
         }

@@ -304,15 +304,18 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 // squared distance from p to segment u-v by clamped projection: t in [0,1] is where the nearest point lies, q = p - nearest.
 // With t clamped, d(d^2)/du = -2 (1-t) q and d(d^2)/dv = -2 t q hold in all three regions of kaolin's case split (t = 0: the
 // nearest point is u, t = 1: it is v).  Hardware reciprocal: the backward is held to 1e-4, not to the bit.
-struct SegHit { float d2, t, qx, qy; };
-__device__ inline SegHit seg_nearest(float px, float py, float ux, float uy, float vx, float vy) {
-    const float ex = vx - ux, ey = vy - uy, rx = px - ux, ry = py - uy;
-    const float len2 = ex * ex + ey * ey;
-    float t = (len2 > 0.f) ? (rx * ex + ry * ey) * __builtin_amdgcn_rcpf(len2) : 0.f;
+// (x, y) pairs as two-lane vectors: gfx950 executes v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on both halves at once
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ inline float dot2(f2 a, f2 b) { const f2 m = a * b; return m.x + m.y; }
+struct SegHit { float d2, t; f2 q; };
+__device__ inline SegHit seg_nearest(f2 p, f2 u, f2 v) {
+    const f2 e = v - u, r = p - u;
+    const float len2 = dot2(e, e);
+    float t = (len2 > 0.f) ? dot2(r, e) * __builtin_amdgcn_rcpf(len2) : 0.f;
     t = fminf(fmaxf(t, 0.f), 1.f);
     SegHit h;
-    h.t = t; h.qx = rx - t * ex; h.qy = ry - t * ey;
-    h.d2 = h.qx * h.qx + h.qy * h.qy;
+    h.t = t; h.q = r - t * e;
+    h.d2 = dot2(h.q, h.q);
     return h;
 }
 
@@ -515,11 +518,12 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= lf &&
                 !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl)) {
                 const float4 p0 = fs.p0, p1 = fs.p1;
-                SegHit h = seg_nearest(x0, y0, p0.x, p0.y, p0.z, p0.w);       // edge 0: corner a -> b
+                const f2 pp = {x0, y0}, ca = {p0.x, p0.y}, cb = {p0.z, p0.w}, cc = {p1.x, p1.y};
+                SegHit h = seg_nearest(pp, ca, cb);               // edge 0: corner a -> b
                 int e = 0;
-                const SegHit h1 = seg_nearest(x0, y0, p0.z, p0.w, p1.x, p1.y); // edge 1: b -> c
+                const SegHit h1 = seg_nearest(pp, cb, cc);        // edge 1: b -> c
                 if (h1.d2 < h.d2) { h = h1; e = 1; }
-                const SegHit h2 = seg_nearest(x0, y0, p1.x, p1.y, p0.x, p0.y); // edge 2: c -> a
+                const SegHit h2 = seg_nearest(pp, cc, ca);        // edge 2: c -> a
                 if (h2.d2 < h.d2) { h = h2; e = 2; }
                 const float p = __builtin_amdgcn_exp2f(-(h.d2 * (a.sigmainv / s2)) * 1.4426950408889634f);
                 const float q = 1.f - p;
@@ -531,8 +535,9 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
                     // edge e runs from corner e to corner (e+1)%3
                     const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;
                     const float cu = -2.f * (1.f - h.t) * gd, cv = -2.f * h.t * gd;
-                    atomicAdd(&fs.acc[iu], cu * h.qx); atomicAdd(&fs.acc[iu + 1], cu * h.qy);
-                    atomicAdd(&fs.acc[iv], cv * h.qx); atomicAdd(&fs.acc[iv + 1], cv * h.qy);
+                    const f2 gu = cu * h.q, gv = cv * h.q;
+                    atomicAdd(&fs.acc[iu], gu.x); atomicAdd(&fs.acc[iu + 1], gu.y);
+                    atomicAdd(&fs.acc[iv], gv.x); atomicAdd(&fs.acc[iv + 1], gv.y);
                 }
             }
         }

@@ -69,6 +69,7 @@ def main():
                     help="successive (independent) steps are enqueued round-robin on this many HIP streams, each with its own buffers")
     ap.add_argument("--unfused", action="store_true", help="recon_data as its own three launches instead of folded into the render kernels")
     ap.add_argument("--resident", action="store_true", help="opt into the LDS-resident forward kernel (MM_OPT_RESIDENT)")
+    ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed run-in before the warmup steps (clock ramp)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--profile-steps", type=int, default=30, help="extra eager steps with per-kernel HIP events")
     args = ap.parse_args()
@@ -129,6 +130,13 @@ def main():
             rgbs, _ = dr.render(no_mask=True, **a)
             dr.recon_data(rgbs, gtd, no_mask=True).backward()
 
+    # untimed settling phase before the W warmup steps: clocks and queues of a device that has just been idle (or has just
+    # finished another process's work) ramp over hundreds of milliseconds, longer than W short steps last
+    settle = time.perf_counter()
+    while time.perf_counter() - settle < args.settle_seconds:
+        for _ in range(32):
+            one()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         one()
     barrier(); torch.cuda.synchronize(dev)

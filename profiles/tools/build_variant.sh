@@ -6,7 +6,7 @@ cd /root/repo/3d-magic-mirror_amd
 name=$1; src=$2; shift 2
 python build_native.py > /dev/null
 mode="-ffp-contract=off"
-[ "$src" = mm_backward.hip ] && mode="-ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt"
+[ "$src" = mm_backward.hip ] && mode="-ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize"
 flags=$(python - <<PY
 import importlib.util
 s = importlib.util.spec_from_file_location("b", "build_native.py"); m = importlib.util.module_from_spec(s); s.loader.exec_module(m)

@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
         loss_totals(a.ltot, b, l1s, up, un);
         const float U = un + 1e-10f;
         const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
-        const float cnt = (float)a.B * 3.f * (float)a.H * (float)a.W;
+        // everything that is the same for all pixels of the image is folded into three coefficients (wave-uniform arithmetic
+        // once, instead of four divisions per lane): dL/dpred_c = kl1 * sign * gm,  dL/dalpha = ka * gm + kb * (1 - gm)
+        const float kl1 = gs * a.image_weight / ((float)a.B * 3.f * (float)a.H * (float)a.W);
+        const float ka = -gs / ((float)a.B * U), kb = gs * up / ((float)a.B * U * U);
         if (in_img) {
             hf = a.face_idx[pix];
             const float4 pr = *(const float4*)(a.rgba + pix * 4);
@@ -106,9 +109,9 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
                 const float gi = g[c * hw + pin] * gm + 1.f * (1.f - gm);
                 const float pi = prc[c] * gm + 1.f * (1.f - gm);
                 const float df = pi - gi, sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-                gq[c] = gs * a.image_weight * sg * gm / cnt;
+                gq[c] = kl1 * sg * gm;
             }
-            g4 = make_float4(gq[0], gq[1], gq[2], gs * (-(1.f / (float)a.B) * (gm / U - up * (1.f - gm) / (U * U))));
+            g4 = make_float4(gq[0], gq[1], gq[2], ka * gm + kb * (1.f - gm));
         }
     } else if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
     const float gin[3] = {g4.x, g4.y, g4.z};

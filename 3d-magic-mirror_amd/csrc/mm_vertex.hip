@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         const float p[3] = {vb[v * 3], vb[v * 3 + 1], vb[v * 3 + 2]};
         const Float3 me = to_camera(p, T);
         const float pz = me.z * a.proj2;
-        const float xi = (me.x * a.proj0) / pz, yi = (me.y * a.proj1) / pz;
+        const float ipz = 1.f / pz;                               // one division per vertex, not three per corner
+        const float xi = (me.x * a.proj0) * ipz, yi = (me.y * a.proj1) * ipz;
         float d[3] = {0.f, 0.f, 0.f};
         const int beg = a.vc_offsets[v], end = a.vc_offsets[v + 1];
         for (int it = beg + cl; it < end; it += 8) {
@@ -178,9 +179,9 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             const size_t o = (size_t)b * a.F + f;
             // through face_vertices_image
             const float gx = a.dfxy[o * 6 + k * 2], gy = a.dfxy[o * 6 + k * 2 + 1];
-            d[0] += gx * a.proj0 / pz;
-            d[1] += gy * a.proj1 / pz;
-            d[2] += -(gx * xi + gy * yi) * a.proj2 / pz;
+            d[0] += gx * a.proj0 * ipz;
+            d[1] += gy * a.proj1 * ipz;
+            d[2] += -(gx * xi + gy * yi) * a.proj2 * ipz;
             // through the unit face normal
             float g[3] = {a.dfn[o * 3], a.dfn[o * 3 + 1], a.dfn[o * 3 + 2]};
             if (a.gfn) { g[0] += a.gfn[o * 3]; g[1] += a.gfn[o * 3 + 1]; g[2] += a.gfn[o * 3 + 2]; }
@@ -194,12 +195,11 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
                 const float len = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
                 const float den = len + 1e-10f;
                 const float ng = (n[0] * g[0] + n[1] * g[1]) + n[2] * g[2];
+                // d/dn of g . n / (|n| + 1e-10):  g / den - (n . g) / den^2 * n / |n|   (two divisions for the three components)
+                const float iden = 1.f / den, c = (len > 0.f) ? (ng * iden * iden) / len : 0.f;
                 float dn[3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float dirj = (len > 0.f) ? n[j] / len : 0.f;
-                    dn[j] = g[j] / den - (ng / (den * den)) * dirj;
-                }
+                for (int j = 0; j < 3; ++j) dn[j] = g[j] * iden - c * n[j];
                 float de0[3], de1[3];
                 cross3(e1, dn, de0);
                 cross3(dn, e0, de1);

@@ -8,6 +8,6 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(glob.glob("/tmp/pv/*counter_collection.csv")[0])):
     agg[r["Kernel_Name"].split("(")[0].replace("void ","").replace("mm::","")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("variant $v:", {k: int(sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"])) for k, c in agg.items() if "raster" in k or "gather" in k or "pixel" in k or "walk" in k or "bin" in k})
+print("variant $v:", {k: int(sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"])) for k, c in agg.items() if "raster" in k or "gather" in k or "pixel" in k or "walk" in k or "vertex" in k})
 PY
 done

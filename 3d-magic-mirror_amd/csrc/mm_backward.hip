@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             const float4* geo = a.geo + ((size_t)b * a.F + hf) * 3;
             p0 = geo[0]; p1 = geo[1];
             edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
-            w0 /= nrm; w1 /= nrm; w2 /= nrm;
+            const float inrm = 1.f / nrm;
+            w0 *= inrm; w1 *= inrm; w2 *= inrm;
             const float* fuv = a.face_uvs + (size_t)hf * 6;
 #pragma unroll
             for (int i = 0; i < 6; ++i) fu[i] = fuv[i];
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             const float G1 = ((dm + du * fu[2]) + dv * fu[3]) + gnn;
             const float G2 = ((dm + du * fu[4]) + dv * fu[5]) + gnn;
             const float Gm = (w0 * G0 + w1 * G1) + w2 * G2;
-            const float dw0 = (G0 - Gm) / nrm, dw1 = (G1 - Gm) / nrm, dw2 = (G2 - Gm) / nrm;
+            const float inrm = 1.f / nrm;
+            const float dw0 = (G0 - Gm) * inrm, dw1 = (G1 - Gm) * inrm, dw2 = (G2 - Gm) * inrm;
             const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
             a.gp0[pix] = make_float4((dw1 * (-cey) + dw2 * bey) * a.mult, (dw1 * cex + dw2 * (-bex)) * a.mult,
                                      (dw0 * cey + dw2 * (-aey)) * a.mult, (dw0 * (-cex) + dw2 * aex) * a.mult);

@@ -111,7 +111,12 @@ def main():
         step.capture()
         one = step.replay
     elif args.mode == "eager" and args.streams > 1:
-        steps_ = [step] + [stepmod.RenderLossStep(dr, datt, gtd, no_mask=True, fused=not args.unfused) for _ in range(args.streams - 1)]
+        # every stream renders its OWN batch (distinct synthetic draws): no input is shared between the steps in flight
+        steps_ = [step]
+        for i in range(1, args.streams):
+            att_i, gt_i = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=1000 * i + rank)
+            datt_i = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att_i.items()}
+            steps_.append(stepmod.RenderLossStep(dr, datt_i, gt_i.to(dev), no_mask=True, fused=not args.unfused))
         streams_ = [torch.cuda.Stream(dev) for _ in steps_]
         ctr = [0]
 

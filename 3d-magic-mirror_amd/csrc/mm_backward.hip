@@ -363,13 +363,15 @@ struct __attribute__((aligned(16))) SweepStage {
     unsigned short items[MM_SWEEP * 64];   // (sweep slot << 6) | lane
 };
 
-// ballot-compaction of four per-lane flags into an ordered LDS item list; returns the item count (wave-uniform)
-__device__ inline int compact4(const bool (&flag)[MM_SWEEP], int lane, unsigned short* items) {
+// ballot-compaction of the lanes' hits into an ordered LDS item list: (owned pixel ? 0x8000 : 0) | sweep slot << 6 | lane;
+// returns the item count (wave-uniform)
+__device__ inline int compact4(const bool (&own)[MM_SWEEP], const bool (&opn)[MM_SWEEP], int lane, unsigned short* items) {
     int base = 0;
 #pragma unroll
     for (int i = 0; i < MM_SWEEP; ++i) {
-        const unsigned long long m = __ballot(flag[i]);
-        if (flag[i]) items[base + ballot_rank(m)] = (unsigned short)((i << 6) | lane);
+        const bool hit = own[i] || opn[i];
+        const unsigned long long m = __ballot(hit);
+        if (hit) items[base + ballot_rank(m)] = (unsigned short)((own[i] ? 0x8000 : 0) | (i << 6) | lane);
         base += __popcll(m);
     }
     return base;
@@ -384,7 +386,7 @@ __device__ inline void wave_sync_lds() {
 // pixel index of item `it` of the current trip: the item names the sweeping lane (hence its 16-lane group = face slot and
 // its position in the box walk)
 __device__ inline void item_pixel(const SweepStage* st, unsigned it, int base, int& g, int& px, int& py) {
-    const int l = it & 63, i = it >> 6;
+    const int l = it & 63, i = (it >> 6) & 0x1FF;
     g = l / MM_FL;
     const FaceSlot& fs = st->slot[g];
     box_pixel(base + i * MM_FL + (l % MM_FL), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
@@ -490,11 +492,8 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
         }
         // one compacted item list for both kinds of hit: pixels these faces own (K2: add the pixel pass's contributions)
         // and uncovered pixels that may hold one of these faces among their first knum soft-mask faces (K4, Appendix A.2)
-        bool hit[MM_SWEEP];
-#pragma unroll
-        for (int i = 0; i < MM_SWEEP; ++i) hit[i] = own[i] || opn[i];
         GP_T(t1); GP_ACC(1, t0, t1);                             // sweep: box walk + face_idx loads
-        const int n = compact4(hit, lane, st->items);
+        const int n = compact4(own, opn, lane, st->items);
         wave_sync_lds();
         GP_T(t2); GP_ACC(2, t1, t2);                             // compaction
 #ifdef MM_GATHER_PROF
@@ -502,17 +501,19 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
 #endif
         for (int j = lane; j < n; j += 64) {
             int g, px, py;
-            item_pixel(st, st->items[j], base, g, px, py);
+            const unsigned it = st->items[j];
+            item_pixel(st, it, base, g, px, py);
             FaceSlot& fs = st->slot[g];
-            const int bb = b;                                    // every group of the wave sweeps the same image
-            const size_t pix = (size_t)bb * hw + (size_t)py * a.W + px;
-            // issue every load of the item first; which ones matter depends on the pixel's owner
-            const int fi = a.face_idx[pix];
-            const float4 q0 = a.gp0[pix], q1 = a.gp1[pix];
+            const size_t pix = (size_t)b * hw + (size_t)py * a.W + px;   // every group of the wave sweeps the same image
+            // the sweep already knows which kind of hit this is: only the three loads that kind needs are issued
+            const bool owned = (it & 0x8000u) != 0;
             const float q2 = a.gp2[pix];
-            const float sq = a.softq[pix];
-            const int lf = a.lastf[pix];
-            if (fi == fs.f) {
+            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+            float sq = 0.f;
+            int lf = 0;
+            if (owned) { q0 = a.gp0[pix]; q1 = a.gp1[pix]; }
+            else { sq = a.softq[pix]; lf = a.lastf[pix]; }
+            if (owned) {
                 atomicAdd(&fs.acc[0], q0.x); atomicAdd(&fs.acc[1], q0.y); atomicAdd(&fs.acc[2], q0.z); atomicAdd(&fs.acc[3], q0.w);
                 atomicAdd(&fs.acc[4], q1.x); atomicAdd(&fs.acc[5], q1.y); atomicAdd(&fs.acc[6], q1.z); atomicAdd(&fs.acc[7], q1.w);
                 atomicAdd(&fs.acc[8], q2);

@@ -45,10 +45,9 @@ struct BwdArgs {
     const float* lights;
     const float* bg;
     const int32_t* face_idx;
-    const float* softq;
-    const int* lastf;
+    const float2* soft;
     const float* grad_rgba;
-    float4* gp0; float4* gp1; float* gp2;
+    float4* gp; float* gp2;
     float* dl_part;
     float* grad_bg;
     float* dTacc; unsigned* ticket;
@@ -225,9 +224,9 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             const float inrm = 1.f / nrm;
             const float dw0 = (G0 - Gm) * inrm, dw1 = (G1 - Gm) * inrm, dw2 = (G2 - Gm) * inrm;
             const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
-            a.gp0[pix] = make_float4((dw1 * (-cey) + dw2 * bey) * a.mult, (dw1 * cex + dw2 * (-bex)) * a.mult,
+            a.gp[pix * 2 + 0] = make_float4((dw1 * (-cey) + dw2 * bey) * a.mult, (dw1 * cex + dw2 * (-bex)) * a.mult,
                                      (dw0 * cey + dw2 * (-aey)) * a.mult, (dw0 * (-cex) + dw2 * aex) * a.mult);
-            a.gp1[pix] = make_float4((dw0 * (-bey) + dw1 * aey) * a.mult, (dw0 * bex + dw1 * (-aex)) * a.mult,
+            a.gp[pix * 2 + 1] = make_float4((dw0 * (-bey) + dw1 * aey) * a.mult, (dw0 * bex + dw1 * (-aex)) * a.mult,
                                      (w0 * dnx + w1 * dnx) + w2 * dnx, (w0 * dny + w1 * dny) + w2 * dny);
             a.gp2[pix] = (w0 * dnz + w1 * dnz) + w2 * dnz;
             if (dtcv[0] != 0.f || dtcv[1] != 0.f || dtcv[2] != 0.f) {
@@ -511,8 +510,8 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
             float sq = 0.f;
             int lf = 0;
-            if (owned) { q0 = a.gp0[pix]; q1 = a.gp1[pix]; }
-            else { sq = a.softq[pix]; lf = a.lastf[pix]; }
+            if (owned) { q0 = a.gp[pix * 2 + 0]; q1 = a.gp[pix * 2 + 1]; }
+            else { const float2 sl2 = a.soft[pix]; sq = sl2.x; lf = __float_as_int(sl2.y); }
             if (owned) {
                 atomicAdd(&fs.acc[0], q0.x); atomicAdd(&fs.acc[1], q0.y); atomicAdd(&fs.acc[2], q0.z); atomicAdd(&fs.acc[3], q0.w);
                 atomicAdd(&fs.acc[4], q1.x); atomicAdd(&fs.acc[5], q1.y); atomicAdd(&fs.acc[6], q1.z); atomicAdd(&fs.acc[7], q1.w);
@@ -591,8 +590,8 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.blocks_per_image = w.blocks_per_image;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.geo = w.geo; a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
-    a.face_idx = d->face_idx; a.softq = w.softq; a.lastf = w.lastf; a.grad_rgba = g->grad_rgba;
-    a.gp0 = w.gp0; a.gp1 = w.gp1; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
+    a.face_idx = d->face_idx; a.soft = w.soft; a.grad_rgba = g->grad_rgba;
+    a.gp = w.gp; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.dTacc = w.dTacc; a.ticket = w.ticket;
     a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;
     a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;

@@ -51,16 +51,16 @@ struct Workspace {
     float4* geo;           // (B,F,3)    {ax,ay,bx,by} {cx,cy,az,bz} {cz, unit normal z, box origin, box extent}; xy in multiplier
                            //            units; box = inflated pixel box px0 | py0 << 16, w | h << 16 (as int bits)
     uint64_t* binmask;     // (B,nbins,ceil(F/64)) bit f: the pixel box of face f, inflated by the soft-mask margin, touches the bin
-    float* softq;          // (B,H,W)    soft-mask product state of uncovered pixels: +prod(1-p) if no factor is 0,
+    float2* soft;          // (B,H,W)    .x = soft-mask product state of uncovered pixels: +prod(1-p) if no factor is 0,
                            //            -prod(non-zero factors) if exactly one factor is 0, 0 if two or more are
     float* dfxy;           // (B,F,3,2)  backward accumulator: dL/d face_vertices_image (unscaled NDC)
     float* dfn;            // (B,F,3)    backward accumulator: dL/d unit face normal (from the rasterised normals)
     float* dTacc;          // (B,12)     backward accumulator: dL/d camera transform (zeroed by the pixel backward)
     unsigned* ticket;      // (B)        arrival counter of the vertex-backward workgroups of an image (same)
-    int* lastf;            // (B,H,W)    uncovered pixels: id of the knum-th soft-mask face taken, INT_MAX if fewer were
-    float4* gp0;           // (B,H,W)    covered pixels: K2 contributions d/d(ax,ay,bx,by) of the pixel to its face
-    float4* gp1;           // (B,H,W)    d/d(cx,cy), d/d(nx,ny)
-    float* gp2;            // (B,H,W)    d/d(nz); uncovered pixels: dL/dalpha
+                           //            .y (as int bits) = id of the knum-th soft-mask face taken, INT_MAX if fewer were
+    float4* gp;            // (B,H,W,2)  covered pixels: K2 contributions of the pixel to its face {d/d(ax,ay,bx,by)} {d/d(cx,cy), d/d(nx,ny)}:
+                           //            one 32-byte record = one cache line per item
+    float* gp2;            // (B,H,W)    covered pixels: d/d(nz); uncovered pixels: dL/dalpha
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
@@ -89,14 +89,12 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.T = (float*)(p + o);          o += align256((size_t)B * 12 * sizeof(float));
     w.geo = (float4*)(p + o);       o += align256((size_t)B * F * 3 * sizeof(float4));
     w.binmask = (uint64_t*)(p + o); o += align256(w.binmask_bytes);
-    w.softq = (float*)(p + o);      o += align256((size_t)B * H * W * sizeof(float));
+    w.soft = (float2*)(p + o);      o += align256((size_t)B * H * W * sizeof(float2));
     w.dfxy = (float*)(p + o);       o += align256((size_t)B * F * 6 * sizeof(float));
     w.dfn = (float*)(p + o);        o += align256((size_t)B * F * 3 * sizeof(float));
     w.dTacc = (float*)(p + o);      o += align256((size_t)B * 12 * sizeof(float));
     w.ticket = (unsigned*)(p + o);  o += align256((size_t)B * sizeof(unsigned));
-    w.lastf = (int*)(p + o);        o += align256((size_t)B * H * W * sizeof(int));
-    w.gp0 = (float4*)(p + o);       o += align256((size_t)B * H * W * sizeof(float4));
-    w.gp1 = (float4*)(p + o);       o += align256((size_t)B * H * W * sizeof(float4));
+    w.gp = (float4*)(p + o);        o += align256((size_t)B * H * W * 2 * sizeof(float4));
     w.gp2 = (float*)(p + o);        o += align256((size_t)B * H * W * sizeof(float));
     w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));

@@ -241,7 +241,7 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.blocks_per_image = w.blocks_per_image;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
-    a.geo = w.geo; a.binmask = w.binmask; a.softq = w.softq; a.lastf = w.lastf; a.gt = d->fused_gt; a.ltot = w.ltot;
+    a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.gt = d->fused_gt; a.ltot = w.ltot;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     a.V = d->V; a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2];

@@ -20,8 +20,7 @@ struct RasterArgs {
     const float* textures;
     const float* lights;
     const float* bg;
-    float* softq;
-    int* lastf;
+    float2* soft;                           // per pixel {soft-mask product state, id of the knum-th face taken (int bits)}
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     // resident kernel only
@@ -284,8 +283,7 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
     if (t.in_img) {
         *(float4*)(a.rgba + pix * 4) = make_float4(out[0], out[1], out[2], out[3]);
         a.face_idx[pix] = h.f;
-        a.softq[pix] = (h.f >= 0 || ss.zeros >= 2) ? 0.f : (ss.zeros == 1 ? -ss.qnz : ss.qnz);
-        if (h.f < 0) a.lastf[pix] = ss.lastf;
+        a.soft[pix] = make_float2((h.f >= 0 || ss.zeros >= 2) ? 0.f : (ss.zeros == 1 ? -ss.qnz : ss.qnz), __int_as_float(ss.lastf));
         if (a.imnormal) { a.imnormal[pix * 3] = nx; a.imnormal[pix * 3 + 1] = ny; a.imnormal[pix * 3 + 2] = nz; }
     }
     if (a.gt) {                                                  // recon_data terms of this tile (networks.py:370-377)

@@ -1,4 +1,4 @@
-// mm_backward.hip -- pixel-stage backward of the render path for gfx950, without a single global atomic.
+// mm_backward.hip -- pixel-stage backward of the render path for gfx950, without a single floating-point atomic on HBM.
 //
 // kaolin's backward kernels (rasterize_backward_cuda, dibr_soft_mask_backward_cuda) and torch's grid_sampler backward
 // SCATTER per-pixel contributions with atomicAdd.  On MI355X an agent-scope float atomic is executed at the memory side

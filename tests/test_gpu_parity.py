@@ -324,7 +324,7 @@ def test_concurrent_steps_on_four_streams_match_the_serial_result(pkg):
             st.run(s)
     torch.cuda.synchronize()
     for st, (loss, grads, fidx, rgba) in zip(steps, refs):
-        assert abs(float(st.loss) - loss) < 1e-6
+        assert float(st.loss) == loss            # the fused loss is a sum of exact integer (fixed-point) sums: bitwise repeatable under overlap
         assert torch.equal(st.face_idx, fidx) and torch.equal(st.rgba, rgba)
         for k, g in grads.items():
             _close(st.grads[k].cpu().numpy(), g.cpu().numpy(), 2e-6)

@@ -65,12 +65,20 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
-def allreduce_mean_(tensors, bucket_bytes=64 << 20):
+def allreduce_mean_(tensors, bucket_bytes=64 << 20, local_weight=None):
     """In-place mean over ranks of a list of tensors, through few large flat buckets (see module docstring).
-    With equal per-rank batch sizes, per-rank mean losses + this average = the global-batch mean gradient."""
+    With equal per-rank batch sizes, per-rank mean losses + this average = the global-batch mean gradient.  When the shards are
+    NOT equal (shard_bounds hands the first B % world ranks one extra image) pass ``local_weight`` = this rank's batch size: the
+    result is then sum_r w_r * t_r / sum_r w_r, the global-batch mean of per-rank batch means."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     world = dist.get_world_size()
+    scale_in, scale_out = 1.0, 1.0 / world
+    if local_weight is not None:
+        first = next((t for t in tensors if t is not None), None)
+        wt = torch.tensor([float(local_weight)], dtype=torch.float64, device=first.device if first is not None else "cpu")
+        dist.all_reduce(wt, op=dist.ReduceOp.SUM)
+        scale_in, scale_out = float(local_weight), 1.0 / float(wt.item())
     bucket, size = [], 0
 
     def flush():
@@ -78,8 +86,10 @@ def allreduce_mean_(tensors, bucket_bytes=64 << 20):
         if not bucket:
             return
         flat = torch.cat([t.reshape(-1) for t in bucket])
+        if scale_in != 1.0:
+            flat.mul_(scale_in)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(world)
+        flat.mul_(scale_out)
         o = 0
         for t in bucket:
             t.copy_(flat[o:o + t.numel()].view_as(t))
@@ -95,6 +105,56 @@ def allreduce_mean_(tensors, bucket_bytes=64 << 20):
         bucket.append(t)
         size += nb
     flush()
+
+
+class GradAllReducer:
+    """Mean all-reduce of ONE flat gradient buffer per step, issued on a side stream so that it overlaps the next step's render
+    kernels (the render path needs no collective, so nothing on the compute streams ever waits for xGMI except the optimizer).
+
+    SURVEY 8(e): the message is the attribute-producing networks' gradient (135-200 MB fp32).  xGMI is point-to-point, a ring
+    is bound by one link per direction, so the buffer goes out as few LARGE chunks (default 64 MiB), back to back on the
+    communicator's stream.  Usage per step:  launch() after the backward that filled ``flat``;  wait() before ``flat`` is read
+    (optimizer) or overwritten (next backward).  CPU / gloo: same calls, asynchronous work handles instead of streams."""
+
+    def __init__(self, flat, chunk_bytes=64 << 20):
+        self.flat = flat
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        n = max(1, chunk_bytes // flat.element_size())
+        self.chunks = [flat[o:o + n] for o in range(0, flat.numel(), n)]
+        self.cuda = flat.is_cuda
+        self.side = torch.cuda.Stream(flat.device) if self.cuda and self.world > 1 else None
+        self.pending = []
+        self.launched = 0
+
+    def launch(self):
+        if self.world == 1:
+            return
+        self.wait()                                              # at most one reduction of this buffer in flight
+        if self.cuda:
+            self.side.wait_stream(torch.cuda.current_stream(self.flat.device))    # the gradients must have been produced
+            with torch.cuda.stream(self.side):
+                for c in self.chunks:
+                    dist.all_reduce(c, op=dist.ReduceOp.SUM)     # enqueued after everything on `side`; the host does not block
+                    c.mul_(1.0 / self.world)
+        else:
+            self.pending = [dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True) for c in self.chunks]
+        self.launched += 1
+
+    def wait(self):
+        """Make the current stream (CPU: the host) wait for the reduction in flight, if any."""
+        if self.world == 1:
+            return
+        if self.cuda:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+        else:
+            for w in self.pending:
+                w.wait()
+            if self.pending:
+                self.flat.mul_(1.0 / self.world)
+            self.pending = []
+
+    def bytes_per_step(self):
+        return self.flat.numel() * self.flat.element_size()
 
 
 def broadcast_(tensor, src=0):

@@ -87,6 +87,28 @@ class RenderLossStep:
         self.graph = None
         self.ev_render = self.ev_recon = None
 
+    def set_inputs(self, attributes, gt):
+        """Point the step at another batch of the SAME shapes (device tensors, fp32, dense): only the descriptors' input
+        pointers change, every output / scratch buffer is reused.  Lets a loop rotate through more input data than the
+        256 MiB Infinity Cache holds without one workspace per batch.  Not valid between capture() and replay()."""
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        new = {k: (f32(attributes[k]) if attributes.get(k) is not None else None) for k in LEAVES}
+        for k, v in new.items():
+            old = self.inp[k]
+            if (v is None) != (old is None) or (v is not None and (v.shape != old.shape or v.device != old.device)):
+                raise RuntimeError("set_inputs: '%s' does not match the planned shape" % k)
+        gt = f32(gt)
+        if gt.shape != self.gt.shape or gt.device != self.gt.device:
+            raise RuntimeError("set_inputs: gt does not match the planned shape")
+        self.inp, self.gt = new, gt
+        i, d = self.inp, self.d
+        d.vertices, d.textures, d.lights = N.ptr(i["vertices"]), N.ptr(i["textures"]), N.ptr(i["lights"])
+        d.bg = N.ptr(i["bg"] if self.no_mask else None)
+        d.azimuths, d.elevations, d.distances, d.biases = N.ptr(i["azimuths"]), N.ptr(i["elevations"]), N.ptr(i["distances"]), N.ptr(i["biases"])
+        self.r.gt = N.ptr(self.gt)
+        if self.fused:
+            d.fused_gt = N.ptr(self.gt)
+
     def run(self, stream=None):
         """Enqueue one full step on ``stream`` (a torch.cuda.Stream; default: the current stream)."""
         L = N.lib()

@@ -4,16 +4,26 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch: mm_render_forward -> mm_recon_data_forward ->
-mm_recon_data_backward -> mm_render_backward (gradients to vertices, textures, lights, bg, distances, elevations,
-azimuths, biases), inputs resident in HBM.  Every step does all of that work on a full B=48 batch; successive steps are
-independent (the reference's trainer issues four independent renders per iteration, trainer.py:276,345,347,367) and are
-enqueued round-robin on --streams HIP streams (default 4, one hardware queue each) so that the steps' kernels overlap;
-"value_one_stream" is the same loop on a single stream.  Workload at every N: BASELINE config 2 (template smpl_uv_642, B=48 per
-GPU, 128x128, texture 256x128, no_mask).  The batch shards across ranks with no data-path collective (weak scaling).
-Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path over one batch of B images: render forward (+ fused recon_data forward) -> recon_data
+backward -> render backward, gradients to vertices, textures, lights, bg, distances, elevations, azimuths, biases; inputs are
+resident in HBM, and every step does all of that work on a full batch.  Workload at every N: BASELINE config 2 (template
+smpl_uv_642, B=48 per GPU, 128x128, texture 256x128, no_mask).
+
+What the ONE JSON line (rank 0) reports, all on the same workload:
+  value             K steps enqueued round-robin on --streams HIP streams (default 4): successive steps are independent batches
+                    (the reference's trainer issues four renders per iteration, trainer.py:276,345,347,367) and their kernels overlap.
+                    This is the whole-job throughput of the C-ABI path when the caller keeps several batches in flight.
+  value_one_stream  the same K steps strictly one after the other on ONE stream: what a caller gets who renders one batch at a time.
+  value_api         DiffRender.render -> DiffRender.recon_data -> loss.backward() through the torch.autograd wrappers (the calls
+                    trainer.py makes), one stream, imnormal materialised like the reference does.
+Every stream rotates through --rotate distinct synthetic batches (default 8 per stream: > 256 MiB of inputs in total, more than
+the Infinity Cache holds), so inputs are not cache-resident from one step to the next.
+N > 1: the batch shards across ranks with no data-path collective (weak scaling); what crosses xGMI in a training step is the
+gradient of the attribute-producing networks, so every step also all-reduces (mean) a flat fp32 buffer of --grad-mb megabytes
+(default 135 = the reference's custom encoders) on a side stream, overlapped with the next step.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -23,18 +33,20 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # One hardware queue per stream: HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, and two of the bench's streams
-# landing on one queue serialise their steps (475 k instead of 600 k images/s); main() therefore picks, untimed, a set of streams
-# that do not share one.  Four queues for four streams measured best (615 k; 5: 606 k, 8: 597 k, fewer than 4: < 490 k).
+# landing on one queue serialise their steps; main() therefore picks, untimed, a set of streams that do not share one.
 # Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+CLOCK_MHZ = 2400.0          # MI355X_MICROARCH.md: max shader clock
+SIMDS = 1024                # 256 CUs x 4 SIMD-32
+VALU_CYCLES = 2.0           # cycles a wave64 VALU instruction occupies its SIMD-32 (MI355X_MICROARCH.md; measured on the box by
+                            # profiles/tools/valu_calib.hip -> profiles/r02_valu_calibration.json)
 
 CONFIGS = {
     # name: (template, B, image_size, ratio)
     "config2": ("smpl_uv_642", 48, 128, 1),
     "config1": ("sphere", 4, 64, 1),
-    "config2x3": ("smpl_uv_642", 144, 128, 1),      # experiment: three config-2 batches in one call
     "config2x8": ("smpl_uv_642", 384, 128, 1),
     "market": ("smpl_uv_642", 48, 64, 2),
     "config3": ("ellipsoid", 48, 256, 1),
@@ -50,13 +62,47 @@ def algorithmic_bytes(kernel, B, F, V, HW, T):
         "raster_fwd": 52 * F + 12 * T + 20 * HW,
         "recon_partial": 32 * HW,
         "recon_bwd": 48 * HW,
-        "bin": 16 * F,
         "order": 0,
         "pixel_bwd": 52 * F + 12 * T + 20 * HW,
         "gather_bwd": 36 * F + 12 * T,
         "vertex_bwd": 36 * F + 24 * V,
     }.get(kernel)
     return None if per_image is None else per_image * B
+
+
+def csrc_digest():
+    """sha of the kernel sources: the committed PMC summaries (profiles/*_latest.json) carry the digest they were measured
+    on, so a bench line never quotes counters of kernels that have changed since."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "3d-magic-mirror_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".h")):
+            h.update(n.encode()); h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_counters(name, config):
+    """(per-kernel dict or None, note) from profiles/<name>_latest.json for this config, only if measured on these sources."""
+    path = os.path.join(ROOT, "profiles", name + "_latest.json")
+    try:
+        j = json.load(open(path))
+    except Exception:
+        return None, "no " + os.path.basename(path)
+    if config not in j:
+        return None, "not collected for " + config
+    if j.get("csrc_digest", {}).get(config) != csrc_digest():
+        return None, "stale: kernels changed since the PMC pass (%s)" % j.get("note", "")
+    return j[config], j.get("note", "")
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def main():
@@ -66,14 +112,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="config2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="eager", choices=["hipgraph", "eager", "torch"],
-                    help="hipgraph: whole step replayed as one HIP graph; eager: 4 ABI calls per step; torch: DiffRender autograd API")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="successive (independent) steps are enqueued round-robin on this many HIP streams, each with its own buffers")
+                    help="what `value` times.  eager: C-ABI calls per step on --streams streams; hipgraph: the step replayed as one HIP "
+                         "graph; torch: the DiffRender autograd API (same as value_api)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps are enqueued on round-robin")
+    ap.add_argument("--rotate", type=int, default=8, help="distinct synthetic input batches per stream, visited in turn")
     ap.add_argument("--unfused", action="store_true", help="recon_data as its own three launches instead of folded into the render kernels")
     ap.add_argument("--resident", action="store_true", help="opt into the LDS-resident forward kernel (MM_OPT_RESIDENT)")
     ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed run-in before the warmup steps (clock ramp)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget, all threads (0 disables)")
+    ap.add_argument("--cpu-single-seconds", type=float, default=8.0, help="CPU-baseline budget, one thread (0 disables)")
     ap.add_argument("--profile-steps", type=int, default=30, help="extra eager steps with per-kernel HIP events")
+    ap.add_argument("--api-steps", type=int, default=200, help="steps of the DiffRender autograd path timed for value_api (0 disables)")
+    ap.add_argument("--trainer-steps", type=int, default=8, help="trainer-shaped config-3 steps timed for value_config3 (0 disables; N=1 only)")
+    ap.add_argument("--grad-mb", type=float, default=None, help="fp32 gradient bytes all-reduced per step over RCCL (default 135 when N>1, else 0)")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,9 +134,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE\n" % (world, args.gpus))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE\n" % (world, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -94,66 +144,121 @@ def main():
 
     pkg = importlib.import_module("3d-magic-mirror_amd")
     stepmod = importlib.import_module("3d-magic-mirror_amd.step")
+    par = importlib.import_module("3d-magic-mirror_amd.parallel")
     name, B, S, ratio = CONFIGS[args.config]
-    dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio, emit_imnormal=False)
+    tpath = os.path.join(ROOT, "tests", "golden", "templates", name + ".npz")
+    dr = pkg.DiffRender(tpath, S, ratio=ratio, emit_imnormal=False)
     if args.resident:
         dr.options = pkg._native.OPT_RESIDENT
     H, W = dr.render_height, dr.image_size
-    att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=rank)
-    datt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}
-    gtd = gt.to(dev)
-    Ht, Wt = att["textures"].shape[2:]
+    nstreams = max(1, args.streams) if args.mode == "eager" else 1
+    nrot = max(1, args.rotate)
+
+    def make_batch(seed):
+        att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=seed)
+        return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}, gt.to(dev), att, gt
+
+    # batches[s][r]: rotation slot r of stream s; batch (0,0) is the one the CPU baseline and the parity tests use (seed = rank)
+    batches, host0 = [], None
+    for s_ in range(nstreams):
+        row = []
+        for r_ in range(nrot):
+            datt, gtd, att, gt = make_batch(rank + 1000 * s_ + 100000 * r_)
+            if host0 is None:
+                host0 = (att, gt)
+            row.append((datt, gtd))
+        batches.append(row)
+    att0, gt0 = host0
+    Ht, Wt = att0["textures"].shape[2:]
+    input_bytes = sum(v.numel() * 4 for v in batches[0][0][0].values() if torch.is_tensor(v)) + batches[0][0][1].numel() * 4
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    step = stepmod.RenderLossStep(dr, datt, gtd, no_mask=True, fused=not args.unfused)
+    def timed(fn, n):
+        """n calls of fn bracketed by barrier + synchronize on both sides; max over ranks."""
+        barrier(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev); barrier()
+        return par.max_over_ranks(time.perf_counter() - t0, dev)
+
+    steps_ = [stepmod.RenderLossStep(dr, batches[s_][0][0], batches[s_][0][1], no_mask=True, fused=not args.unfused) for s_ in range(nstreams)]
+    step = steps_[0]
+
+    # ---- the gradient all-reduce a data-parallel trainer adds to every step (N > 1) ---------------------------------------------
+    grad_mb = args.grad_mb if args.grad_mb is not None else (135.0 if world > 1 else 0.0)
+    reducer = None
+    if world > 1 and grad_mb > 0:
+        flat = torch.full((int(grad_mb * 1e6 / 4),), float(rank + 1), device=dev, dtype=torch.float32)
+        reducer = par.GradAllReducer(flat)
+
+    streams_ = [torch.cuda.current_stream(dev)]
+    if args.mode == "eager" and nstreams > 1:
+        # HIP maps streams onto a fixed number of hardware queues; two of our streams landing on ONE queue serialise their steps.
+        # Untimed: try a few sets out of twice as many streams and keep the best.
+        pool = [torch.cuda.Stream(dev) for _ in range(2 * nstreams)]
+        cands = [pool[:nstreams], pool[nstreams:], pool[0::2], pool[1::2]]
+        rates = []
+        for cand in cands:
+            for i in range(3 * nstreams):
+                steps_[i % nstreams].run(cand[i % nstreams])
+            torch.cuda.synchronize(dev)
+            c0 = time.perf_counter()
+            for i in range(24 * nstreams):
+                steps_[i % nstreams].run(cand[i % nstreams])
+            torch.cuda.synchronize(dev)
+            rates.append(24 * nstreams / (time.perf_counter() - c0))
+        streams_ = cands[int(np.argmax(rates))]
+
+    ctr = [0]
+
+    def one_multi():
+        k = ctr[0]; ctr[0] += 1
+        s_ = k % nstreams
+        st = steps_[s_]
+        if nrot > 1:
+            st.set_inputs(*batches[s_][(k // nstreams) % nrot])
+        st.run(streams_[s_] if nstreams > 1 else None)
+        if reducer is not None:
+            reducer.launch()          # waits (on its own stream) for the current stream only; overlaps the following steps
+
+    ctr1 = [0]
+
+    def one_single():
+        k = ctr1[0]; ctr1[0] += 1
+        if nrot > 1:
+            step.set_inputs(*batches[0][k % nrot])
+        step.run()
+        if reducer is not None:
+            reducer.launch()
+
+    # the DiffRender autograd path (what trainer.py calls): imnormal materialised, workspace from the per-object pool
+    dr_api = pkg.DiffRender(tpath, S, ratio=ratio)
+    leaves_rot = [{k: batches[0][r_][0][k].clone().requires_grad_(True) for k in stepmod.LEAVES} for r_ in range(nrot)]
+    ctr2 = [0]
+
+    def one_api():
+        k = ctr2[0] % nrot; ctr2[0] += 1
+        lv = leaves_rot[k]
+        for v in lv.values():
+            v.grad = None
+        a = dict(batches[0][k][0]); a.update(lv)
+        rgbs, _ = dr_api.render(no_mask=True, **a)
+        dr_api.recon_data(rgbs, batches[0][k][1], no_mask=True).backward()
+
     if args.mode == "hipgraph":
         step.capture()
         one = step.replay
-    elif args.mode == "eager" and args.streams > 1:
-        # every stream renders its OWN batch (distinct synthetic draws): no input is shared between the steps in flight
-        steps_ = [step]
-        for i in range(1, args.streams):
-            att_i, gt_i = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=1000 * i + rank)
-            datt_i = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att_i.items()}
-            steps_.append(stepmod.RenderLossStep(dr, datt_i, gt_i.to(dev), no_mask=True, fused=not args.unfused))
-        # HIP maps streams onto a fixed number of hardware queues; two of our streams landing on ONE queue serialise their steps
-        # (measured: 475 k instead of 600 k images/s).  Untimed: try a few sets out of twice as many streams and keep the best.
-        pool = [torch.cuda.Stream(dev) for _ in range(2 * len(steps_))]
-        n_ = len(steps_)
-        cands = [pool[:n_], pool[n_:], pool[0::2], pool[1::2]]
-        rates = []
-        for cand in cands:
-            for i in range(3 * n_):
-                steps_[i % n_].run(cand[i % n_])
-            torch.cuda.synchronize(dev)
-            c0 = time.perf_counter()
-            for i in range(24 * n_):
-                steps_[i % n_].run(cand[i % n_])
-            torch.cuda.synchronize(dev)
-            rates.append(24 * n_ / (time.perf_counter() - c0))
-        streams_ = cands[int(np.argmax(rates))]
-        ctr = [0]
-
-        def one():
-            i = ctr[0] % len(steps_); ctr[0] += 1
-            steps_[i].run(streams_[i])
-    elif args.mode == "eager":
-        one = step.run
+    elif args.mode == "torch":
+        one = one_api
     else:
-        leaves = {k: datt[k].clone().requires_grad_(True) for k in stepmod.LEAVES}
+        one = one_multi
 
-        def one():
-            for v in leaves.values():
-                v.grad = None
-            a = dict(datt); a.update(leaves)
-            rgbs, _ = dr.render(no_mask=True, **a)
-            dr.recon_data(rgbs, gtd, no_mask=True).backward()
-
-    # untimed settling phase before the W warmup steps: clocks and queues of a device that has just been idle (or has just
-    # finished another process's work) ramp over hundreds of milliseconds, longer than W short steps last
+    # untimed settling phase before the W warmup steps: clocks and queues of a device that has just been idle ramp over hundreds of
+    # milliseconds, longer than W short steps last
     settle = time.perf_counter()
     while time.perf_counter() - settle < args.settle_seconds:
         for _ in range(32):
@@ -161,31 +266,29 @@ def main():
         torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         one()
-    barrier(); torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one()
-    torch.cuda.synchronize(dev); barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if reducer is not None:
+        reducer.wait()
+    elapsed = timed(lambda: one(), args.steps)
+    if reducer is not None:
+        reducer.wait(); torch.cuda.synchronize(dev)
     loss_value = float(step.loss) if args.mode != "torch" else None
-    # the same K steps strictly one after the other on one stream (no overlap between steps), for reference
-    one_stream = None
-    if args.mode == "eager" and args.streams > 1:
-        torch.cuda.synchronize(dev); barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step.run()
-        torch.cuda.synchronize(dev); barrier()
-        e1 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([e1], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e1 = float(t.item())
+
+    one_stream = api_value = allreduce_ms = None
+    if args.mode == "eager":
+        for _ in range(min(args.warmup, 20)):
+            one_single()
+        e1 = timed(one_single, args.steps)
         one_stream = round(world * B * args.steps / e1, 1)
+    if args.api_steps > 0:
+        for _ in range(10):
+            one_api()
+        e2 = timed(one_api, args.api_steps)
+        api_value = round(world * B * args.api_steps / e2, 1)
+    if reducer is not None:
+        # the collective alone (nothing to overlap with): K reductions back to back
+        reducer.wait(); torch.cuda.synchronize(dev)
+        e3 = timed(lambda: (reducer.launch(), reducer.wait()), 10)
+        allreduce_ms = round(e3 / 10 * 1e3, 3)
 
     # ---- per-kernel durations (HIP events recorded by the library around each launch, same stream) ------------
     roofline, kernels_us = None, {}
@@ -193,6 +296,8 @@ def main():
         step.enable_profiling()
         acc = {}
         for i in range(args.profile_steps + 3):
+            if nrot > 1:
+                step.set_inputs(*batches[0][i % nrot])
             step.run()
             torch.cuda.synchronize(dev)
             if i >= 3:
@@ -203,65 +308,97 @@ def main():
         dom = max(kernels_us, key=kernels_us.get)
         nbytes = algorithmic_bytes(dom, B, dr.num_faces, dr.num_vertices, H * W, Ht * Wt)
         achieved = nbytes / (kernels_us[dom] * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.config, {}).get(dom)
-            except Exception:
-                traffic = None
+        traffic_all, tnote = load_counters("traffic", args.config)
+        step_bytes = (140 * dr.num_faces + 36 * Ht * Wt + 56 * H * W) * B
+        step_us_one = (1e6 * B * world / one_stream) if one_stream else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(kernels_us[dom], 3)}
-        # What actually bounds this path is vector-instruction issue, not HBM: a wave64 VALU instruction holds
-        # its SIMD16 for 4 cycles, so one step cannot take less than sum(SQ_INSTS_VALU) * 4 / (1024 SIMDs * 2.4 GHz).  The counts
-        # come from the committed rocprofv3 --pmc pass of this same workload (profiles/valu_latest.json).
-        vpath = os.path.join(ROOT, "profiles", "valu_latest.json")
-        if os.path.exists(vpath):
-            try:
-                insts = json.load(open(vpath)).get(args.config)
-                if insts:
-                    floor_us = sum(insts.values()) * 4.0 / 1024.0 / 2400.0
-                    step_us = elapsed / args.steps * 1e6 / 1.0
-                    roofline["valu_issue"] = {"insts_per_step": int(sum(insts.values())), "floor_us_per_step": round(floor_us, 2),
-                                              "measured_us_per_step": round(step_us, 2), "frac": round(floor_us / step_us, 4),
-                                              "dominant_kernel_frac": round(insts.get(dom, 0) * 4.0 / 1024.0 / 2400.0 / kernels_us[dom], 4)}
-            except Exception:
-                pass
+                    "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": (traffic_all or {}).get(dom), "traffic_note": tnote,
+                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(kernels_us[dom], 3),
+                    "whole_step": {"algorithmic_bytes": step_bytes,
+                                   "frac_overlapped": round(step_bytes / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBPS, 5),
+                                   "frac_one_stream": round(step_bytes / (step_us_one * 1e-6) / 1e9 / PEAK_HBM_GBPS, 5) if step_us_one else None}}
+        # Second roof, reported beside the HBM one: vector-instruction issue.  A wave64 VALU instruction occupies its SIMD-32 for
+        # VALU_CYCLES cycles (calibrated on the box: profiles/r02_valu_calibration.json), so a step cannot take less than
+        # sum(SQ_INSTS_VALU) * VALU_CYCLES / (1024 SIMDs * 2.4 GHz).  Counts: the committed rocprofv3 --pmc pass of this workload.
+        insts, vnote = load_counters("valu", args.config)
+        if insts:
+            tot = sum(v for v in insts.values() if isinstance(v, (int, float)))
+            floor_us = tot * VALU_CYCLES / SIMDS / CLOCK_MHZ
+            step_us = elapsed / args.steps * 1e6
+            roofline["valu_issue"] = {"insts_per_step": int(tot), "cycles_per_inst": VALU_CYCLES, "floor_us_per_step": round(floor_us, 2),
+                                      "measured_us_per_step": round(step_us, 2), "frac": round(floor_us / step_us, 4),
+                                      "frac_one_stream": round(floor_us / step_us_one, 4) if step_us_one else None,
+                                      "dominant_kernel_frac": round(insts.get(dom, 0) * VALU_CYCLES / SIMDS / CLOCK_MHZ / kernels_us[dom], 4)}
+        else:
+            roofline["valu_issue"] = {"note": vnote}
+
+    # ---- trainer-shaped config-3 step (BASELINE config 3): encoder -> 4 renders -> recon_data -> regularisers -> backward -> Adam
+    config3 = None
+    if rank == 0 and world == 1 and args.trainer_steps > 0:
+        try:
+            ts = importlib.import_module("3d-magic-mirror_amd.trainer_step")
+            config3 = ts.bench(dev, steps=args.trainer_steps, warmup=3)
+        except Exception as e:                                    # never lose the headline line to the secondary measurement
+            config3 = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- CPU baseline: the oracle's step (C restatement of the kaolin DIB-R semantics) on the host cores ----------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle
-        inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att.items()}
+        inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att0.items()}
         inp["faces"] = dr.faces.numpy().astype(np.int32)
         inp["face_uvs"] = dr.face_uvs.numpy()[0]
         proj = dr.cam_proj.numpy().reshape(3)
-        nb = min(B, 16)
-        sub = {k: (v[:nb] if isinstance(v, np.ndarray) and k not in ("faces", "face_uvs") else v) for k, v in inp.items()}
-        oracle.step(sub, gt.numpy()[:nb], H, W, True, proj, image_weight=dr.image_weight)     # warm
-        n, c0 = 0, time.perf_counter()
-        while time.perf_counter() - c0 < args.cpu_seconds:
-            oracle.step(sub, gt.numpy()[:nb], H, W, True, proj, image_weight=dr.image_weight)
-            n += nb
-        cdt = time.perf_counter() - c0
-        cpu = {"value": round(n / cdt, 2), "unit": "images/s", "cores": oracle.num_threads(), "kind": "port",
-               "sample": "%d steps of the first %d images of the same batch (%s, %dx%d), render+loss+backward, OpenMP over "
-                         "(image,row)/(image)" % (n // nb, nb, name, H, W)}
+        gtn = gt0.numpy()
+
+        def cpu_rate(nb, budget):
+            sub = {k: (v[:nb] if isinstance(v, np.ndarray) and k not in ("faces", "face_uvs") else v) for k, v in inp.items()}
+            oracle.step(sub, gtn[:nb], H, W, True, proj, image_weight=dr.image_weight)     # warm
+            n, c0 = 0, time.perf_counter()
+            while n == 0 or time.perf_counter() - c0 < budget:
+                oracle.step(sub, gtn[:nb], H, W, True, proj, image_weight=dr.image_weight)
+                n += nb
+            return n / (time.perf_counter() - c0), n // nb
+
+        nthreads = oracle.num_threads()
+        rate_all, n_all = cpu_rate(B, args.cpu_seconds)
+        single = None
+        if args.cpu_single_seconds > 0:
+            nb1 = min(B, 4)
+            oracle.set_threads(1)
+            rate_1, n_1 = cpu_rate(nb1, args.cpu_single_seconds)
+            oracle.set_threads(nthreads)
+            single = {"value": round(rate_1, 3), "cores": 1, "sample": "%d steps of the first %d images" % (n_1, nb1)}
+        cpu = {"value": round(rate_all, 2), "unit": "images/s", "cores": nthreads, "kind": "port", "cpu_model": cpu_model(),
+               "single_thread": single,
+               "sample": "%d steps of the full batch of %d images (%s, %dx%d), render+loss+backward, OpenMP over (image,row)/(image); "
+                         "CPU restatement of the kaolin DIB-R semantics, not kaolin" % (n_all, B, name, H, W)}
 
     if rank == 0:
         total_images = world * B * args.steps
         out = {
-            "metric": "render+loss+bwd images/sec at B=48 128x128, ~1.3k faces",
+            "metric": "render+loss+bwd images/sec at B=%d %dx%d, ~%.1fk faces" % (B, H, W, dr.num_faces / 1000.0),
             "value": round(total_images / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: template %s (V=%d,F=%d), B=%d per GPU, %dx%d, texture %dx%d, no_mask, fwd+loss+bwd to all "
                                    "8 inputs" % (args.config, name, dr.num_vertices, dr.num_faces, B, H, W, Ht, Wt),
-                       "mode": args.mode, "streams": args.streams if args.mode == "eager" else 1, "fused_loss": not args.unfused,
-                       "sharding": "batch, no data-path collective"},
-            "value_one_stream": one_stream, "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},
+                       "value_is": {"eager": "%d independent steps in flight on %d HIP streams (C ABI, fused loss); one batch at a time = "
+                                             "value_one_stream; the DiffRender autograd API = value_api" % (nstreams, nstreams),
+                                    "hipgraph": "one step replayed as a HIP graph on one stream",
+                                    "torch": "the DiffRender autograd API on one stream"}[args.mode],
+                       "mode": args.mode, "streams": nstreams, "fused_loss": not args.unfused,
+                       "inputs": "%d distinct batches per stream visited in turn (%.0f MB of inputs in total; Infinity Cache 256 MiB)"
+                                 % (nrot, nstreams * nrot * input_bytes / 1e6),
+                       "imnormal": "not materialised in value / value_one_stream (visualise-only output, networks.py:320); materialised in value_api",
+                       "sharding": "batch, no data-path collective",
+                       "grad_allreduce": None if reducer is None else
+                                         {"mb_per_step_per_rank": round(reducer.bytes_per_step() / 1e6, 1), "per_step": True, "overlapped": True,
+                                          "launched": reducer.launched, "alone_ms": allreduce_ms}},
+            "value_one_stream": one_stream, "value_api": api_value,
+            "value_config3": None if not config3 else config3.get("images_per_s"), "config3": config3,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},
             "loss": loss_value,
         }
         print(json.dumps(out))

@@ -40,7 +40,7 @@ def _close(got, ref, tol=1e-4):
     ("sphere2", 2, 40, 1, False, 6),        # 5 120 faces, white background
     ("smpl_uv_642", 48, 128, 1, True, 0),   # BASELINE config 2 at FULL size: the bench's batch, pixel for pixel
     ("smpl_uv_642", 48, 64, 2, True, 7),    # BASELINE config 4 (Market 128x64) at full size
-    ("ellipsoid", 6, 256, 1, True, 8),      # BASELINE config 3 resolution (256x256, 16-px bins, 1024 tiles per image)
+    ("ellipsoid", 48, 256, 1, True, 8),     # BASELINE config 3's render at FULL size (B=48, 256x256, texture 512x256)
 ])
 def test_render_loss_backward_matches_oracle(pkg, oracle, name, B, S, ratio, no_mask, seed):
     dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, ratio=ratio, seed=seed, no_mask=no_mask)

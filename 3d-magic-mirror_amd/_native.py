@@ -20,8 +20,7 @@ c_p = ctypes.c_void_p
 class MMRenderDesc(ctypes.Structure):
     _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("V", c_i), ("F", c_i), ("Ht", c_i), ("Wt", c_i), ("no_mask", c_i),
                 ("knum", c_i), ("proj", c_f * 3), ("sigmainv", c_f), ("boxlen", c_f), ("multiplier", c_f), ("eps", c_f),
-                ("faces", c_p), ("face_uvs", c_p), ("vc_offsets", c_p), ("vc_items", c_p), ("uvt_offsets", c_p), ("uvt_faces", c_p),
-                ("uvt_size", c_i), ("face_order", c_p),
+                ("faces", c_p), ("face_uvs", c_p), ("vc_offsets", c_p), ("vc_items", c_p), ("face_order", c_p),
                 ("vertices", c_p), ("textures", c_p), ("lights", c_p), ("bg", c_p), ("azimuths", c_p), ("elevations", c_p),
                 ("distances", c_p), ("biases", c_p),
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
@@ -75,32 +74,84 @@ class MMMeshRegGrads(ctypes.Structure):
     _fields_ = [("weights", c_p), ("grad_vertices", c_p), ("grad_delta_vertices", c_p), ("grad_face_normals", c_p)]
 
 
-PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "bin", "order")
-UV_TILE = 32
-OPT_STREAMED = 1
-OPT_RESIDENT = 2
+class MMPrepareDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("V", c_i), ("F", c_i), ("proj", c_f * 3), ("faces", c_p), ("vc_offsets", c_p), ("vc_items", c_p),
+                ("vertices", c_p), ("transform", c_p), ("face_vertices_camera", c_p), ("face_vertices_image", c_p), ("face_normals", c_p),
+                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
+class MMPrepareGrads(ctypes.Structure):
+    _fields_ = [("grad_face_vertices_camera", c_p), ("grad_face_vertices_image", c_p), ("grad_face_normals", c_p),
+                ("grad_vertices", c_p), ("grad_transform", c_p)]
+
+
+class MMDibrDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("F", c_i), ("D", c_i), ("knum", c_i), ("sigmainv", c_f), ("boxlen", c_f),
+                ("multiplier", c_f), ("eps", c_f), ("face_vertices_z", c_p), ("face_vertices_image", c_p), ("face_features", c_p),
+                ("face_normals_z", c_p), ("interpolated_features", c_p), ("soft_mask", c_p), ("face_idx", c_p),
+                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("options", c_i)]
+
+
+class MMDibrGrads(ctypes.Structure):
+    _fields_ = [("grad_interpolated_features", c_p), ("grad_soft_mask", c_p), ("grad_face_vertices_image", c_p), ("grad_face_features", c_p)]
+
+
+class MMTexMapDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("N", c_i), ("C", c_i), ("Ht", c_i), ("Wt", c_i), ("mode", c_i), ("uv", c_p), ("textures", c_p), ("out", c_p)]
+
+
+class MMTexMapGrads(ctypes.Structure):
+    _fields_ = [("grad_out", c_p), ("grad_uv", c_p), ("grad_textures", c_p)]
+
+
+class MMShDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("N", c_i), ("normals", c_p), ("lights", c_p), ("out", c_p)]
+
+
+class MMShGrads(ctypes.Structure):
+    _fields_ = [("grad_out", c_p), ("grad_normals", c_p), ("grad_lights", c_p)]
+
+
+class MMMaskIouDesc(ctypes.Structure):
+    _fields_ = [("B", c_i), ("N", c_i), ("lhs", c_p), ("rhs", c_p), ("sums", c_p), ("loss", c_p)]
+
+
+PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "order")
+ABI_VERSION = 2
+OPT_CULL_STRICT, OPT_SOFT_SKIP_CULLED, OPT_BBOX_HALF_OPEN, OPT_BARY_ONE_MINUS, OPT_SH_ORDER_XYZ = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_recon_query_workspace",
-           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_uv_tiles", "mm_nearest_neighbour", "mm_status_string", "mm_last_error_detail",
+           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_nearest_neighbour", "mm_status_string", "mm_last_error_detail",
            "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward", "mm_texture_flow_forward",
            "mm_texture_flow_backward", "mm_attribute_loss_query_workspace", "mm_attribute_loss_forward",
            "mm_attribute_loss_backward",
+           "mm_prepare_vertices_query_workspace", "mm_prepare_vertices_forward", "mm_prepare_vertices_backward",
+           "mm_face_normals_forward", "mm_face_normals_backward", "mm_dibr_query_workspace", "mm_dibr_rasterization_forward",
+           "mm_dibr_rasterization_backward", "mm_texture_mapping_forward", "mm_texture_mapping_backward", "mm_sh_lighting_forward",
+           "mm_sh_lighting_backward", "mm_mask_iou_forward", "mm_mask_iou_backward", "mm_struct_size",
            "mm_abi_version")
 
 
+_STRUCT_IDS = None
+
+
 def lib():
-    """Load libmm_render.so (building it in-tree first if the sources are newer and hipcc is available)."""
+    """Load libmm_render.so (building it in-tree first, under a file lock, if the sources are newer and hipcc is available).
+    A failed rebuild raises -- a stale library is never used silently -- and the library's ABI version and struct sizes are
+    checked against this binding's mirror of include/mm_render.h."""
     global _LIB
     if _LIB is not None:
         return _LIB
-    try:
-        from . import build_native
-        if build_native.needs_build() and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
-            build_native.build()
-    except Exception as e:  # a stale-but-present library is still usable; a missing one is fatal below
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("libmm_render.so is missing and could not be built: %s" % e)
+    from . import build_native
+    if build_native.needs_build():
+        if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            try:
+                build_native.build()
+            except Exception as e:
+                raise RuntimeError("libmm_render.so is out of date and rebuilding it failed: %s" % e)
+        elif os.path.exists(LIB_PATH):
+            raise RuntimeError("libmm_render.so is older than its sources and hipcc is not available to rebuild it")
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libmm_render.so not found at %s (run __graft_entry__.build())" % LIB_PATH)
     L = ctypes.CDLL(LIB_PATH)
@@ -126,12 +177,39 @@ def lib():
     L.mm_attribute_loss_backward.argtypes = [ctypes.POINTER(MMAttLossDesc), ctypes.POINTER(MMAttLossGrads), c_p]
     L.mm_texture_flow_forward.argtypes = [ctypes.POINTER(MMTexFlowDesc), c_p]
     L.mm_texture_flow_backward.argtypes = [ctypes.POINTER(MMTexFlowDesc), ctypes.POINTER(MMTexFlowGrads), c_p]
+    P = ctypes.POINTER
+    L.mm_prepare_vertices_query_workspace.restype = ctypes.c_size_t
+    L.mm_prepare_vertices_query_workspace.argtypes = [P(MMPrepareDesc)]
+    L.mm_prepare_vertices_forward.argtypes = [P(MMPrepareDesc), c_p]
+    L.mm_prepare_vertices_backward.argtypes = [P(MMPrepareDesc), P(MMPrepareGrads), c_p]
+    L.mm_face_normals_forward.argtypes = [ctypes.c_int64, c_i, c_p, c_p, c_p]
+    L.mm_face_normals_backward.argtypes = [ctypes.c_int64, c_i, c_p, c_p, c_p, c_p]
+    L.mm_dibr_query_workspace.restype = ctypes.c_size_t
+    L.mm_dibr_query_workspace.argtypes = [P(MMDibrDesc)]
+    L.mm_dibr_rasterization_forward.argtypes = [P(MMDibrDesc), c_p]
+    L.mm_dibr_rasterization_backward.argtypes = [P(MMDibrDesc), P(MMDibrGrads), c_p]
+    L.mm_texture_mapping_forward.argtypes = [P(MMTexMapDesc), c_p]
+    L.mm_texture_mapping_backward.argtypes = [P(MMTexMapDesc), P(MMTexMapGrads), c_p]
+    L.mm_sh_lighting_forward.argtypes = [P(MMShDesc), c_p]
+    L.mm_sh_lighting_backward.argtypes = [P(MMShDesc), P(MMShGrads), c_p]
+    L.mm_mask_iou_forward.argtypes = [P(MMMaskIouDesc), c_p]
+    L.mm_mask_iou_backward.argtypes = [P(MMMaskIouDesc), c_p, c_p, c_p, c_p]
+    L.mm_struct_size.restype = ctypes.c_size_t
+    L.mm_struct_size.argtypes = [ctypes.c_int]
     L.mm_build_vertex_corner_csr.argtypes = [c_i, c_i, c_p, c_p, c_p]
-    L.mm_build_uv_tiles.argtypes = [c_i, c_p, c_i, c_i, c_p, c_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.mm_status_string.restype = ctypes.c_char_p
     L.mm_status_string.argtypes = [ctypes.c_int]
     L.mm_last_error_detail.restype = ctypes.c_char_p
     L.mm_last_error_detail.argtypes = []
+    L.mm_abi_version.restype = ctypes.c_int
+    if L.mm_abi_version() != ABI_VERSION:
+        raise RuntimeError("libmm_render.so has ABI version %d, this binding mirrors version %d" % (L.mm_abi_version(), ABI_VERSION))
+    mirrors = (MMRenderDesc, MMRenderGrads, MMReconDesc, MMMeshRegDesc, MMMeshRegGrads, MMAttLossDesc, MMAttLossGrads, MMTexFlowDesc,
+               MMTexFlowGrads, MMPrepareDesc, MMPrepareGrads, MMDibrDesc, MMDibrGrads, MMTexMapDesc, MMTexMapGrads, MMShDesc, MMShGrads,
+               MMMaskIouDesc)
+    for i, cls in enumerate(mirrors):
+        if L.mm_struct_size(i) != ctypes.sizeof(cls):
+            raise RuntimeError("struct layout mismatch for %s: library %d bytes, binding %d" % (cls.__name__, L.mm_struct_size(i), ctypes.sizeof(cls)))
     _LIB = L
     return L
 

@@ -16,14 +16,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmm_render.so")
-OBJ = os.path.join(HERE, "lib", "obj")
 # -fno-slp-vectorize on the relaxed files: the SLP vectoriser's packed-fp32 code costs more v_mov shuffling than it saves here
 # (measured: same instruction count, +2 % images/s without it; the exact files lose 7 % instructions without it and keep it).
 EXACT = ["-ffp-contract=off"]
 RELAXED = ["-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
-SOURCES = {"mm_abi.hip": EXACT, "mm_reg.hip": EXACT, "mm_texflow.hip": EXACT, "mm_attloss.hip": EXACT, "mm_vertex.hip": EXACT, "mm_raster.hip": EXACT, "mm_raster_resident.hip": EXACT,
-           "mm_backward.hip": RELAXED, "mm_loss.hip": EXACT, "mm_nn.hip": EXACT}
-HEADERS = ["mm_device.h", "mm_raster_common.h", os.path.join("..", "..", "include", "mm_render.h")]
+SOURCES = {"mm_abi.hip": EXACT, "mm_reg.hip": EXACT, "mm_texflow.hip": EXACT, "mm_attloss.hip": EXACT, "mm_vertex.hip": EXACT, "mm_raster.hip": EXACT,
+           "mm_backward.hip": RELAXED, "mm_loss.hip": EXACT, "mm_nn.hip": EXACT, "mm_dibr.hip": EXACT, "mm_ops.hip": EXACT}
+HEADERS = ["mm_device.h", "mm_raster_common.h", "mm_raster_walk.h", os.path.join("..", "..", "include", "mm_render.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -36,27 +35,44 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Compile + link under an exclusive file lock, into a private directory, and publish the library with one atomic rename:
+    N ranks starting together on a fresh checkout (torchrun bench.py) build once, and nobody can dlopen a half-written file."""
+    import fcntl
+    import shutil
+    import tempfile
     if not force and not needs_build():
         return LIB
-    os.makedirs(OBJ, exist_ok=True)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("MM_EXTRA_FLAGS", "").split()
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    with open(os.path.join(os.path.dirname(LIB), ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():                  # another process built it while we waited for the lock
+                return LIB
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            extra = os.environ.get("MM_EXTRA_FLAGS", "").split()
+            tmp = tempfile.mkdtemp(prefix="obj.", dir=os.path.dirname(LIB))
+            try:
+                def compile_one(item):
+                    src, mode = item
+                    obj = os.path.join(tmp, src.replace(".hip", ".o"))
+                    cmd = [hipcc] + FLAGS + mode + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd))
+                    subprocess.check_call(cmd)
+                    return obj
 
-    def compile_one(item):
-        src, mode = item
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + mode + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        return obj
-
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
-        objs = list(pool.map(compile_one, SOURCES.items()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC"] + objs + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+                with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+                    objs = list(pool.map(compile_one, SOURCES.items()))
+                out = os.path.join(tmp, "libmm_render.so")
+                cmd = [hipcc, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC"] + objs + ["-o", out]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                os.replace(out, LIB)                             # atomic on one filesystem
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

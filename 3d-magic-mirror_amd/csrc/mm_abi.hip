@@ -51,7 +51,7 @@ int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
     mm::clear_stale_error();
     st = mm::launch_vertex_fwd(d, w, s);
     if (st != MM_OK) return st;
-    return mm::launch_raster_fwd(d, w, s);      // streamed: bin masks + tile order + raster; resident: one launch
+    return mm::launch_raster_fwd(d, w, s);      // tile order + raster
 }
 
 int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {
@@ -205,46 +205,6 @@ int mm_texture_flow_backward(const MMTexFlowDesc* d, const MMTexFlowGrads* g, mm
     return mm::launch_texflow_bwd(d, g, (hipStream_t)stream);
 }
 
-int mm_build_uv_tiles(int32_t F, const float* fuv, int32_t Ht, int32_t Wt, int32_t* offsets, int32_t* items, int64_t capacity,
-                      int64_t* needed) {
-    if (!fuv || !offsets || !needed) return MM_ERR_NULL_POINTER;
-    if (F <= 0 || Ht <= 0 || Wt <= 0) return MM_ERR_BAD_SHAPE;
-    const int TS = MM_UV_TILE, ntx = (Wt + TS - 1) / TS, nty = (Ht + TS - 1) / TS, nt = ntx * nty;
-    // texel-space box of every face's samples: ix = u*Wt - 0.5, iy = (1-v)*Ht - 0.5 (texture_mapping, a9), clipped to the
-    // texture like grid_sample's border mode, widened by the bilinear footprint and one texel of slack
-    auto range = [&](int f, int& x0, int& x1, int& y0, int& y1) {
-        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
-        for (int k = 0; k < 3; ++k) {
-            const float u = fuv[(f * 3 + k) * 2], v = fuv[(f * 3 + k) * 2 + 1];
-            const float ix = (((u * 2.f - 1.f) + 1.f) * (float)Wt - 1.f) / 2.f, iy = (((-(v * 2.f - 1.f)) + 1.f) * (float)Ht - 1.f) / 2.f;
-            xmin = ix < xmin ? ix : xmin; xmax = ix > xmax ? ix : xmax; ymin = iy < ymin ? iy : ymin; ymax = iy > ymax ? iy : ymax;
-        }
-        auto clampi = [](float v, int hi) { if (!(v > 0.f)) return 0; if (v > (float)hi) return hi; return (int)v; };
-        x0 = clampi(floorf(xmin) - 1.f, Wt - 1); x1 = clampi(floorf(xmax) + 2.f, Wt - 1);
-        y0 = clampi(floorf(ymin) - 1.f, Ht - 1); y1 = clampi(floorf(ymax) + 2.f, Ht - 1);
-    };
-    for (int t = 0; t <= nt; ++t) offsets[t] = 0;
-    int64_t total = 0;
-    for (int f = 0; f < F; ++f) {
-        int x0, x1, y0, y1; range(f, x0, x1, y0, y1);
-        for (int ty = y0 / TS; ty <= y1 / TS; ++ty) for (int tx = x0 / TS; tx <= x1 / TS; ++tx) { ++offsets[ty * ntx + tx + 1]; ++total; }
-    }
-    *needed = total;
-    for (int t = 0; t < nt; ++t) offsets[t + 1] += offsets[t];
-    if (!items || capacity < total) return items ? MM_ERR_WORKSPACE : MM_OK;
-    for (int f = 0; f < F; ++f) {                                // ascending face id within a tile; offsets doubles as cursor
-        int x0, x1, y0, y1; range(f, x0, x1, y0, y1);
-        bool first = true;
-        for (int ty = y0 / TS; ty <= y1 / TS; ++ty) for (int tx = x0 / TS; tx <= x1 / TS; ++tx) {
-            items[offsets[ty * ntx + tx]++] = first ? (int32_t)((uint32_t)f | 0x80000000u) : f;
-            first = false;
-        }
-    }
-    for (int t = nt; t > 0; --t) offsets[t] = offsets[t - 1];
-    offsets[0] = 0;
-    return MM_OK;
-}
-
 int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces, int32_t* offsets, int32_t* items) {
     if (!faces || !offsets || !items) return MM_ERR_NULL_POINTER;
     if (V <= 0 || F <= 0) return MM_ERR_BAD_SHAPE;
@@ -281,6 +241,18 @@ const char* mm_last_error_detail(void) {
     return buf;
 }
 
-int mm_abi_version(void) { return 1; }
+size_t mm_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(MMRenderDesc);    case 1: return sizeof(MMRenderGrads);   case 2: return sizeof(MMReconDesc);
+        case 3: return sizeof(MMMeshRegDesc);   case 4: return sizeof(MMMeshRegGrads);  case 5: return sizeof(MMAttLossDesc);
+        case 6: return sizeof(MMAttLossGrads);  case 7: return sizeof(MMTexFlowDesc);   case 8: return sizeof(MMTexFlowGrads);
+        case 9: return sizeof(MMPrepareDesc);   case 10: return sizeof(MMPrepareGrads); case 11: return sizeof(MMDibrDesc);
+        case 12: return sizeof(MMDibrGrads);    case 13: return sizeof(MMTexMapDesc);   case 14: return sizeof(MMTexMapGrads);
+        case 15: return sizeof(MMShDesc);       case 16: return sizeof(MMShGrads);      case 17: return sizeof(MMMaskIouDesc);
+        default: return 0;
+    }
+}
+
+int mm_abi_version(void) { return MM_ABI_VERSION; }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 #define MM_BLOCK_PX 16        // a 256-thread workgroup renders a 16x16 pixel block: 2x2 wave tiles
 #define MM_BLOCK_WAVES 4
 #define MM_LSUB 8             // sub-accumulators per image for the fused loss sums (one 32-byte row each: spreads same-address atomics)
+#define MM_UV_TILE 32         // texture-gradient tiles: 32x32 texels, one workgroup and one record list each
 #define MM_GROUP_WORDS 16     // bin-mask words (of 64 faces) expanded per step: 1024 faces -> 2 KiB of uint16 ids per wave
 
 namespace mm {
@@ -337,6 +338,52 @@ __device__ inline uint64_t wave_transpose64(uint64_t x, int lane) {
     x = transpose_stage<2>(x, lane);
     x = transpose_stage<1>(x, lane);
     return x;
+}
+
+// ---- screen binning of one wave's 64 faces = mask word c of every bin -------------------------------------------------
+// A lane turns its face's pixel box (inflated by the soft-mask margin, conservative; bw <= 0: none) into bin column / row
+// ranges.  Per block of 8x8 bins the lane's coverage is a 64-bit row-major bit matrix (rows x columns outer product); ONE wave
+// transpose turns the 64 faces' coverage words into the 64 bins' mask words, stored plainly -- every word of every bin is
+// written (blocks no face touches skip the transpose): no atomics, no zero-fill, no second pass over the face records.
+// The raster kernel re-tests every (pixel, face) pair exactly, so a conservative mask changes no result.
+__device__ inline void bin_wave_faces(uint64_t* mask, int b, int nbx, int nby, int words, int bin_shift, int c, int lane,
+                                      int bx0, int by0, int bw, int bh) {
+    int c0 = 0, c1 = -1, r0 = 0, r1 = -1;                         // bin columns / rows the box touches (none)
+    if (bw > 0 && bh > 0) {
+        c0 = bx0 >> bin_shift; c1 = (bx0 + bw - 1) >> bin_shift;
+        r0 = by0 >> bin_shift; r1 = (by0 + bh - 1) >> bin_shift;
+    }
+    const int sbx = (nbx + 7) >> 3, sby = (nby + 7) >> 3;
+    for (int s = 0; s < sbx * sby; ++s) {
+        const int kx0 = (s % sbx) * 8, ky0 = (s / sbx) * 8;
+        const int clo = max(c0 - kx0, 0), chi = min(c1 - kx0, 7), rlo = max(r0 - ky0, 0), rhi = min(r1 - ky0, 7);
+        const unsigned col = chi >= clo ? ((2u << chi) - (1u << clo)) : 0u;       // bits clo..chi
+        const unsigned row = rhi >= rlo ? ((2u << rhi) - (1u << rlo)) : 0u;
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            lo |= ((row >> r) & 1u) ? (col << (8 * r)) : 0u;
+            hi |= ((row >> (r + 4)) & 1u) ? (col << (8 * r)) : 0u;
+        }
+        const uint64_t cov = ((uint64_t)hi << 32) | lo;           // bit (r*8+c): this face touches bin (ky0+r, kx0+c)
+        uint64_t word = 0;
+        if (__ballot(cov != 0)) word = wave_transpose64(cov, lane);               // lane j: bit i = face c*64+i touches bin j
+        const int kx = kx0 + (lane & 7), ky = ky0 + (lane >> 3);
+        if (kx < nbx && ky < nby) mask[((size_t)b * nbx * nby + (size_t)ky * nbx + kx) * words + c] = word;
+    }
+}
+
+// the face's pixel box inflated by the soft-mask margin (conservative, see pixel_range), packed for the face sweeps of the
+// backward: org = px0 | py0 << 16, ext = width | height << 16 (0 x 0 if it misses the image)
+__device__ inline void face_pixel_box(float ax, float ay, float bx, float by, float cx, float cy, float infl, float mult, int W, int H,
+                                      int& bx0, int& by0, int& bw, int& bh, unsigned& org, unsigned& ext) {
+    int bx1, by1;
+    pixel_range(fminf(fminf(ax, bx), cx) - infl, fmaxf(fmaxf(ax, bx), cx) + infl, mult, W, false, bx0, bx1);
+    pixel_range(fminf(fminf(ay, by), cy) - infl, fmaxf(fmaxf(ay, by), cy) + infl, mult, H, true, by0, by1);
+    bw = bx1 - bx0 + 1; bh = by1 - by0 + 1;
+    const bool hit = bw > 0 && bh > 0;
+    org = hit ? ((unsigned)bx0 | ((unsigned)by0 << 16)) : 0u;
+    ext = hit ? ((unsigned)bw | ((unsigned)bh << 16)) : 0u;
 }
 
 // fused recon_data totals of image b: {sum|pi-gi|, sum p*g, sum p+g-p*g} (exact integer sums of the raster waves' partials)

@@ -1,0 +1,480 @@
+// mm_ops.hip -- the small kaolin operators of the reference's import boundary as stand-alone gfx950 kernels:
+//   kaolin.render.mesh.prepare_vertices            (call site /root/reference/networks.py:284-287)
+//   kaolin.ops.mesh.face_normals                   (:289)
+//   kaolin.render.mesh.texture_mapping             (:305)   = F.grid_sample(align_corners=False, padding_mode='border') on (2u-1, -(2v-1))
+//   kaolin.render.mesh.spherical_harmonic_lighting (:306)
+//   kaolin.metrics.render.mask_iou                 (:377, trainer.py:793,933)
+// Upstream these are compositions of ATen ops (10-20 launches each); here each is one launch per direction (two where a
+// fixed-order reduction needs a second, tiny one), with the same device functions the fused render kernels use (to_camera,
+// bilin_setup, sh_bands), so values agree bit for bit with the fused path's intermediate quantities.
+// Semantics: SURVEY.md 8(a) rows a5, a6, a9, a10, a14; gradients Appendix A.3 and exact chain rules of the forwards.
+#include "mm_device.h"
+
+namespace mm {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// prepare_vertices
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prepare_fwd_kernel(MMPrepareDesc d) {
+    const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= d.F) return;
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = d.transform[b * 12 + i];
+    const float* vb = d.vertices + (size_t)b * d.V * 3;
+    const size_t o = (size_t)b * d.F + f;
+    Float3 c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c[k] = to_camera(vb + (size_t)d.faces[f * 3 + k] * 3, T);
+        const float pz = c[k].z * d.proj[2];
+        float* fc = d.face_vertices_camera + (o * 3 + k) * 3;
+        fc[0] = c[k].x; fc[1] = c[k].y; fc[2] = c[k].z;
+        d.face_vertices_image[(o * 3 + k) * 2 + 0] = (c[k].x * d.proj[0]) / pz;
+        d.face_vertices_image[(o * 3 + k) * 2 + 1] = (c[k].y * d.proj[1]) / pz;
+    }
+    const float e0[3] = {c[1].x - c[0].x, c[1].y - c[0].y, c[1].z - c[0].z};
+    const float e1[3] = {c[2].x - c[0].x, c[2].y - c[0].y, c[2].z - c[0].z};
+    float n[3];
+    cross3(e0, e1, n);
+    const float len = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+    const float den = len + 1e-10f;
+    d.face_normals[o * 3 + 0] = n[0] / den; d.face_normals[o * 3 + 1] = n[1] / den; d.face_normals[o * 3 + 2] = n[2] / den;
+}
+
+// d/d(corner positions) of g . n / (|n| + 1e-10), n = (B - A) x (C - A): adds to dA, dB, dC
+__device__ inline void normal_backward(const Float3& A, const Float3& Bv, const Float3& C, const float* g, bool unit, float* dA, float* dB, float* dC) {
+    const float e0[3] = {Bv.x - A.x, Bv.y - A.y, Bv.z - A.z};
+    const float e1[3] = {C.x - A.x, C.y - A.y, C.z - A.z};
+    float n[3], dn[3];
+    cross3(e0, e1, n);
+    if (unit) {
+        const float len = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+        const float den = len + 1e-10f;
+        const float ng = (n[0] * g[0] + n[1] * g[1]) + n[2] * g[2];
+        const float iden = 1.f / den, c = (len > 0.f) ? (ng * iden * iden) / len : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dn[j] = g[j] * iden - c * n[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dn[j] = g[j];
+    }
+    float de0[3], de1[3];
+    cross3(e1, dn, de0);
+    cross3(dn, e0, de1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { dB[j] += de0[j]; dC[j] += de1[j]; dA[j] -= de0[j] + de1[j]; }
+}
+
+// Eight lanes per vertex gather through the static vertex->corner CSR (no atomics); each workgroup leaves its partial of
+// dL/dT in the workspace and prepare_final sums the partials of an image in index order: deterministic.
+__global__ __launch_bounds__(256) void prepare_bwd_kernel(MMPrepareDesc d, MMPrepareGrads g) {
+    __shared__ float s_red[4][12];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = d.transform[b * 12 + i];
+    const float* vb = d.vertices + (size_t)b * d.V * 3;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    const int v = blockIdx.x * 32 + (tid >> 3), cl = tid & 7;
+    if (v < d.V) {
+        const float p[3] = {vb[v * 3], vb[v * 3 + 1], vb[v * 3 + 2]};
+        const Float3 me = to_camera(p, T);
+        const float pz = me.z * d.proj[2];
+        const float xi = (me.x * d.proj[0]) / pz, yi = (me.y * d.proj[1]) / pz;
+        float dv[3] = {0.f, 0.f, 0.f};
+        const int beg = d.vc_offsets[v], end = d.vc_offsets[v + 1];
+        for (int it = beg + cl; it < end; it += 8) {
+            const int item = d.vc_items[it];
+            const int f = item / 3, k = item - f * 3;
+            const size_t o = (size_t)b * d.F + f;
+            if (g.grad_face_vertices_camera) {
+                const float* q = g.grad_face_vertices_camera + (o * 3 + k) * 3;
+                dv[0] += q[0]; dv[1] += q[1]; dv[2] += q[2];
+            }
+            if (g.grad_face_vertices_image) {
+                const float gx = g.grad_face_vertices_image[(o * 3 + k) * 2], gy = g.grad_face_vertices_image[(o * 3 + k) * 2 + 1];
+                dv[0] += gx * d.proj[0] / pz;
+                dv[1] += gy * d.proj[1] / pz;
+                dv[2] += -(gx * xi + gy * yi) * d.proj[2] / pz;
+            }
+            if (g.grad_face_normals) {
+                const float gn[3] = {g.grad_face_normals[o * 3], g.grad_face_normals[o * 3 + 1], g.grad_face_normals[o * 3 + 2]};
+                if (gn[0] != 0.f || gn[1] != 0.f || gn[2] != 0.f) {
+                    const Float3 A = to_camera(vb + (size_t)d.faces[f * 3] * 3, T), Bv = to_camera(vb + (size_t)d.faces[f * 3 + 1] * 3, T),
+                                 C = to_camera(vb + (size_t)d.faces[f * 3 + 2] * 3, T);
+                    float dA[3] = {0.f, 0.f, 0.f}, dB[3] = {0.f, 0.f, 0.f}, dC[3] = {0.f, 0.f, 0.f};
+                    normal_backward(A, Bv, C, gn, true, dA, dB, dC);
+                    const float* mine = k == 0 ? dA : (k == 1 ? dB : dC);
+                    dv[0] += mine[0]; dv[1] += mine[1]; dv[2] += mine[2];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { dv[j] += __shfl_xor(dv[j], 4, 8); dv[j] += __shfl_xor(dv[j], 2, 8); dv[j] += __shfl_xor(dv[j], 1, 8); }
+        if (cl == 0) {
+            float* gv = g.grad_vertices + ((size_t)b * d.V + v) * 3;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                gv[i] = (T[i * 3 + 0] * dv[0] + T[i * 3 + 1] * dv[1]) + T[i * 3 + 2] * dv[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i * 3 + j] = p[i] * dv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[9 + j] = dv[j];
+        }
+    }
+    if (!g.grad_transform) return;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = wave_sum(acc[i]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s_red[tid >> 6][i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 12) ((float*)d.workspace)[((size_t)b * gridDim.x + blockIdx.x) * 12 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+}
+
+__global__ __launch_bounds__(64) void prepare_final_kernel(const float* partial, int groups, float* grad_transform) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int i = 0; i < 12; ++i) {
+        float s = 0.f;
+        for (int k = lane; k < groups; k += 64) s += partial[((size_t)b * groups + k) * 12 + i];
+        s = wave_sum(s);
+        if (lane == 0) grad_transform[b * 12 + i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// face_normals
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void face_normals_fwd_kernel(long long n, int unit, const float* fv, float* out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* q = fv + i * 9;
+    const float e0[3] = {q[3] - q[0], q[4] - q[1], q[5] - q[2]};
+    const float e1[3] = {q[6] - q[0], q[7] - q[1], q[8] - q[2]};
+    float nn[3];
+    cross3(e0, e1, nn);
+    if (unit) {
+        const float den = sqrtf((nn[0] * nn[0] + nn[1] * nn[1]) + nn[2] * nn[2]) + 1e-10f;
+        nn[0] = nn[0] / den; nn[1] = nn[1] / den; nn[2] = nn[2] / den;
+    }
+    out[i * 3] = nn[0]; out[i * 3 + 1] = nn[1]; out[i * 3 + 2] = nn[2];
+}
+
+__global__ __launch_bounds__(256) void face_normals_bwd_kernel(long long n, int unit, const float* fv, const float* gout, float* gfv) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* q = fv + i * 9;
+    const Float3 A = {q[0], q[1], q[2]}, Bv = {q[3], q[4], q[5]}, C = {q[6], q[7], q[8]};
+    const float g[3] = {gout[i * 3], gout[i * 3 + 1], gout[i * 3 + 2]};
+    float dA[3] = {0.f, 0.f, 0.f}, dB[3] = {0.f, 0.f, 0.f}, dC[3] = {0.f, 0.f, 0.f};
+    normal_backward(A, Bv, C, g, unit != 0, dA, dB, dC);
+    float* o = gfv + i * 9;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { o[j] = dA[j]; o[3 + j] = dB[j]; o[6 + j] = dC[j]; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// texture_mapping
+// ---------------------------------------------------------------------------------------------------------------------
+// grid_sample 'nearest' with border padding: unnormalise, clip to [0, size-1], round half to even
+__device__ inline void nearest_texel(float u, float v, int Ht, int Wt, int& x, int& y) {
+    const float gx = u * 2.f - 1.f, gy = -(v * 2.f - 1.f);
+    float ix = ((gx + 1.f) * (float)Wt - 1.f) / 2.f, iy = ((gy + 1.f) * (float)Ht - 1.f) / 2.f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(Wt - 1)); iy = fminf(fmaxf(iy, 0.f), (float)(Ht - 1));
+    x = (int)nearbyintf(ix); y = (int)nearbyintf(iy);
+}
+
+__global__ __launch_bounds__(256) void texmap_fwd_kernel(MMTexMapDesc d) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= d.N) return;
+    const size_t p = (size_t)b * d.N + n;
+    const float u = d.uv[p * 2], v = d.uv[p * 2 + 1];
+    const size_t plane = (size_t)d.Ht * d.Wt;
+    if (d.mode == MM_TEXMAP_NEAREST) {
+        int x, y;
+        nearest_texel(u, v, d.Ht, d.Wt, x, y);
+        for (int c = 0; c < d.C; ++c) d.out[p * d.C + c] = d.textures[((size_t)b * d.C + c) * plane + (size_t)y * d.Wt + x];
+        return;
+    }
+    const Bilin s = bilin_setup(u, v, d.Ht, d.Wt);
+    const bool inw = s.x0 < d.Wt && s.y0 < d.Ht, ine = s.x1 < d.Wt && s.y0 < d.Ht;
+    const bool isw = s.x0 < d.Wt && s.y1 < d.Ht, ise = s.x1 < d.Wt && s.y1 < d.Ht;
+    for (int c = 0; c < d.C; ++c) {
+        const float* tex = d.textures + ((size_t)b * d.C + c) * plane;
+        float tc = 0.f;
+        if (inw) tc += tex[(size_t)s.y0 * d.Wt + s.x0] * s.wnw;
+        if (ine) tc += tex[(size_t)s.y0 * d.Wt + s.x1] * s.wne;
+        if (isw) tc += tex[(size_t)s.y1 * d.Wt + s.x0] * s.wsw;
+        if (ise) tc += tex[(size_t)s.y1 * d.Wt + s.x1] * s.wse;
+        d.out[p * d.C + c] = tc;
+    }
+}
+
+// The texture gradient is a scatter.  The fused path gathers it through per-tile record lists; this stand-alone operator keeps
+// kaolin/ATen's formulation (hardware float atomics into a zero-filled gradient) but never issues an atomic for a zero
+// contribution: pixels no face covers all sample uv = (0,0) and would otherwise pile onto one texel.
+__global__ __launch_bounds__(256) void texmap_bwd_kernel(MMTexMapDesc d, MMTexMapGrads g) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= d.N) return;
+    const size_t p = (size_t)b * d.N + n;
+    const float u = d.uv[p * 2], v = d.uv[p * 2 + 1];
+    const size_t plane = (size_t)d.Ht * d.Wt;
+    if (d.mode == MM_TEXMAP_NEAREST) {
+        if (g.grad_uv) { g.grad_uv[p * 2] = 0.f; g.grad_uv[p * 2 + 1] = 0.f; }
+        if (g.grad_textures) {
+            int x, y;
+            nearest_texel(u, v, d.Ht, d.Wt, x, y);
+            for (int c = 0; c < d.C; ++c) {
+                const float go = g.grad_out[p * d.C + c];
+                if (go != 0.f) atomicAdd(g.grad_textures + ((size_t)b * d.C + c) * plane + (size_t)y * d.Wt + x, go);
+            }
+        }
+        return;
+    }
+    const Bilin s = bilin_setup(u, v, d.Ht, d.Wt);
+    const bool inw = s.x0 < d.Wt && s.y0 < d.Ht, ine = s.x1 < d.Wt && s.y0 < d.Ht;
+    const bool isw = s.x0 < d.Wt && s.y1 < d.Ht, ise = s.x1 < d.Wt && s.y1 < d.Ht;
+    const float ex = 1.f - s.tx, ey = 1.f - s.ty;
+    float gix = 0.f, giy = 0.f;
+    for (int c = 0; c < d.C; ++c) {
+        const float* tex = d.textures + ((size_t)b * d.C + c) * plane;
+        const float go = g.grad_out[p * d.C + c];
+        const float tnw = inw ? tex[(size_t)s.y0 * d.Wt + s.x0] : 0.f, tne = ine ? tex[(size_t)s.y0 * d.Wt + s.x1] : 0.f;
+        const float tsw = isw ? tex[(size_t)s.y1 * d.Wt + s.x0] : 0.f, tse = ise ? tex[(size_t)s.y1 * d.Wt + s.x1] : 0.f;
+        if (g.grad_textures && go != 0.f) {
+            float* dt = g.grad_textures + ((size_t)b * d.C + c) * plane;
+            if (inw) atomicAdd(dt + (size_t)s.y0 * d.Wt + s.x0, go * s.wnw);
+            if (ine) atomicAdd(dt + (size_t)s.y0 * d.Wt + s.x1, go * s.wne);
+            if (isw) atomicAdd(dt + (size_t)s.y1 * d.Wt + s.x0, go * s.wsw);
+            if (ise) atomicAdd(dt + (size_t)s.y1 * d.Wt + s.x1, go * s.wse);
+        }
+        gix += go * ((tne - tnw) * ey + (tse - tsw) * s.ty);
+        giy += go * ((tsw - tnw) * ex + (tse - tne) * s.tx);
+    }
+    if (g.grad_uv) {
+        g.grad_uv[p * 2 + 0] = gix * s.mx * ((float)d.Wt / 2.f) * 2.f;
+        g.grad_uv[p * 2 + 1] = giy * s.my * ((float)d.Ht / 2.f) * -2.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// spherical_harmonic_lighting
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sh_fwd_kernel(MMShDesc d) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= d.N) return;
+    const size_t p = (size_t)b * d.N + n;
+    float bnd[9];
+    sh_bands(d.normals[p * 3], d.normals[p * 3 + 1], d.normals[p * 3 + 2], bnd);
+    const float* L = d.lights + b * 9;
+    float coef = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) coef += bnd[i] * L[i];
+    d.out[p] = coef;
+}
+
+__global__ __launch_bounds__(256) void sh_bwd_kernel(MMShDesc d, MMShGrads g) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    const bool live = n < d.N;
+    const size_t p = (size_t)b * d.N + (live ? n : 0);
+    const float x = d.normals[p * 3], y = d.normals[p * 3 + 1], z = d.normals[p * 3 + 2];
+    const float go = live ? g.grad_out[p] : 0.f;
+    const float* L = d.lights + b * 9;
+    if (live && g.grad_normals) {
+        g.grad_normals[p * 3 + 0] = go * (((MM_SH_C1 * L[1] + MM_SH_C4 * y * L[4]) + MM_SH_C7 * z * L[7]) + 2.f * MM_SH_C8 * x * L[8]);
+        g.grad_normals[p * 3 + 1] = go * (((MM_SH_C1 * L[3] + MM_SH_C4 * x * L[4]) + MM_SH_C4 * z * L[5]) - 2.f * MM_SH_C8 * y * L[8]);
+        g.grad_normals[p * 3 + 2] = go * (((MM_SH_C1 * L[2] + MM_SH_C4 * y * L[5]) + 2.f * MM_SH_C6 * z * L[6]) + MM_SH_C7 * x * L[7]);
+    }
+    if (g.grad_lights) {
+        float bnd[9];
+        sh_bands(x, y, z, bnd);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float s = wave_sum(go * bnd[i]);
+            if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(g.grad_lights + b * 9 + i, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mask_iou: one 1024-thread workgroup per image reduces in a fixed order (deterministic); a single wave folds the images
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void mask_iou_sums_kernel(MMMaskIouDesc d) {
+    __shared__ float s_red[16][2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* l = d.lhs + (size_t)b * d.N; const float* r = d.rhs + (size_t)b * d.N;
+    float up = 0.f, down = 0.f;
+    for (int i = tid; i < d.N; i += 1024) { const float mul = l[i] * r[i]; up += mul; down += (l[i] + r[i]) - mul; }
+    up = wave_sum(up); down = wave_sum(down);
+    if ((tid & 63) == 0) { s_red[tid >> 6][0] = up; s_red[tid >> 6][1] = down; }
+    __syncthreads();
+    if (tid < 2) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += s_red[w][tid];
+        d.sums[b * 2 + tid] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void mask_iou_final_kernel(MMMaskIouDesc d) {
+    float iou = 0.f;
+    for (int b = threadIdx.x; b < d.B; b += 64) iou += d.sums[b * 2] / (d.sums[b * 2 + 1] + 1e-10f);
+    iou = wave_sum(iou);
+    if (threadIdx.x == 0) d.loss[0] = 1.f - iou / (float)d.B;
+}
+
+__global__ __launch_bounds__(256) void mask_iou_bwd_kernel(MMMaskIouDesc d, const float* grad_loss, float* gl, float* gr) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.N) return;
+    const float up = d.sums[b * 2], U = d.sums[b * 2 + 1] + 1e-10f;
+    const float gs = grad_loss ? grad_loss[0] : 1.f;
+    const float ka = -gs / ((float)d.B * U), kb = gs * up / ((float)d.B * U * U);
+    const size_t p = (size_t)b * d.N + i;
+    const float l = d.lhs[p], r = d.rhs[p];
+    // d(up)/dl = r, d(down)/dl = 1 - r  (and symmetrically for r)
+    if (gl) gl[p] = ka * r + kb * (1.f - r);
+    if (gr) gr[p] = ka * l + kb * (1.f - l);
+}
+
+}  // namespace mm
+
+extern "C" {
+
+size_t mm_prepare_vertices_query_workspace(const MMPrepareDesc* d) {
+    if (!d || d->B <= 0 || d->V <= 0) return 0;
+    return mm::align256((size_t)d->B * ((d->V + 31) / 32) * 12 * sizeof(float));
+}
+
+static int check_prepare(const MMPrepareDesc* d) {
+    if (!d) return MM_ERR_NULL_POINTER;
+    if (d->B <= 0 || d->V <= 0 || d->F <= 0) return MM_ERR_BAD_SHAPE;
+    if (!d->faces || !d->vertices || !d->transform) return MM_ERR_NULL_POINTER;
+    return MM_OK;
+}
+
+int mm_prepare_vertices_forward(const MMPrepareDesc* d, mm_stream_t stream) {
+    const int st = check_prepare(d);
+    if (st != MM_OK) return st;
+    if (!d->face_vertices_camera || !d->face_vertices_image || !d->face_normals) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    hipLaunchKernelGGL(mm::prepare_fwd_kernel, dim3((d->F + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d);
+    return mm::launch_ok("prepare_vertices_fwd");
+}
+
+int mm_prepare_vertices_backward(const MMPrepareDesc* d, const MMPrepareGrads* g, mm_stream_t stream) {
+    const int st = check_prepare(d);
+    if (st != MM_OK) return st;
+    if (!g || !g->grad_vertices || !d->vc_offsets || !d->vc_items) return MM_ERR_NULL_POINTER;
+    if (g->grad_transform && (!d->workspace || d->workspace_bytes < mm_prepare_vertices_query_workspace(d))) return MM_ERR_WORKSPACE;
+    mm::clear_stale_error();
+    const int groups = (d->V + 31) / 32;
+    hipLaunchKernelGGL(mm::prepare_bwd_kernel, dim3(groups, d->B), dim3(256), 0, (hipStream_t)stream, *d, *g);
+    if (mm::launch_ok("prepare_vertices_bwd") != MM_OK) return MM_ERR_LAUNCH;
+    if (g->grad_transform)
+        hipLaunchKernelGGL(mm::prepare_final_kernel, dim3(d->B), dim3(64), 0, (hipStream_t)stream, (const float*)d->workspace, groups, g->grad_transform);
+    return mm::launch_ok("prepare_vertices_final");
+}
+
+int mm_face_normals_forward(int64_t n, int32_t unit, const float* fv, float* normals, mm_stream_t stream) {
+    if (!fv || !normals) return MM_ERR_NULL_POINTER;
+    if (n <= 0 || n > (int64_t)0x7FFFFFFF * 256) return MM_ERR_BAD_SHAPE;
+    mm::clear_stale_error();
+    hipLaunchKernelGGL(mm::face_normals_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n, unit, fv, normals);
+    return mm::launch_ok("face_normals_fwd");
+}
+
+int mm_face_normals_backward(int64_t n, int32_t unit, const float* fv, const float* gout, float* gfv, mm_stream_t stream) {
+    if (!fv || !gout || !gfv) return MM_ERR_NULL_POINTER;
+    if (n <= 0 || n > (int64_t)0x7FFFFFFF * 256) return MM_ERR_BAD_SHAPE;
+    mm::clear_stale_error();
+    hipLaunchKernelGGL(mm::face_normals_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n, unit, fv, gout, gfv);
+    return mm::launch_ok("face_normals_bwd");
+}
+
+static int check_texmap(const MMTexMapDesc* d) {
+    if (!d) return MM_ERR_NULL_POINTER;
+    if (d->B <= 0 || d->N <= 0 || d->C <= 0 || d->Ht <= 0 || d->Wt <= 0 || d->B > 65535) return MM_ERR_BAD_SHAPE;
+    if (d->mode != MM_TEXMAP_NEAREST && d->mode != MM_TEXMAP_BILINEAR) return MM_ERR_UNSUPPORTED;
+    if (!d->uv || !d->textures) return MM_ERR_NULL_POINTER;
+    return MM_OK;
+}
+
+int mm_texture_mapping_forward(const MMTexMapDesc* d, mm_stream_t stream) {
+    const int st = check_texmap(d);
+    if (st != MM_OK) return st;
+    if (!d->out) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    hipLaunchKernelGGL(mm::texmap_fwd_kernel, dim3((d->N + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d);
+    return mm::launch_ok("texture_mapping_fwd");
+}
+
+int mm_texture_mapping_backward(const MMTexMapDesc* d, const MMTexMapGrads* g, mm_stream_t stream) {
+    const int st = check_texmap(d);
+    if (st != MM_OK) return st;
+    if (!g || !g->grad_out || (!g->grad_uv && !g->grad_textures)) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    if (g->grad_textures && hipMemsetAsync(g->grad_textures, 0, sizeof(float) * (size_t)d->B * d->C * d->Ht * d->Wt, (hipStream_t)stream) != hipSuccess)
+        return mm::launch_ok("texture_mapping_memset") == MM_OK ? MM_ERR_LAUNCH : MM_ERR_LAUNCH;
+    hipLaunchKernelGGL(mm::texmap_bwd_kernel, dim3((d->N + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d, *g);
+    return mm::launch_ok("texture_mapping_bwd");
+}
+
+static int check_sh(const MMShDesc* d) {
+    if (!d) return MM_ERR_NULL_POINTER;
+    if (d->B <= 0 || d->N <= 0 || d->B > 65535) return MM_ERR_BAD_SHAPE;
+    if (!d->normals || !d->lights) return MM_ERR_NULL_POINTER;
+    return MM_OK;
+}
+
+int mm_sh_lighting_forward(const MMShDesc* d, mm_stream_t stream) {
+    const int st = check_sh(d);
+    if (st != MM_OK) return st;
+    if (!d->out) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    hipLaunchKernelGGL(mm::sh_fwd_kernel, dim3((d->N + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d);
+    return mm::launch_ok("sh_lighting_fwd");
+}
+
+int mm_sh_lighting_backward(const MMShDesc* d, const MMShGrads* g, mm_stream_t stream) {
+    const int st = check_sh(d);
+    if (st != MM_OK) return st;
+    if (!g || !g->grad_out || (!g->grad_normals && !g->grad_lights)) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    if (g->grad_lights && hipMemsetAsync(g->grad_lights, 0, sizeof(float) * (size_t)d->B * 9, (hipStream_t)stream) != hipSuccess) return MM_ERR_LAUNCH;
+    hipLaunchKernelGGL(mm::sh_bwd_kernel, dim3((d->N + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d, *g);
+    return mm::launch_ok("sh_lighting_bwd");
+}
+
+static int check_iou(const MMMaskIouDesc* d) {
+    if (!d) return MM_ERR_NULL_POINTER;
+    if (d->B <= 0 || d->N <= 0 || d->B > 65535) return MM_ERR_BAD_SHAPE;
+    if (!d->lhs || !d->rhs || !d->sums) return MM_ERR_NULL_POINTER;
+    return MM_OK;
+}
+
+int mm_mask_iou_forward(const MMMaskIouDesc* d, mm_stream_t stream) {
+    const int st = check_iou(d);
+    if (st != MM_OK) return st;
+    if (!d->loss) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    hipLaunchKernelGGL(mm::mask_iou_sums_kernel, dim3(d->B), dim3(1024), 0, (hipStream_t)stream, *d);
+    if (mm::launch_ok("mask_iou_sums") != MM_OK) return MM_ERR_LAUNCH;
+    hipLaunchKernelGGL(mm::mask_iou_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *d);
+    return mm::launch_ok("mask_iou_final");
+}
+
+int mm_mask_iou_backward(const MMMaskIouDesc* d, const float* grad_loss, float* gl, float* gr, mm_stream_t stream) {
+    const int st = check_iou(d);
+    if (st != MM_OK) return st;
+    if (!gl && !gr) return MM_ERR_NULL_POINTER;
+    mm::clear_stale_error();
+    hipLaunchKernelGGL(mm::mask_iou_bwd_kernel, dim3((d->N + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d, grad_loss, gl, gr);
+    return mm::launch_ok("mask_iou_bwd");
+}
+
+}  // extern "C"

@@ -1,9 +1,7 @@
-// mm_raster_common.h -- pieces shared by the two forward pixel kernels of libmm_render.so (gfx950):
-//   mm_raster.hip           "streamed": any mesh size; candidates come from the bin masks, face records from HBM/L2
-//   mm_raster_resident.hip  "resident": small templates (the reference's 642-vertex meshes); the image's transformed
-//                           vertices live in LDS and nothing but the texture is fetched on the critical path
-// Both evaluate the SAME fp32 expressions on the same values, so their outputs are
-// bit-identical; tests/test_gpu_parity.py holds them to that.
+// mm_raster_common.h -- pieces shared by the forward pixel kernels of libmm_render.so (gfx950):
+//   mm_raster.hip   the fused render kernel (walk + texture + SH + composite + fused loss sums)
+//   mm_dibr.hip     the un-fused kaolin-shaped dibr_rasterization (same walk, generic feature interpolation)
+// Both evaluate the SAME fp32 expressions on the same values.
 #pragma once
 #include "mm_device.h"
 
@@ -23,16 +21,14 @@ struct RasterArgs {
     float2* soft;                           // per pixel {soft-mask product state, id of the knum-th face taken (int bits)}
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
-    // resident kernel only
-    int V, regions_x, regions_per_image;
-    float proj0, proj1, proj2;
-    const int32_t* faces;
-    const float* vertices;
-    const float* T;                         // (B,12) camera transforms written by the vertex stage
     // outputs
     float* rgba;
     int32_t* face_idx;
     float* imnormal;
+    // un-fused dibr_rasterization entry point only (mm_dibr.hip)
+    const float* feats; int D;              // (B,F,3,D) per-corner features
+    float* interp; float* soft_out; long long* face_idx64;
+    int options;                            // MM_OPT_* bits
 };
 
 #define MM_PAIR_ROUND 512
@@ -43,7 +39,7 @@ struct TileCtx {
     bool empty;                             // no face can touch the tile (known from the order kernel): nothing to walk
     float x0, y0;
     float xs[MM_TILE], ys[MM_TILE];         // pixel-centre columns / rows of the tile (same in every lane)
-    const uint64_t* mask;                   // streamed: this wave's bin row of candidate bits: `words` 64-bit words
+    const uint64_t* mask;                   // this wave's bin row of candidate bits: `words` 64-bit words
 };
 
 __device__ inline void tile_pixels(const RasterArgs& a, TileCtx& t) {
@@ -308,9 +304,10 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
     }
 }
 
-// launch plumbing shared by the two kernels' translation units
+// launch plumbing shared by the kernels' translation units
 RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w);
-bool resident_path(const MMRenderDesc* d);
-int launch_raster_fwd_resident(const MMRenderDesc* d, const Workspace& w, hipStream_t s);
+// heavy-first tile order for the walk kernels (mm_raster.hip); returns the order buffer to put in RasterArgs::order, or nullptr
+// where the sort does not pay (then the natural order is used)
+const unsigned short* launch_order(const RasterArgs& a, unsigned short* order, int B, void** prof_events, hipStream_t s);
 
 }  // namespace mm

@@ -1,0 +1,155 @@
+// mm_raster_walk.h -- the candidate walk of the streamed pixel kernels (gfx950): bin mask -> ordered candidate batches staged in
+// LDS -> box tests -> wave bit transposes -> balanced (pixel, candidate) pair evaluation with exact LDS atomics.  Shared by the
+// fused render kernel (mm_raster.hip) and by the un-fused kaolin-shaped dibr_rasterization entry point (mm_dibr.hip): both run
+// the SAME walk, so face_idx / barycentrics / soft-mask state are bit-identical between the two boundaries.
+#pragma once
+#include "mm_raster_common.h"
+
+namespace mm {
+
+
+// per-wave LDS staging: 64 candidates as three float4 rows + the id list of one mask group
+struct __attribute__((aligned(16))) WaveStage {
+    float4 p0[64];      // ax, ay, bx, by   (multiplier units)
+    float4 p1[64];      // cx, cy, az, bz
+    float4 p2[64];      // cz, unit normal z, face id (bits), 0
+    unsigned short ids[MM_GROUP_WORDS * 64];
+    unsigned short pairs[MM_PAIR_ROUND];    // (candidate << 8) | pixel, or (owner lane << 8) | candidate
+    unsigned long long key[64];             // per pixel: best (orderable z << 32 | ~face) so far; 0 = none
+    long long logsum[64];                   // per pixel: sum of log2(1-p) in 2^-32 fixed point (integer adds commute)
+    int zeros[64];                          // per pixel: number of factors (1-p) that are exactly 0
+};
+
+__device__ inline TileCtx make_tile(const RasterArgs& a) {
+    TileCtx t;
+    int blk;
+    // one wave per workgroup (a slow tile then never pins the LDS of finished neighbours).  Launch order: the tiles with
+    // the most candidates first (order_kernel), images interleaved -- the kernel's duration is set by its slowest waves, so
+    // they must not start last.  Workgroup i -> image i % B (XCD i % 8 = image % 8 when 8 | B), rank i / B.
+    if (a.order) {
+        t.b = blockIdx.x % a.B;
+        const unsigned e = a.order[(size_t)t.b * 4 * a.blocks_per_image + blockIdx.x / a.B];
+        const int slot = (int)(e & 0x7FFFu);
+        t.empty = (e >> 15) != 0;                                // the order kernel counted no candidate at all for this tile
+        blk = slot >> 2; t.wave = slot & 3;
+    } else {
+        map_block(blockIdx.x >> 2, a.B, a.blocks_per_image, t.b, blk);
+        t.wave = blockIdx.x & 3;
+        t.empty = false;
+    }
+    t.blk = blk;
+    t.lane = threadIdx.x & 63;
+    const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
+    const int tx0 = bx * MM_BLOCK_PX + (t.wave & 1) * MM_TILE, ty0 = by * MM_BLOCK_PX + (t.wave >> 1) * MM_TILE;
+    t.tx0 = tx0; t.ty0 = ty0;
+    tile_pixels(a, t);
+    // tiles never straddle bins (bin edge is 8, 16 or 32); a tile fully outside the image borrows the last bin
+    const int binx = min(tx0 >> a.bin_shift, a.nbx - 1), biny = min(ty0 >> a.bin_shift, a.nby - 1);
+    const size_t mrow = ((size_t)t.b * a.nbx * a.nby + (size_t)biny * a.nbx + binx) * a.words;
+    t.mask = a.binmask + mrow;
+    return t;
+}
+
+// Walk the bin's candidates in face order, 64 at a time.  For every batch the candidates are staged in st->p0/p1/p2[0..n)
+// and body(n, ph, ps) receives the batch's two hit matrices pixel-major (this lane's pixel, bit j = candidate j):
+//   ph  front faces whose box contains the pixel (colour);   ps  all faces whose inflated box contains it (silhouette;
+//   0 when want_soft() -- wave-uniform, asked once per batch -- says no pixel can take another silhouette face).
+template <class WantSoft, class Body>
+__device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, WantSoft&& want_soft, Body&& body) {
+    const float4* geo = a.geo + (size_t)t.b * a.F * 3;
+    for (int wbase = 0; wbase < a.words; wbase += MM_GROUP_WORDS) {
+        uint64_t w = 0;
+        if (t.lane < MM_GROUP_WORDS && wbase + t.lane < a.words) w = t.mask[wbase + t.lane];
+        int total;
+        int pos = wave_prefix_excl(__popcll(w), t.lane, total);
+        if (total == 0) continue;
+        while (w) {                                              // <= MM_GROUP_WORDS lanes, <= 64 iterations
+            const int bit = __ffsll((unsigned long long)w) - 1;
+            w &= w - 1;
+            st->ids[pos++] = (unsigned short)(t.lane * 64 + bit);
+        }
+        wave_lds_sync();
+        // batches of 64; the face records of batch k+1 are requested before batch k is evaluated (a tile with hundreds of
+        // candidates would otherwise pay a dependent trip to memory per batch)
+        float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+        int nf = 0;
+        auto fetch = [&](int k0) {
+            if (k0 + t.lane < total) {
+                nf = wbase * 64 + st->ids[k0 + t.lane];
+                n0 = geo[(size_t)nf * 3 + 0]; n1 = geo[(size_t)nf * 3 + 1]; n2 = geo[(size_t)nf * 3 + 2];
+            }
+        };
+        fetch(0);
+        for (int k0 = 0; k0 < total; k0 += 64) {
+            const int n = min(64, total - k0);
+            const float4 g0 = n0, g1 = n1, g2 = n2;
+            const int f = nf;
+            if (k0 + 64 < total) fetch(k0 + 64);
+            const bool soft = want_soft();
+            uint64_t mh = 0, ms = 0;                             // candidate-major: lane j = candidate j, bit p = pixel p
+            if (t.lane < n) {
+                st->p0[t.lane] = g0; st->p1[t.lane] = g1;
+                st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), __int_as_float(f));   // cz, nz, rank, face id
+                const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
+                const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
+                if (g2.y >= 0.f) mh = box_pixels(t, xmin - 0.f, ymin - 0.f, xmax + 0.f, ymax + 0.f);
+                if (soft) ms = box_pixels(t, xmin - a.infl, ymin - a.infl, xmax + a.infl, ymax + a.infl);
+            }
+            const uint64_t ph = __ballot(mh != 0) ? wave_transpose64(mh, t.lane) : 0ull;
+            const uint64_t ps = __ballot(ms != 0) ? wave_transpose64(ms, t.lane) : 0ull;
+            wave_lds_sync();
+            body(n, ph, ps);
+            wave_lds_sync();
+        }
+    }
+}
+
+__device__ inline void winner(const RasterArgs& a, const TileCtx& t, unsigned long long k, Hit& h) {
+    h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
+    if (k != 0ull) {                                             // barycentrics of the winner (same expressions, same values)
+        h.f = depth_key_rank(k);
+        const float4* geo = a.geo + ((size_t)t.b * a.F + h.f) * 3;
+        const float4 p0 = geo[0], p1 = geo[1];
+        float nrm;
+        edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, t.x0, t.y0, a.eps, h.w0, h.w1, h.w2, nrm);
+        h.w0 /= nrm; h.w1 /= nrm; h.w2 /= nrm;
+    }
+}
+
+
+// ONE walk over the tile's candidates serves both rules.
+// K1, nearest front face per pixel: kaolin walks faces in index order and keeps strict z > best, i.e. the winner is
+// argmax over (z, -index); that maximum is taken with a 64-bit LDS atomic max per (pixel, face) pair, which is exact
+// and order-free.  NaN and -inf depths never win, as in the reference.
+// K3, soft silhouette of the pixels no front face covers: prod(1-p) over the pixel's first knum nearby faces is
+// accumulated as an integer sum of log2(1-p) in 2^-32 fixed point (exact, commutative LDS adds) plus a count of exact
+// zeros.  A pixel takes silhouette faces while no face of the batches SO FAR covers it: for a pixel that stays
+// uncovered that is every batch, in order -- exactly the two-pass result; whatever a pixel gathered before a later
+// batch covered it is never looked at.
+__device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h, SoftState& ss) {
+    h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
+    ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
+    if (t.empty) return;                                         // wave-uniform: more than half of all tiles are empty
+    st->key[t.lane] = 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0;
+    wave_lds_sync();
+    const float s2 = a.sigmainv / (a.mult * a.mult);
+    int cnt = 0, lastf = 0x7FFFFFFF;
+    bool open = t.in_img;
+    for_each_batch(a, t, st, [&]() { return __ballot(open && cnt < a.knum) != 0; }, [&](int n, uint64_t ph, uint64_t ps) {
+        if (__ballot(ph != 0)) {
+            pair_parallel(t, st, ph, [&](int l, int j, bool live) { hard_pair(a, t, st, j, l, live); });   // pixel l, candidate j
+            open = t.in_img && st->key[t.lane] == 0ull;
+        }
+        const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
+        cnt += __popcll(sm);
+        if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].w);   // knum-th face taken
+        if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, s2, l, j, live); });
+    });
+    wave_lds_sync();
+    winner(a, t, st->key[t.lane], h);
+    ss.zeros = st->zeros[t.lane];
+    ss.qnz = exp2f((float)((double)st->logsum[t.lane] * (1.0 / 4294967296.0)));
+    ss.lastf = lastf;
+}
+
+}  // namespace mm

@@ -11,8 +11,6 @@
 
 namespace mm {
 
-bool resident_path(const MMRenderDesc* d);
-
 struct VertexFwdArgs {
     int B, V, F, H, W;
     float proj0, proj1, proj2, mult, infl;
@@ -78,47 +76,16 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     a.geo[o * 3 + 1] = make_float4(cx, cy, A.z, Bv.z);
     // the pixel box of the face inflated by the soft-mask margin (conservative, see pixel_range), packed for the backward's
     // face sweep: x = px0 | py0 << 16, y = width | height << 16 (0 x 0 if it misses the image)
-    int bx1, by1;
-    pixel_range(fminf(fminf(ax, bx), cx) - a.infl, fmaxf(fmaxf(ax, bx), cx) + a.infl, a.mult, a.W, false, bx0, bx1);
-    pixel_range(fminf(fminf(ay, by), cy) - a.infl, fmaxf(fmaxf(ay, by), cy) + a.infl, a.mult, a.H, true, by0, by1);
-    bw = bx1 - bx0 + 1; bh = by1 - by0 + 1;
-    const bool hit = bw > 0 && bh > 0;
-    a.geo[o * 3 + 2] = make_float4(C.z, nz, __uint_as_float(hit ? ((unsigned)bx0 | ((unsigned)by0 << 16)) : 0u),
-                                     __uint_as_float(hit ? ((unsigned)bw | ((unsigned)bh << 16)) : 0u));
+    unsigned org, ext;
+    face_pixel_box(ax, ay, bx, by, cx, cy, a.infl, a.mult, a.W, a.H, bx0, by0, bw, bh, org, ext);
+    a.geo[o * 3 + 2] = make_float4(C.z, nz, __uint_as_float(org), __uint_as_float(ext));
     a.face_normals[o * 3 + 0] = nx; a.face_normals[o * 3 + 1] = ny; a.face_normals[o * 3 + 2] = nz;
     }
 
-    // ---- screen binning: this wave's 64 faces are exactly mask word c ---------------------------------------------------
-    // A lane turns its face's pixel box (inflated by the soft-mask margin, conservative) into bin column / row ranges.  Per
-    // block of 8x8 bins the lane's coverage is a 64-bit row-major bit matrix (rows x columns outer product); ONE wave
-    // transpose turns the 64 faces' coverage words into the 64 bins' mask words, stored plainly -- every word of every bin is
-    // written (blocks no face touches skip the transpose): no atomics, no zero-fill, no second pass over the face records.
-    // The raster kernel re-tests every (pixel, face) pair exactly, so a conservative mask changes no result.
-    const int c = blockIdx.x * 4 + (tid >> 6), lane = tid & 63;
+    // ---- screen binning: this wave's 64 faces are exactly mask word c (bin_wave_faces, mm_device.h) ---------------------------
+    const int c = blockIdx.x * 4 + (tid >> 6);
     if (a.mask == nullptr || c >= a.words) return;
-    int c0 = 0, c1 = -1, r0 = 0, r1 = -1;                         // bin columns / rows the box touches (none)
-    if (bw > 0 && bh > 0) {
-        c0 = bx0 >> a.bin_shift; c1 = (bx0 + bw - 1) >> a.bin_shift;
-        r0 = by0 >> a.bin_shift; r1 = (by0 + bh - 1) >> a.bin_shift;
-    }
-    const int sbx = (a.nbx + 7) >> 3, sby = (a.nby + 7) >> 3;
-    for (int s = 0; s < sbx * sby; ++s) {
-        const int kx0 = (s % sbx) * 8, ky0 = (s / sbx) * 8;
-        const int clo = max(c0 - kx0, 0), chi = min(c1 - kx0, 7), rlo = max(r0 - ky0, 0), rhi = min(r1 - ky0, 7);
-        const unsigned col = chi >= clo ? ((2u << chi) - (1u << clo)) : 0u;       // bits clo..chi
-        const unsigned row = rhi >= rlo ? ((2u << rhi) - (1u << rlo)) : 0u;
-        unsigned lo = 0, hi = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            lo |= ((row >> r) & 1u) ? (col << (8 * r)) : 0u;
-            hi |= ((row >> (r + 4)) & 1u) ? (col << (8 * r)) : 0u;
-        }
-        const uint64_t cov = ((uint64_t)hi << 32) | lo;           // bit (r*8+c): this face touches bin (ky0+r, kx0+c)
-        uint64_t word = 0;
-        if (__ballot(cov != 0)) word = wave_transpose64(cov, lane);               // lane j: bit i = face c*64+i touches bin j
-        const int kx = kx0 + (lane & 7), ky = ky0 + (lane >> 3);
-        if (kx < a.nbx && ky < a.nby) a.mask[((size_t)b * a.nbx * a.nby + (size_t)ky * a.nbx + kx) * a.words + c] = word;
-    }
+    bin_wave_faces(a.mask, b, a.nbx, a.nby, a.words, a.bin_shift, c, tid & 63, bx0, by0, bw, bh);
 }
 
 struct VertexBwdArgs {
@@ -286,7 +253,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B;
     a.ltot = w.ltot; a.nltot = d->B * MM_LSUB * 4;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
-    a.mask = resident_path(d) ? nullptr : w.binmask;            // the LDS-resident forward builds its own lists
+    a.mask = w.binmask;
     dim3 grid((d->F + 255) / 256, d->B);
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
       hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }

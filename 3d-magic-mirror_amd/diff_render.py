@@ -148,7 +148,7 @@ class DiffRender(object):
         self.lambda_flat = lambda_flat
         self.ratio = ratio
         self.emit_imnormal = emit_imnormal
-        self.options = 0                                # MMRenderDesc.options (N.OPT_RESIDENT: LDS-resident forward kernel)
+        self.options = 0                                # MMRenderDesc.options: MM_OPT_* bits (SURVEY Appendix C switches); 0 = defaults
         camera_fovy = np.arctan(1.0 / 2.5) * 2
         self.cam_proj = template.generate_perspective_projection(camera_fovy, ratio=1 / ratio)     # networks.py:172-174
         mesh = obj_io.load_template(mesh_name)                                                   # :176
@@ -179,26 +179,6 @@ class DiffRender(object):
             print("Unique Edge Number: %d" % self.edges.shape[0])
 
     # ---- device-resident static template data (the reference re-uploads faces/face_uvs on every call, :272-273) ----
-    def _uv_tiles(self, device, Ht, Wt):
-        """Static texture-space tiling for the backward gather (mm_build_uv_tiles), cached per texture size and device."""
-        key = (str(device), Ht, Wt)
-        hit = self._static_cache.get(key)
-        if hit is None:
-            L = N.lib()
-            fuv = self.face_uvs.to(torch.float32).reshape(-1, 3, 2).contiguous().numpy()
-            nt = ((Wt + N.UV_TILE - 1) // N.UV_TILE) * ((Ht + N.UV_TILE - 1) // N.UV_TILE)
-            offsets = np.zeros(nt + 1, dtype=np.int32)
-            need = ctypes.c_int64(0)
-            N.check(L.mm_build_uv_tiles(self.num_faces, fuv.ctypes.data_as(ctypes.c_void_p), Ht, Wt,
-                                        offsets.ctypes.data_as(ctypes.c_void_p), None, 0, ctypes.byref(need)), "mm_build_uv_tiles")
-            items = np.zeros(max(1, need.value), dtype=np.int32)
-            N.check(L.mm_build_uv_tiles(self.num_faces, fuv.ctypes.data_as(ctypes.c_void_p), Ht, Wt,
-                                        offsets.ctypes.data_as(ctypes.c_void_p), items.ctypes.data_as(ctypes.c_void_p),
-                                        items.size, ctypes.byref(need)), "mm_build_uv_tiles")
-            hit = (torch.from_numpy(offsets).to(device), torch.from_numpy(items).to(device))
-            self._static_cache[key] = hit
-        return hit
-
     def _static(self, device):
         key = str(device)
         st = self._static_cache.get(key)

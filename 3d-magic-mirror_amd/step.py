@@ -35,7 +35,10 @@ class HipEvents:
     def elapsed_ms(self, slot):
         ms = ctypes.c_float()
         rc = self.hip.hipEventElapsedTime(ctypes.byref(ms), self.arr[2 * slot], self.arr[2 * slot + 1])
-        return ms.value if rc == 0 else float("nan")
+        if rc != 0:
+            self.hip.hipGetLastError()          # a slot the library did not run (never-recorded events): do not leave the error
+            return float("nan")                 # behind for the caller's next runtime call to trip over
+        return ms.value
 
 
 class RenderLossStep:

@@ -40,8 +40,11 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 CLOCK_MHZ = 2400.0          # MI355X_MICROARCH.md: max shader clock
 SIMDS = 1024                # 256 CUs x 4 SIMD-32
-VALU_CYCLES = 2.0           # cycles a wave64 VALU instruction occupies its SIMD-32 (MI355X_MICROARCH.md; measured on the box by
-                            # profiles/tools/valu_calib.hip -> profiles/r02_valu_calibration.json)
+VALU_CYCLES = 2.0           # cycles a wave64 VALU instruction occupies its SIMD-32 (MI355X_MICROARCH.md: SIMD-32, 157.3 TF fp32 peak)
+VALU_RATE = 875.8           # MEASURED sustained issue rate, wave-instructions per microsecond per SIMD (independent v_fma_f32, 8 waves
+                            # per SIMD, all 256 CUs: profiles/tools/valu_calib.hip -> profiles/r02_valu_calibration.json).  That is
+                            # 2.74 cycles at the nominal 2.4 GHz, i.e. 2 cycles at the ~1.75 GHz the chip sustains under an all-VALU
+                            # load; a SIMD-16 (4 cycles) could not exceed 600.  Floors below use the measured rate.
 
 CONFIGS = {
     # name: (template, B, image_size, ratio)
@@ -117,7 +120,6 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps are enqueued on round-robin")
     ap.add_argument("--rotate", type=int, default=8, help="distinct synthetic input batches per stream, visited in turn")
     ap.add_argument("--unfused", action="store_true", help="recon_data as its own three launches instead of folded into the render kernels")
-    ap.add_argument("--resident", action="store_true", help="opt into the LDS-resident forward kernel (MM_OPT_RESIDENT)")
     ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed run-in before the warmup steps (clock ramp)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget, all threads (0 disables)")
     ap.add_argument("--cpu-single-seconds", type=float, default=8.0, help="CPU-baseline budget, one thread (0 disables)")
@@ -148,8 +150,6 @@ def main():
     name, B, S, ratio = CONFIGS[args.config]
     tpath = os.path.join(ROOT, "tests", "golden", "templates", name + ".npz")
     dr = pkg.DiffRender(tpath, S, ratio=ratio, emit_imnormal=False)
-    if args.resident:
-        dr.options = pkg._native.OPT_RESIDENT
     H, W = dr.render_height, dr.image_size
     nstreams = max(1, args.streams) if args.mode == "eager" else 1
     nrot = max(1, args.rotate)
@@ -318,17 +318,18 @@ def main():
                                    "frac_overlapped": round(step_bytes / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBPS, 5),
                                    "frac_one_stream": round(step_bytes / (step_us_one * 1e-6) / 1e9 / PEAK_HBM_GBPS, 5) if step_us_one else None}}
         # Second roof, reported beside the HBM one: vector-instruction issue.  A wave64 VALU instruction occupies its SIMD-32 for
-        # VALU_CYCLES cycles (calibrated on the box: profiles/r02_valu_calibration.json), so a step cannot take less than
-        # sum(SQ_INSTS_VALU) * VALU_CYCLES / (1024 SIMDs * 2.4 GHz).  Counts: the committed rocprofv3 --pmc pass of this workload.
+        # 2 cycles; the chip SUSTAINS VALU_RATE wave-instructions per microsecond per SIMD (measured, profiles/r02_valu_calibration.json),
+        # so a step cannot take less than sum(SQ_INSTS_VALU) / (1024 SIMDs * VALU_RATE).  Counts: the committed rocprofv3 --pmc pass.
         insts, vnote = load_counters("valu", args.config)
         if insts:
             tot = sum(v for v in insts.values() if isinstance(v, (int, float)))
-            floor_us = tot * VALU_CYCLES / SIMDS / CLOCK_MHZ
+            floor_us = tot / SIMDS / VALU_RATE
             step_us = elapsed / args.steps * 1e6
-            roofline["valu_issue"] = {"insts_per_step": int(tot), "cycles_per_inst": VALU_CYCLES, "floor_us_per_step": round(floor_us, 2),
+            roofline["valu_issue"] = {"insts_per_step": int(tot), "cycles_per_inst": VALU_CYCLES, "measured_issue_rate_per_simd_per_us": VALU_RATE,
+                                      "floor_us_per_step": round(floor_us, 2), "floor_us_at_nominal_clock": round(tot * VALU_CYCLES / SIMDS / CLOCK_MHZ, 2),
                                       "measured_us_per_step": round(step_us, 2), "frac": round(floor_us / step_us, 4),
                                       "frac_one_stream": round(floor_us / step_us_one, 4) if step_us_one else None,
-                                      "dominant_kernel_frac": round(insts.get(dom, 0) * VALU_CYCLES / SIMDS / CLOCK_MHZ / kernels_us[dom], 4)}
+                                      "dominant_kernel_frac": round(insts.get(dom, 0) / SIMDS / VALU_RATE / kernels_us[dom], 4)}
         else:
             roofline["valu_issue"] = {"note": vnote}
 

@@ -39,7 +39,7 @@ typedef enum MMStatus {
     MM_ERR_BAD_SHAPE = -2,      /* a size is <= 0 or inconsistent */
     MM_ERR_WORKSPACE = -3,      /* workspace missing or smaller than mm_query_workspace() */
     MM_ERR_LAUNCH = -4,         /* hipLaunchKernel / hipMemsetAsync reported an error */
-    MM_ERR_UNSUPPORTED = -5     /* option outside what the kernels implement (e.g. knum > 64) */
+    MM_ERR_UNSUPPORTED = -5     /* outside what the kernels implement (knum <= 0, image side > 65535, > MM_DIBR_MAX_D channels) */
 } MMStatus;
 
 /* --------------------------------------------------------------------------------------------------------------------
@@ -61,9 +61,6 @@ typedef struct MMRenderDesc {
     const float* face_uvs;      /* (F,3,2) raw OBJ uv of every corner (networks.py:196-202) */
     const int32_t* vc_offsets;  /* (V+1) CSR: vertex -> incident corners ...        (backward only; may be NULL forward) */
     const int32_t* vc_items;    /* (3F)  ... each item = face*3 + corner, ascending (backward only) */
-    const int32_t* uvt_offsets; /* reserved, may be NULL: static texture tile -> faces lists (mm_build_uv_tiles).  The texture */
-    const int32_t* uvt_faces;   /*   gradient is gathered from per-tile RECORD lists written by the pixel backward instead, so   */
-    int32_t uvt_size;           /*   these are no longer read; kept so that the struct layout stays stable                      */
     const int32_t* face_order;  /* (F) optional: faces sorted by decreasing template area; only the ORDER in which the
                                  *     backward visits faces depends on it (big screen boxes first); NULL = index order */
     /* per-sample attributes (device), the 'attributes' dict of networks.py:259-270 */
@@ -94,17 +91,23 @@ typedef struct MMRenderDesc {
     float fused_image_weight;       /* DiffRender.image_weight */
     float* fused_loss;              /* (1) device scalar, written by mm_render_backward; may be NULL */
     const float* fused_grad_loss;   /* (1) device scalar dL/dloss, or NULL for 1 */
-    int32_t options;                /* bit set of MM_OPT_*; 0 = let the library choose */
+    int32_t options;                /* bit set of MM_OPT_* (below); 0 = the semantics of SURVEY.md 8(a) */
 } MMRenderDesc;
 
-/* mm_render_forward has two pixel kernels with bit-identical results: "streamed" (any mesh size, via screen-bin masks; the
- * default) and "resident" (templates whose transformed vertices fit the LDS of a workgroup -- the reference's 642-vertex
- * meshes: fewer vector instructions and no bin / order launches, but a longer tail; opt-in while it is being tuned). */
-enum { MM_OPT_STREAMED = 1,         /* force the streamed kernels */
-       MM_OPT_RESIDENT = 2 };       /* use the resident kernel when the template fits (else streamed) */
+/* MMRenderDesc.options / MMDibrDesc.options: 0 = the semantics of SURVEY.md 8(a) (the oracle's defaults).  The bits switch,
+ * one by one, the choices that SURVEY.md Appendix C lists as recalled from kaolin's sources and not re-verifiable here
+ * (kaolin is not vendored): a maintainer with a CUDA box and real kaolin can pin the path by flipping a bit instead of
+ * editing kernels.  oracle/mm_oracle.inc takes the same bits, and tests/ hold HIP == oracle for every one of them. */
+enum { MM_OPT_CULL_STRICT = 1 << 4,        /* rasterise faces with face_normals_z > 0 instead of >= 0                    (App. C-1) */
+       MM_OPT_SOFT_SKIP_CULLED = 1 << 5,   /* the soft mask skips the faces the colour pass culls                          (App. C-1) */
+       MM_OPT_BBOX_HALF_OPEN = 1 << 6,     /* a pixel centre exactly on a face's bbox edge is outside (<= / >= reject)     (App. C-4) */
+       MM_OPT_BARY_ONE_MINUS = 1 << 7,     /* barycentrics as w1 = k1/(S+eps), w2 = k2/(S+eps), w0 = 1 - w1 - w2 (eps added, not
+                                            * copysign'd) instead of three edge functions / copysign-padded sum          (App. C-3) */
+       MM_OPT_SH_ORDER_XYZ = 1 << 8 };     /* SH linear bands in x,y,z order and quadratic bands xy,yz,3z^2-1,xz,x^2-y^2 paired with
+                                            * lights 1..8 in THAT order (instead of x,z,y / xy,yz,z^2,xz,x^2-y^2)          (App. C-6) */
 
 enum { MM_PROF_VERTEX_FWD = 0, MM_PROF_RASTER_FWD = 1, MM_PROF_PIXEL_BWD = 2, MM_PROF_GATHER_BWD = 3, MM_PROF_VERTEX_BWD = 4,
-       MM_PROF_BIN = 5 /* unused: binning is part of the vertex stage */, MM_PROF_ORDER = 6, MM_PROF_RENDER_SLOTS = 7 };
+       MM_PROF_ORDER = 5, MM_PROF_RENDER_SLOTS = 6 };
 enum { MM_PROF_RECON_PARTIAL = 0, MM_PROF_RECON_FINAL = 1, MM_PROF_RECON_BWD = 2, MM_PROF_RECON_CONTOUR = 3,
        MM_PROF_RECON_SLOTS = 4 };
 
@@ -264,20 +267,141 @@ int mm_texture_flow_forward(const MMTexFlowDesc* desc, mm_stream_t stream);
 int mm_texture_flow_backward(const MMTexFlowDesc* desc, const MMTexFlowGrads* grads, mm_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------------------------------
+ * Op boundary: the kaolin / pytorch3d operators the reference imports at module top (networks.py:6-19, trainer.py:31-40),
+ * un-fused, one entry point per operator and direction.  The Python package 3d-magic-mirror_amd/shim exposes them under
+ * kaolin's own module paths and signatures, so networks.py / trainer.py import and run unmodified.
+ * They run the SAME device code as the fused render path (the same candidate walk, barycentrics, bilinear fetch and SH bands),
+ * so face_idx is identical between the two boundaries.  Upstream semantics: NVIDIAGameWorks/kaolin v0.12.0 (not vendored;
+ * restated in SURVEY.md 8(a)); gradients SURVEY.md Appendix A.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* kaolin.render.mesh.prepare_vertices(vertices, faces, camera_proj, camera_transform=...)   (call site networks.py:284-287):
+ * vc = [v,1] @ T; vi = (vc.xy * proj.xy) / (vc.z * proj.z); gather by faces; unit normals with +1e-10 on the length. */
+typedef struct MMPrepareDesc {
+    int32_t B, V, F;
+    float proj[3];                  /* camera_proj (3,1) */
+    const int32_t* faces;           /* (F,3) */
+    const int32_t* vc_offsets;      /* (V+1) vertex -> corner CSR (mm_build_vertex_corner_csr); backward only */
+    const int32_t* vc_items;        /* (3F) */
+    const float* vertices;          /* (B,V,3) */
+    const float* transform;         /* (B,4,3) camera_transform [R;t] */
+    float* face_vertices_camera;    /* (B,F,3,3) */
+    float* face_vertices_image;     /* (B,F,3,2) */
+    float* face_normals;            /* (B,F,3)   */
+    void* workspace;                /* backward only: >= mm_prepare_vertices_query_workspace bytes (per-workgroup dT partials) */
+    size_t workspace_bytes;
+} MMPrepareDesc;
+
+typedef struct MMPrepareGrads {
+    const float* grad_face_vertices_camera;  /* (B,F,3,3) or NULL */
+    const float* grad_face_vertices_image;   /* (B,F,3,2) or NULL */
+    const float* grad_face_normals;          /* (B,F,3)   or NULL */
+    float* grad_vertices;                    /* (B,V,3) overwritten */
+    float* grad_transform;                   /* (B,4,3) overwritten, or NULL */
+} MMPrepareGrads;
+
+size_t mm_prepare_vertices_query_workspace(const MMPrepareDesc* desc);
+int mm_prepare_vertices_forward(const MMPrepareDesc* desc, mm_stream_t stream);
+int mm_prepare_vertices_backward(const MMPrepareDesc* desc, const MMPrepareGrads* grads, mm_stream_t stream);
+
+/* kaolin.ops.mesh.face_normals(face_vertices (n,3,3), unit)   (call site networks.py:289): cross(v1-v0, v2-v0), optionally
+ * divided by (length + 1e-10).  n = B*F faces.  backward: grad_normals (n,3) -> grad_face_vertices (n,3,3), overwritten. */
+int mm_face_normals_forward(int64_t n, int32_t unit, const float* face_vertices, float* normals, mm_stream_t stream);
+int mm_face_normals_backward(int64_t n, int32_t unit, const float* face_vertices, const float* grad_normals,
+                             float* grad_face_vertices, mm_stream_t stream);
+
+/* kaolin.render.mesh.dibr_rasterization(height, width, face_vertices_z, face_vertices_image, face_features, face_normals_z,
+ * sigmainv=7000, boxlen=0.02, knum=30, multiplier=1000, eps=1e-8)   (call site networks.py:297-299)
+ *   = rasterize (kaolin._C packed_rasterize_forward_cuda / rasterize_backward_cuda, K1/K2)
+ *   + dibr_soft_mask (dibr_soft_mask_forward_cuda / _backward_cuda, K3/K4).
+ * Outputs as kaolin returns them: interpolated features (zeros where uncovered), soft mask, int64 face_idx (-1 = none).
+ * Gradients only to face_vertices_image and face_features (none to z / normals_z, like upstream). */
+#define MM_DIBR_MAX_D 32            /* feature channels per corner the backward's LDS accumulators hold */
+typedef struct MMDibrDesc {
+    int32_t B, H, W, F, D, knum;
+    float sigmainv, boxlen, multiplier, eps;
+    const float* face_vertices_z;       /* (B,F,3) */
+    const float* face_vertices_image;   /* (B,F,3,2) */
+    const float* face_features;         /* (B,F,3,D) (a list of feature tensors is concatenated by the caller) */
+    const float* face_normals_z;        /* (B,F) : faces with normal z >= 0 are rasterised */
+    float* interpolated_features;       /* (B,H,W,D) */
+    float* soft_mask;                   /* (B,H,W) */
+    int64_t* face_idx;                  /* (B,H,W) */
+    void* workspace;                    /* >= mm_dibr_query_workspace bytes, 256-byte aligned; filled by the forward, read by the backward */
+    size_t workspace_bytes;
+    int32_t options;                    /* MM_OPT_* bits (0 = defaults) */
+} MMDibrDesc;
+
+typedef struct MMDibrGrads {
+    const float* grad_interpolated_features;   /* (B,H,W,D) or NULL */
+    const float* grad_soft_mask;               /* (B,H,W)   or NULL */
+    float* grad_face_vertices_image;           /* (B,F,3,2) overwritten */
+    float* grad_face_features;                 /* (B,F,3,D) overwritten, or NULL */
+} MMDibrGrads;
+
+size_t mm_dibr_query_workspace(const MMDibrDesc* desc);
+int mm_dibr_rasterization_forward(const MMDibrDesc* desc, mm_stream_t stream);
+int mm_dibr_rasterization_backward(const MMDibrDesc* desc, const MMDibrGrads* grads, mm_stream_t stream);
+
+/* kaolin.render.mesh.texture_mapping(texture_coordinates, texture_maps, mode)   (call site networks.py:305)
+ * = F.grid_sample(maps, (2u-1, -(2v-1)), mode, align_corners=False, padding_mode='border').  N = points per batch item (H*W). */
+enum { MM_TEXMAP_NEAREST = 0, MM_TEXMAP_BILINEAR = 1 };
+typedef struct MMTexMapDesc {
+    int32_t B, N, C, Ht, Wt, mode;
+    const float* uv;                /* (B,N,2) */
+    const float* textures;          /* (B,C,Ht,Wt) */
+    float* out;                     /* (B,N,C) */
+} MMTexMapDesc;
+typedef struct MMTexMapGrads {
+    const float* grad_out;          /* (B,N,C) */
+    float* grad_uv;                 /* (B,N,2) overwritten, or NULL (zero for MM_TEXMAP_NEAREST) */
+    float* grad_textures;           /* (B,C,Ht,Wt) overwritten (zero-filled on the stream, then float atomics), or NULL */
+} MMTexMapGrads;
+int mm_texture_mapping_forward(const MMTexMapDesc* desc, mm_stream_t stream);
+int mm_texture_mapping_backward(const MMTexMapDesc* desc, const MMTexMapGrads* grads, mm_stream_t stream);
+
+/* kaolin.render.mesh.spherical_harmonic_lighting(imnormal (B,N,3), lights (B,9)) -> (B,N)   (call site networks.py:306) */
+typedef struct MMShDesc {
+    int32_t B, N;
+    const float* normals;           /* (B,N,3) */
+    const float* lights;            /* (B,9) */
+    float* out;                     /* (B,N) */
+} MMShDesc;
+typedef struct MMShGrads {
+    const float* grad_out;          /* (B,N) */
+    float* grad_normals;            /* (B,N,3) overwritten, or NULL */
+    float* grad_lights;             /* (B,9) overwritten (zero-filled on the stream, one float atomic per wave and band), or NULL */
+} MMShGrads;
+int mm_sh_lighting_forward(const MMShDesc* desc, mm_stream_t stream);
+int mm_sh_lighting_backward(const MMShDesc* desc, const MMShGrads* grads, mm_stream_t stream);
+
+/* kaolin.metrics.render.mask_iou(lhs (B,H,W), rhs (B,H,W)) = 1 - mean_b[ sum(l*r) / (sum(l+r-l*r) + 1e-10) ]
+ * (call sites networks.py:377, trainer.py:793,933).  sums: (B,2) device scratch written by the forward and read by the backward. */
+typedef struct MMMaskIouDesc {
+    int32_t B, N;                   /* N = H*W */
+    const float* lhs; const float* rhs;
+    float* sums;                    /* (B,2): {sum l*r, sum l+r-l*r} */
+    float* loss;                    /* (1) */
+} MMMaskIouDesc;
+int mm_mask_iou_forward(const MMMaskIouDesc* desc, mm_stream_t stream);
+int mm_mask_iou_backward(const MMMaskIouDesc* desc, const float* grad_loss, float* grad_lhs, float* grad_rhs, mm_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------------------------------
  * Host helpers (no GPU involved)
  * ------------------------------------------------------------------------------------------------------------------ */
-/* Texture-space tiling used by the backward (static per template and texture size).  A face is listed in every tile
- * its uv triangle (+1 texel) can touch; exactly one of those entries carries bit 31 (the face's primary tile).
- * Query: items == NULL -> *needed receives the number of entries.  offsets: (ntiles+1) with
- * ntiles = ceil(Wt/MM_UV_TILE) * ceil(Ht/MM_UV_TILE). */
-#define MM_UV_TILE 32
-int mm_build_uv_tiles(int32_t F, const float* face_uvs_host, int32_t Ht, int32_t Wt, int32_t* offsets_host,
-                      int32_t* items_host, int64_t capacity, int64_t* needed);
 /* Build the vertex -> corner CSR from HOST faces (F,3).  offsets: (V+1), items: (3F).  Returns MM_OK or an error. */
 int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces_host, int32_t* offsets_host, int32_t* items_host);
 const char* mm_status_string(int status);
 /* After MM_ERR_LAUNCH on this host thread: "<kernel>: <hipGetErrorString> (hipError n)"; "" if none was recorded. */
 const char* mm_last_error_detail(void);
+/* Layout guard for bindings that mirror the structs by hand (ctypes, cgo, JNI): sizeof of struct #which as the library was
+ * compiled, 0 for an unknown id.  Ids: 0 MMRenderDesc, 1 MMRenderGrads, 2 MMReconDesc, 3 MMMeshRegDesc, 4 MMMeshRegGrads,
+ * 5 MMAttLossDesc, 6 MMAttLossGrads, 7 MMTexFlowDesc, 8 MMTexFlowGrads, 9 MMPrepareDesc, 10 MMPrepareGrads, 11 MMDibrDesc,
+ * 12 MMDibrGrads, 13 MMTexMapDesc, 14 MMTexMapGrads, 15 MMShDesc, 16 MMShGrads, 17 MMMaskIouDesc. */
+size_t mm_struct_size(int which);
+/* Bumped whenever a struct or the meaning of a field changes (2: op boundary added, reserved uv-tile fields and profiling slot
+ * MM_PROF_BIN removed, options bits defined).  Bindings must refuse a library whose version differs from what they mirror. */
+#define MM_ABI_VERSION 2
 int mm_abi_version(void);
 
 #ifdef __cplusplus

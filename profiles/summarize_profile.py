@@ -91,16 +91,16 @@ if pmc:
         if alg and k in dur:
             lines.append("| %s | %.1f | %.1f | %.0f | %.3f | %.1f | %.2f | %.0f |" % (k, alg / 1e6, dur[k], alg / dur[k] / 1e3, alg / dur[k] / 1e3 / 8000,
                                                                                b / 1e6, b / alg, 100 * hit / max(1, hit + miss)))
-    lines += ["", "## Vector-instruction issue and occupancy (floor = SQ_INSTS_VALU x %.0f cycles over 1024 SIMD-32 at 2.4 GHz; "
-                  "cycles per instruction calibrated in profiles/%s_valu_calibration.json)" % (bench.VALU_CYCLES, tag), "",
-              "| kernel | waves | VGPR | LDS B/WG | VALU instr | VALU/wave | LDS instr | issue floor us | measured us | floor/measured | wave-cycles waiting % |",
+    lines += ["", "## Vector-instruction issue and occupancy (floor = SQ_INSTS_VALU / (1024 SIMD-32 x %.1f wave-instructions/us, the sustained "
+                  "rate MEASURED in profiles/r02_valu_calibration.json = 2 cycles each at ~1.75 GHz; at the nominal 2.4 GHz the floor would be x0.73)" % bench.VALU_RATE, "",
+              "| kernel | waves | VGPR (rocprofv3) | LDS B/WG | VALU instr | VALU/wave | LDS instr | issue floor us | measured us | floor/measured | wave-cycles waiting % |",
               "|---|---|---|---|---|---|---|---|---|---|---|"]
     tot_floor = 0.0
     for k, c in sorted(pmc.items()):
         if "SQ_INSTS_VALU" not in c or k not in dur:
             continue
         valu[kname(k)] = c["SQ_INSTS_VALU"]
-        floor = c["SQ_INSTS_VALU"] * bench.VALU_CYCLES / bench.SIMDS / bench.CLOCK_MHZ
+        floor = c["SQ_INSTS_VALU"] / bench.SIMDS / bench.VALU_RATE
         tot_floor += floor
         wait = 100 * c.get("SQ_WAIT_ANY", 0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1))
         lines.append("| %s | %.0f | %s | %s | %.0f | %.0f | %.0f | %.1f | %.1f | %.2f | %.0f |" % (

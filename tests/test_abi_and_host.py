@@ -11,19 +11,30 @@ import torch
 
 from conftest import GOLDEN, ROOT, TEMPLATES
 
+N_MAX_D = 32          # MM_DIBR_MAX_D
+
 
 def test_library_exports_every_declared_symbol(pkg):
     hdr = open(os.path.join(ROOT, "include", "mm_render.h")).read()
     declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(mm_\w+)\s*\(", hdr, flags=re.M))
     assert {"mm_render_forward", "mm_render_backward", "mm_recon_data_forward", "mm_recon_data_backward",
-            "mm_query_workspace", "mm_recon_query_workspace", "mm_build_uv_tiles", "mm_build_vertex_corner_csr"} <= declared
+            "mm_query_workspace", "mm_recon_query_workspace", "mm_build_vertex_corner_csr", "mm_dibr_rasterization_forward",
+            "mm_prepare_vertices_forward", "mm_texture_mapping_forward", "mm_sh_lighting_forward", "mm_mask_iou_forward"} <= declared
     from importlib import import_module
     N = import_module("3d-magic-mirror_amd._native")
     lib = N.lib()
     for name in declared:
         assert hasattr(lib, name), name
     assert set(N.EXPORTS) == declared
-    assert lib.mm_abi_version() >= 1
+    assert lib.mm_abi_version() == N.ABI_VERSION == int(re.search(r"#define MM_ABI_VERSION (\d+)", hdr).group(1))
+    # every struct the header declares is mirrored field for field: same size as the library compiled it (N.lib() also checks)
+    names = re.findall(r"^typedef struct (MM\w+) \{", hdr, flags=re.M)
+    ids = re.search(r"Ids: (.*?)\. \*/", hdr, flags=re.S).group(1).replace("\n", " ").replace("*", " ")
+    table = {m.group(2): int(m.group(1)) for m in re.finditer(r"(\d+) (MM\w+)", ids)}
+    assert set(names) - {"MMAttributes"} == set(table), (sorted(names), sorted(table))
+    for nm, i in table.items():
+        assert lib.mm_struct_size(i) == ctypes.sizeof(getattr(N, nm)) > 0, nm
+    assert lib.mm_struct_size(99) == 0
     assert lib.mm_status_string(-3).decode().startswith("workspace")
     assert lib.mm_last_error_detail().decode() == ""            # nothing launched, nothing recorded
     # struct layout agrees with the header (the library sizes the workspace from the same struct)
@@ -38,6 +49,17 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.mm_render_forward(None, None) == -1                       # MM_ERR_NULL_POINTER
     r = N.MMReconDesc()
     assert lib.mm_recon_data_forward(ctypes.byref(r), None) == -2
+    # the op boundary validates before launching too
+    assert lib.mm_dibr_rasterization_forward(None, None) == -1 and lib.mm_dibr_rasterization_forward(ctypes.byref(N.MMDibrDesc()), None) == -2
+    q = N.MMDibrDesc(); q.B, q.H, q.W, q.F, q.D, q.knum = 1, 8, 8, 4, N_MAX_D + 1, 30
+    assert lib.mm_dibr_rasterization_forward(ctypes.byref(q), None) == -5                # MM_ERR_UNSUPPORTED: too many channels
+    q.D = 3
+    assert lib.mm_dibr_query_workspace(ctypes.byref(q)) % 256 == 0 and lib.mm_dibr_rasterization_forward(ctypes.byref(q), None) == -1
+    assert lib.mm_prepare_vertices_forward(ctypes.byref(N.MMPrepareDesc()), None) == -2
+    assert lib.mm_texture_mapping_forward(ctypes.byref(N.MMTexMapDesc()), None) == -2
+    assert lib.mm_sh_lighting_forward(ctypes.byref(N.MMShDesc()), None) == -2
+    assert lib.mm_mask_iou_forward(ctypes.byref(N.MMMaskIouDesc()), None) == -2
+    assert lib.mm_face_normals_forward(0, 1, None, None, None) == -1
 
 
 def test_host_csr_builders(pkg):
@@ -52,29 +74,6 @@ def test_host_csr_builders(pkg):
                                           items.ctypes.data_as(ctypes.c_void_p)) == 0
     ro, ri = pkg.template.vertex_corner_adjacency(V, dr.faces)
     np.testing.assert_array_equal(off, ro.numpy()); np.testing.assert_array_equal(items, ri.numpy())
-    # uv tiles: every face appears, exactly one primary entry per face, tiles cover each corner's texel
-    fuv = dr.face_uvs.reshape(-1, 3, 2).contiguous().numpy()
-    Ht, Wt, TS = 128, 64, N.UV_TILE
-    nt = ((Wt + TS - 1) // TS) * ((Ht + TS - 1) // TS)
-    toff = np.zeros(nt + 1, np.int32); need = ctypes.c_int64(0)
-    assert lib.mm_build_uv_tiles(F, fuv.ctypes.data_as(ctypes.c_void_p), Ht, Wt, toff.ctypes.data_as(ctypes.c_void_p), None, 0, ctypes.byref(need)) == 0
-    ent = np.zeros(need.value, np.int32)
-    assert lib.mm_build_uv_tiles(F, fuv.ctypes.data_as(ctypes.c_void_p), Ht, Wt, toff.ctypes.data_as(ctypes.c_void_p),
-                                 ent.ctypes.data_as(ctypes.c_void_p), ent.size, ctypes.byref(need)) == 0
-    assert toff[0] == 0 and toff[-1] == need.value and (np.diff(toff) >= 0).all()
-    fid = ent & 0x7FFFFFFF
-    assert set(fid.tolist()) == set(range(F))
-    assert np.bincount(fid[ent < 0], minlength=F).tolist() == [1] * F
-    ntx = (Wt + TS - 1) // TS
-    tile_of = np.repeat(np.arange(nt), np.diff(toff))
-    for f in (0, 7, F - 1):
-        tiles = set(tile_of[fid == f].tolist())
-        for k in range(3):
-            ix = min(max(int(np.floor(fuv[f, k, 0] * Wt - 0.5)), 0), Wt - 1); iy = min(max(int(np.floor((1 - fuv[f, k, 1]) * Ht - 0.5)), 0), Ht - 1)
-            assert (iy // TS) * ntx + ix // TS in tiles
-    small = np.zeros(1, np.int32)
-    assert lib.mm_build_uv_tiles(F, fuv.ctypes.data_as(ctypes.c_void_p), Ht, Wt, toff.ctypes.data_as(ctypes.c_void_p),
-                                 small.ctypes.data_as(ctypes.c_void_p), 1, ctypes.byref(need)) == -3
 
 
 def test_render_without_gpu_fails_loudly(pkg):

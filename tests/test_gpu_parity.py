@@ -70,45 +70,16 @@ def test_render_loss_backward_matches_oracle(pkg, oracle, name, B, S, ratio, no_
         assert np.abs(g_o[k]).max() > 0
 
 
-@pytest.mark.parametrize("name,B,S,ratio,no_mask,seed", [
-    ("sphere", 4, 64, 1, True, 0),
-    ("smpl_uv_642", 3, 32, 2, False, 2),    # H = 2W: two regions per image, white background
-    ("sphere", 2, 50, 1, True, 4),          # ragged regions / blocks
-    ("smpl_uv_642", 48, 128, 1, True, 0),   # BASELINE config 2, full size
-    ("ellipsoid", 5, 200, 1, True, 9),
+@pytest.mark.parametrize("knum,boxlen,sigmainv,dist", [
+    (3, 0.02, 7000.0, None),      # knum far below the candidates per pixel: the "first knum faces in index order" rule
+    (30, 0.02, 7000.0, 9.0),      # far camera: the whole mesh in a few tiles, > 30 candidates per silhouette pixel
+    (7, 0.08, 900.0, None),       # wide soft margin, flat falloff: many more faces per pixel, tiles with > 64 candidates
+    (80, 0.3, 60.0, None),        # knum > 64 (more than one staged batch per pixel) with a margin wide enough to reach it
 ])
-def test_resident_and_streamed_forward_kernels_agree_bit_for_bit(pkg, name, B, S, ratio, no_mask, seed):
-    """The two forward pixel kernels (LDS-resident template vs screen-bin streamed, MMRenderDesc.options) evaluate the same
-    expressions: every forward output must be identical, and the backward (fed by their saved state) must agree."""
-    N = pkg._native
-    res = {}
-    for tag, opt in (("resident", N.OPT_RESIDENT), ("streamed", N.OPT_STREAMED)):
-        dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, ratio=ratio, seed=seed, no_mask=no_mask)
-        dr.options = opt
-        rgbs, out = dr.render(no_mask=no_mask, **datt)
-        dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask).backward()
-        res[tag] = (rgbs.detach().clone(), dr.last_face_idx.clone(), out["face_normals"].detach().clone(), out["imnormal"].clone(),
-                    {k: datt[k].grad.clone() for k in LEAVES if datt[k].grad is not None})
-    a, b = res["resident"], res["streamed"]
-    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
-    assert float((a[1] >= 0).float().mean()) > 0.03
-    for k in a[4]:
-        _close(a[4][k].cpu().numpy(), b[4][k].cpu().numpy(), 1e-6)
-
-
-@pytest.mark.parametrize("knum,boxlen,sigmainv,dist,resident", [
-    (3, 0.02, 7000.0, None, False),      # knum far below the candidates per pixel: the "first knum faces in index order" rule
-    (3, 0.02, 7000.0, None, True),
-    (30, 0.02, 7000.0, 9.0, False),      # far camera: the whole mesh in a few tiles, > 30 candidates per silhouette pixel
-    (30, 0.02, 7000.0, 9.0, True),
-    (7, 0.08, 900.0, None, False),       # wide soft margin, flat falloff: many more faces per pixel, tiles with > 64 candidates
-    (7, 0.08, 900.0, None, True),
-])
-def test_soft_mask_truncation_and_margins_match_oracle(pkg, oracle, knum, boxlen, sigmainv, dist, resident):
+def test_soft_mask_truncation_and_margins_match_oracle(pkg, oracle, knum, boxlen, sigmainv, dist):
     """dibr_rasterization's knum / boxlen / sigmainv away from their defaults: forward and backward."""
     dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "sphere", 3, 64, seed=11)
     dr.knum, dr.boxlen, dr.sigmainv = knum, boxlen, sigmainv
-    dr.options = pkg._native.OPT_RESIDENT if resident else 0
     if dist is not None:
         with torch.no_grad():
             datt["distances"].fill_(dist)

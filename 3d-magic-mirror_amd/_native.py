@@ -20,7 +20,7 @@ c_p = ctypes.c_void_p
 class MMRenderDesc(ctypes.Structure):
     _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("V", c_i), ("F", c_i), ("Ht", c_i), ("Wt", c_i), ("no_mask", c_i),
                 ("knum", c_i), ("proj", c_f * 3), ("sigmainv", c_f), ("boxlen", c_f), ("multiplier", c_f), ("eps", c_f),
-                ("faces", c_p), ("face_uvs", c_p), ("vc_offsets", c_p), ("vc_items", c_p), ("face_order", c_p),
+                ("faces", c_p), ("face_uvs", c_p), ("vc_offsets", c_p), ("vc_items", c_p),
                 ("vertices", c_p), ("textures", c_p), ("lights", c_p), ("bg", c_p), ("azimuths", c_p), ("elevations", c_p),
                 ("distances", c_p), ("biases", c_p),
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
@@ -118,6 +118,7 @@ class MMMaskIouDesc(ctypes.Structure):
 
 PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "order")
 ABI_VERSION = 2
+OPT_WALK_BLOCK, OPT_WALK_WAVE = 1 << 1, 1 << 2
 OPT_CULL_STRICT, OPT_SOFT_SKIP_CULLED, OPT_BBOX_HALF_OPEN, OPT_BARY_ONE_MINUS, OPT_SH_ORDER_XYZ = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 

@@ -34,22 +34,23 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None, extra_flags=None):
     """Compile + link under an exclusive file lock, into a private directory, and publish the library with one atomic rename:
     N ranks starting together on a fresh checkout (torchrun bench.py) build once, and nobody can dlopen a half-written file."""
     import fcntl
     import shutil
     import tempfile
-    if not force and not needs_build():
+    target = out or LIB                                          # out: a variant build (profiles/tools), e.g. lib/libmm_timeline.so
+    if out is None and not force and not needs_build():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     with open(os.path.join(os.path.dirname(LIB), ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not needs_build():                  # another process built it while we waited for the lock
+            if out is None and not force and not needs_build():  # another process built it while we waited for the lock
                 return LIB
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-            extra = os.environ.get("MM_EXTRA_FLAGS", "").split()
+            extra = os.environ.get("MM_EXTRA_FLAGS", "").split() + list(extra_flags or [])
             tmp = tempfile.mkdtemp(prefix="obj.", dir=os.path.dirname(LIB))
             try:
                 def compile_one(item):
@@ -63,17 +64,17 @@ def build(force=False, verbose=False):
 
                 with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
                     objs = list(pool.map(compile_one, SOURCES.items()))
-                out = os.path.join(tmp, "libmm_render.so")
-                cmd = [hipcc, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC"] + objs + ["-o", out]
+                built = os.path.join(tmp, "libmm_render.so")
+                cmd = [hipcc, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC"] + objs + ["-o", built]
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd)
-                os.replace(out, LIB)                             # atomic on one filesystem
+                os.replace(built, target)                        # atomic on one filesystem
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

@@ -39,14 +39,14 @@ static int check_render(const MMRenderDesc* d, bool backward) {
 extern "C" {
 
 size_t mm_query_workspace(const MMRenderDesc* d) {
-    if (!d || d->B <= 0 || d->F <= 0 || d->H <= 0 || d->W <= 0 || d->Ht <= 0 || d->Wt <= 0) return 0;
-    return mm::carve_workspace(nullptr, d->B, d->F, d->H, d->W, d->Ht, d->Wt).bytes;
+    if (!d || d->B <= 0 || d->V <= 0 || d->F <= 0 || d->H <= 0 || d->W <= 0 || d->Ht <= 0 || d->Wt <= 0) return 0;
+    return mm::carve_workspace(nullptr, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt).bytes;
 }
 
 int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
     int st = check_render(d, false);
     if (st != MM_OK) return st;
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->F, d->H, d->W, d->Ht, d->Wt);
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt);
     hipStream_t s = (hipStream_t)stream;
     mm::clear_stale_error();
     st = mm::launch_vertex_fwd(d, w, s);
@@ -61,7 +61,7 @@ int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_
         !g->grad_elevations || !g->grad_distances || !g->grad_biases)
         return MM_ERR_NULL_POINTER;
     if (d->no_mask && !g->grad_bg) return MM_ERR_NULL_POINTER;
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->F, d->H, d->W, d->Ht, d->Wt);
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt);
     hipStream_t s = (hipStream_t)stream;
     mm::clear_stale_error();
     st = mm::launch_raster_bwd(d, g, w, s);

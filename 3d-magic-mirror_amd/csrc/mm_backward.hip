@@ -15,23 +15,14 @@
 //   2b. face_gather  8 lanes per (image, face) sweep the face's inflated screen box: pixels it owns give the K2
 //                  barycentric gradient, uncovered pixels that hold the face among their first knum soft-mask faces give
 //                  K4.  dL/d(face xy) and dL/d(face normal) are written once per face with plain stores.
+#include <cstdlib>
 #include "mm_device.h"
 
 MM_TIMELINE_STORAGE(pixel_bwd)
 MM_TIMELINE_STORAGE(gather_bwd)
-
-// -DMM_GATHER_PROF: per-wave cycle totals of the face sweep's phases (debug builds only; profiles/tools/gather_prof.py)
-#ifdef MM_GATHER_PROF
-namespace mm { __device__ unsigned long long g_gprof[16384][8]; }
-extern "C" int mm_debug_gather_prof(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm::g_gprof), sizeof(unsigned long long) * 16384 * 8) == hipSuccess ? 0 : -1;
-}
-#define GP_T(x) __builtin_amdgcn_s_waitcnt(0); const unsigned long long x = clock64()   /* everything issued so far has completed */
-#define GP_ACC(i, a, b) gp[i] += (b) - (a)
-#else
-#define GP_T(x) do { } while (0)
-#define GP_ACC(i, a, b) do { } while (0)
-#endif
+MM_PP_STORAGE(gather_face)      // 0 setup, 1 sweep (face_idx loads), 2 compaction, 3 item loads, 4 item arithmetic + LDS adds, 5 stores; counts: trips, items
+MM_PP_STORAGE(gather_tex)       // 0 count + first record, 1 clear, 2 records, 3 tile store; counts: records
+MM_PP_STORAGE(pixel_bwd)        // 0 loss totals + g4, 1 shading recompute + stores, 2 record append, 3 dlights reduction
 
 namespace mm {
 
@@ -50,17 +41,16 @@ struct BwdArgs {
     float4* gp; float* gp2;
     float* dl_part;
     float* grad_bg;
-    float* dTacc; unsigned* ticket;
+    unsigned* ticket;
     int* tcnt; TexRecord* trec; TexSpill* tspill; int ntiles_;
     // fused recon_data (gt == nullptr: off)
     const float* gt; const float* rgba; const float* grad_loss; float* loss; float image_weight;
     const long long* ltot;                                       // (B,MM_LSUB,4) fused loss sums of the raster waves (fixed point)
     // gather
-    const int32_t* face_order;
+    unsigned* gmax;                                              // (B,2) per image: max |K2 number| and max |dL/dalpha| as float bits (pixel pass -> gather)
+    const int2* items; const int2* nitems; float* part; int item_cap;   // sweep items {face, chunk} of the plan kernel; their partial sums
     int ntx, nty;
     float* grad_textures;
-    float* dfxy;
-    float* dfn;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -70,6 +60,7 @@ template <bool kNoMask>
 __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     MM_TIMELINE_BEGIN();
     __shared__ float s_dl[MM_BLOCK_WAVES][9];
+    __shared__ float s_gm[MM_BLOCK_WAVES][2];
     int b, blk;
     map_block(blockIdx.x, a.B, a.blocks_per_image, b, blk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,10 +70,7 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
     const size_t hw = (size_t)a.H * a.W, pin = (size_t)py * a.W + px;
     const size_t pix = (size_t)b * hw + pin;
-    if (blk == 0) {                                              // accumulators of the vertex backward, used after this kernel
-        if (threadIdx.x < 12) a.dTacc[b * 12 + threadIdx.x] = 0.f;
-        if (threadIdx.x == 12) a.ticket[b] = 0u;
-    }
+    if (blk == 0 && threadIdx.x == 0) a.ticket[b] = 0u;           // arrival counter of the vertex backward, used after this kernel
 
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int hf = -1;
@@ -114,7 +102,8 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
         }
     } else if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
     const float gin[3] = {g4.x, g4.y, g4.z};
-    if (in_img && hf < 0) a.gp2[pix] = g4.w;                     // the face gather (K4) needs dL/dalpha of uncovered pixels
+    float m2 = 0.f, m4 = 0.f;                                    // this lane's largest |K2 number| / |dL/dalpha|: the gather's fixed-point scale
+    if (in_img && hf < 0) { a.gp2[pix] = g4.w; m4 = fabsf(g4.w); }   // the face gather (K4) needs dL/dalpha of uncovered pixels
     float dl[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) dl[i] = 0.f;
@@ -224,11 +213,14 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             const float inrm = 1.f / nrm;
             const float dw0 = (G0 - Gm) * inrm, dw1 = (G1 - Gm) * inrm, dw2 = (G2 - Gm) * inrm;
             const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
-            a.gp[pix * 2 + 0] = make_float4((dw1 * (-cey) + dw2 * bey) * a.mult, (dw1 * cex + dw2 * (-bex)) * a.mult,
-                                     (dw0 * cey + dw2 * (-aey)) * a.mult, (dw0 * (-cex) + dw2 * aex) * a.mult);
-            a.gp[pix * 2 + 1] = make_float4((dw0 * (-bey) + dw1 * aey) * a.mult, (dw0 * bex + dw1 * (-aex)) * a.mult,
-                                     (w0 * dnx + w1 * dnx) + w2 * dnx, (w0 * dny + w1 * dny) + w2 * dny);
-            a.gp2[pix] = (w0 * dnz + w1 * dnz) + w2 * dnz;
+            const float4 k0 = make_float4((dw1 * (-cey) + dw2 * bey) * a.mult, (dw1 * cex + dw2 * (-bex)) * a.mult,
+                                          (dw0 * cey + dw2 * (-aey)) * a.mult, (dw0 * (-cex) + dw2 * aex) * a.mult);
+            const float4 k1 = make_float4((dw0 * (-bey) + dw1 * aey) * a.mult, (dw0 * bex + dw1 * (-aex)) * a.mult,
+                                          (w0 * dnx + w1 * dnx) + w2 * dnx, (w0 * dny + w1 * dny) + w2 * dny);
+            const float k2 = (w0 * dnz + w1 * dnz) + w2 * dnz;
+            a.gp[pix * 2 + 0] = k0; a.gp[pix * 2 + 1] = k1; a.gp2[pix] = k2;
+            m2 = fmaxf(fmaxf(fmaxf(fabsf(k0.x), fabsf(k0.y)), fmaxf(fabsf(k0.z), fabsf(k0.w))),
+                       fmaxf(fmaxf(fmaxf(fabsf(k1.x), fabsf(k1.y)), fmaxf(fabsf(k1.z), fabsf(k1.w))), fabsf(k2)));
             if (dtcv[0] != 0.f || dtcv[1] != 0.f || dtcv[2] != 0.f) {
                 rec.xy = (unsigned)s.x0 | ((unsigned)s.y0 << 16); rec.tx = s.tx; rec.ty = s.ty;
                 rec.d0 = dtcv[0]; rec.d1 = dtcv[1]; rec.d2 = dtcv[2];
@@ -281,11 +273,20 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) dl[i] = wave_sum(dl[i]);
     } else { dl[0] = wave_sum(dl[0]); dl[6] = wave_sum(dl[6]); }     // the other seven are zero
+    m2 = wave_max(m2); m4 = wave_max(m4);
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) s_dl[wave][i] = dl[i];
+        s_gm[wave][0] = m2; s_gm[wave][1] = m4;
     }
     __syncthreads();
+    if (threadIdx.x >= 64 && threadIdx.x < 66) {                 // non-negative floats order like their bit patterns: integer max, one atomic per
+        const int k = threadIdx.x - 64;                          // workgroup and kind (NaN / inf gradients end up as an inf scale = zero sums)
+        const float m = fmaxf(fmaxf(s_gm[0][k], s_gm[1][k]), fmaxf(s_gm[2][k], s_gm[3][k]));
+        // one atomic per workgroup and kind, spread over MM_GSHARD words per image on separate 32-byte sectors (thousands of
+        // workgroups per image on ONE word queue at the memory side: measured +75 % on this kernel at 512x512)
+        if (m > 0.f) atomicMax(a.gmax + ((size_t)b * MM_GSHARD + (blk & (MM_GSHARD - 1))) * 8 + k, __float_as_uint(m));
+    }
     if (threadIdx.x < 9)
         a.dl_part[((size_t)b * a.blocks_per_image + blk) * 12 + threadIdx.x] =
             ((s_dl[0][threadIdx.x] + s_dl[1][threadIdx.x]) + s_dl[2][threadIdx.x]) + s_dl[3][threadIdx.x];
@@ -300,10 +301,9 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
 #ifndef MM_SWEEP
 #define MM_SWEEP 16             // pixels per lane per trip
 #endif
-#ifndef MM_FL
-#define MM_FL 8                 // lanes per face: a trip covers MM_FL * MM_SWEEP pixels of each of the wave's faces
-#endif
-#define MM_FPW (64 / MM_FL)     // faces per wave
+#define MM_FL 8                 // lanes per sweep item: a trip covers MM_FL * MM_SWEEP pixels of each of the wave's items
+#define MM_FPW (64 / MM_FL)     // items per wave
+static_assert(MM_CHUNK_PX % (MM_FL * MM_SWEEP) == 0, "a chunk is a whole number of trips");
 
 // squared distance from p to segment u-v by clamped projection: t in [0,1] is where the nearest point lies, q = p - nearest.
 // With t clamped, d(d^2)/du = -2 (1-t) q and d(d^2)/dv = -2 t q hold in all three regions of kaolin's case split (t = 0: the
@@ -347,24 +347,27 @@ __device__ inline void box_pixel(int idx, int px0, int py0, int bw, float inv_bw
     px = px0 + (idx - yy * bw); py = py0 + yy;
 }
 
-// What a wave keeps in LDS about the (up to) four faces its four 16-lane groups sweep, so that ANY lane can finish a
-// compacted work item of any of them.
+// What a wave keeps in LDS about the eight faces its 8-lane groups sweep, so that ANY lane can finish a compacted work item of
+// any of them.  The per-face sums are 64-bit INTEGERS (fixed point at a per-image power-of-two scale): an LDS float atomic costs
+// ~81 ns of the CU's LDS unit per wave-instruction whatever the addresses (ds_add_f32 takes the 64 lanes one after the other:
+// measured, profiles/r02_lds_atomic_calibration.txt), an integer one 2-7 ns, and nine float ones per item round had made this
+// kernel LDS-bound.  Integer adds also commute exactly: the face gradients are bitwise reproducible.
 struct __attribute__((aligned(16))) FaceSlot {
     float4 p0, p1;                   // ax,ay,bx,by | cx,cy,az,bz  (multiplier units)
     float box[4];                    // xmin, ymin, xmax, ymax
     int px0, py0, bw, f;
     float inv_bw;
-    float acc[9];                    // dL/d(ax,ay,bx,by,cx,cy), dL/d(n)
+    int lo;                          // first box pixel of this sweep (0, or the chunk's start)
+    long long acc[9];                // dL/d(ax,ay,bx,by,cx,cy), dL/d(n), fixed point
 };
 
 struct __attribute__((aligned(16))) SweepStage {
     FaceSlot slot[MM_FPW];
-    unsigned short items[MM_SWEEP * 64];   // (sweep slot << 6) | lane
+    unsigned short items[MM_SWEEP * 64];   // owned << 15 | sweep slot << 6 | lane
 };
 
-// ballot-compaction of the lanes' hits into an ordered LDS item list: (owned pixel ? 0x8000 : 0) | sweep slot << 6 | lane;
-// returns the item count (wave-uniform)
-__device__ inline int compact4(const bool (&own)[MM_SWEEP], const bool (&opn)[MM_SWEEP], int lane, unsigned short* items) {
+// ballot-compaction of the lanes' hits into an ordered LDS item list; returns the item count (wave-uniform)
+__device__ inline int compact_hits(const bool (&own)[MM_SWEEP], const bool (&opn)[MM_SWEEP], int lane, unsigned short* items) {
     int base = 0;
 #pragma unroll
     for (int i = 0; i < MM_SWEEP; ++i) {
@@ -382,37 +385,58 @@ __device__ inline void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// pixel index of item `it` of the current trip: the item names the sweeping lane (hence its 16-lane group = face slot and
-// its position in the box walk)
-__device__ inline void item_pixel(const SweepStage* st, unsigned it, int base, int& g, int& px, int& py) {
-    const int l = it & 63, i = (it >> 6) & 0x1FF;
-    g = l / MM_FL;
-    const FaceSlot& fs = st->slot[g];
-    box_pixel(base + i * MM_FL + (l % MM_FL), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
+// Fixed-point scale of an image's face sums.  The pixel pass left max |K2 number| and max |dL/dalpha| of the image (gmax); a K4
+// contribution is bounded by |dL/dalpha| * mult * sqrt(2 sigma' / e), sigma' = sigmainv / mult^2 (the maximum of d exp(-sigma' d^2)
+// times the constant factors of Appendix A.2).  The largest contribution is placed at 2^40: 2^22 of them fit a 63-bit sum, and
+// the unit is 2^-40 of it.
+__device__ inline float face_sum_scale(const BwdArgs& a, int b, float& inv) {
+    float m2 = 0.f, m4 = 0.f;
+#pragma unroll
+    for (int sh = 0; sh < MM_GSHARD; ++sh) {
+        m2 = fmaxf(m2, __uint_as_float(a.gmax[((size_t)b * MM_GSHARD + sh) * 8]));
+        m4 = fmaxf(m4, __uint_as_float(a.gmax[((size_t)b * MM_GSHARD + sh) * 8 + 1]));
+    }
+    const float sig = a.sigmainv / (a.mult * a.mult);
+    const float M = fmaxf(m2, m4 * a.mult * sqrtf(2.f * sig * 0.36787944f) * 1.0001f);
+    if (!(M > 0.f) || !(M < INFINITY)) { inv = 0.f; return 0.f; }
+    int e;
+    (void)frexpf(M, &e);                                         // M < 2^e
+    const int k = min(max(40 - e, -80), 126);
+    inv = ldexpf(1.f, -k);
+    return ldexpf(1.f, k);
 }
+__device__ inline void fixed_add(long long* p, float v, float scale) { atomicAdd((unsigned long long*)p, (unsigned long long)__float2ll_rn(v * scale)); }
 
-__device__ inline void tex_accumulate(const BwdArgs& a, float (*s_acc)[MM_TS * MM_TS], const TexRecord& rc, int tx0, int ty0) {
+// The tile's accumulators are INTEGERS (fixed point at a per-tile power-of-two scale): an LDS float atomic costs ~81 ns of the
+// CU's LDS unit per wave-instruction whatever the addresses, an integer one 2-7 ns (profiles/r02_lds_atomic_calibration.txt), and
+// twelve of them per record made this half of the gather kernel LDS-bound.  Integer adds also commute exactly, so the texture
+// gradient is bitwise reproducible.  Scale: the largest |contribution| of the tile's records times their number bounds every
+// texel's sum; it is placed just below 2^30.  Quantisation: half a unit = (records * max) * 2^-31 per add.
+__device__ inline void tex_accumulate(const BwdArgs& a, int (*s_acc)[MM_TS * MM_TS], const TexRecord& rc, int tx0, int ty0, float scale) {
     const int x0 = (int)(rc.xy & 0xFFFFu), y0 = (int)(rc.xy >> 16);
     const int lx0 = x0 - tx0, lx1 = lx0 + 1, ly0 = y0 - ty0, ly1 = ly0 + 1;
     const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && x0 + 1 < a.Wt;
     const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && y0 + 1 < a.Ht;
     const float ex = 1.f - rc.tx, ey = 1.f - rc.ty;
     const float wnw = ex * ey, wne = rc.tx * ey, wsw = ex * rc.ty, wse = rc.tx * rc.ty;
-    const float dt[3] = {rc.d0, rc.d1, rc.d2};
+    const float dt[3] = {rc.d0 * scale, rc.d1 * scale, rc.d2 * scale};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (dt[c] != 0.f) {
-            if (cx0 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx0], dt[c] * wnw);
-            if (cx1 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx1], dt[c] * wne);
-            if (cx0 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx0], dt[c] * wsw);
-            if (cx1 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx1], dt[c] * wse);
+            if (cx0 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx0], __float2int_rn(dt[c] * wnw));
+            if (cx1 && cy0) atomicAdd(&s_acc[c][ly0 * MM_TS + lx1], __float2int_rn(dt[c] * wne));
+            if (cx0 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx0], __float2int_rn(dt[c] * wsw));
+            if (cx1 && cy1) atomicAdd(&s_acc[c][ly1 * MM_TS + lx1], __float2int_rn(dt[c] * wse));
         }
     }
 }
 
+__device__ inline float tex_record_max(const TexRecord& rc) { return fmaxf(fmaxf(fabsf(rc.d0), fabsf(rc.d1)), fabsf(rc.d2)); }
+
 // 2a. texture gradient: one workgroup per (image, 32x32-texel tile) streams the records the pixel pass appended for the
 //     tile into LDS accumulators and writes every texel of the tile once.
-__device__ inline void texture_gather_block(const BwdArgs& a, int block, float (*s_acc)[MM_TS * MM_TS]) {
+__device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s_acc)[MM_TS * MM_TS]) {
+    __shared__ float s_max[4];
     const int ntiles = a.ntx * a.nty;
     int b, T;
     map_block(block, a.B, ntiles, b, T);
@@ -422,87 +446,92 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, float (
     // it lies below the count.
     const int tx0 = (T % a.ntx) * MM_TS, ty0 = (T / a.ntx) * MM_TS;
     const TexRecord* recs = a.trec + ((size_t)b * ntiles + T) * MM_TREC_CAP;
+    MM_PP_BEGIN();
     const int nrec = a.tcnt[(size_t)b * ntiles + T];
     const TexRecord first = recs[tid];
-    for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) (&s_acc[0][0])[i] = 0.f;
+    const int ncap = min(nrec, MM_TREC_CAP);
+    int nsp = 0;
+    const TexSpill* sp = a.tspill + (size_t)b * 4 * a.H * a.W;
+    if (nrec > MM_TREC_CAP) nsp = a.tcnt[(size_t)a.B * ntiles + b];   // the list was full: the tile's other records are in the image's spill list
+    MM_PP_MARK(0);
+    // largest contribution of the tile's records (first pass; the second one below re-reads them from L2)
+    float mx = tid < ncap ? tex_record_max(first) : 0.f;
+    for (int r = tid + 256; r < ncap; r += 256) mx = fmaxf(mx, tex_record_max(recs[r]));
+    for (int r = tid; r < nsp; r += 256) if (sp[r].tile == T) mx = fmaxf(mx, tex_record_max(sp[r].r));
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) s_max[tid >> 6] = mx;
+    for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) (&s_acc[0][0])[i] = 0;
     __syncthreads();
-    if (tid < min(nrec, MM_TREC_CAP)) tex_accumulate(a, s_acc, first, tx0, ty0);
-    for (int r = tid + 256; r < min(nrec, MM_TREC_CAP); r += 256) tex_accumulate(a, s_acc, recs[r], tx0, ty0);
-    if (nrec > MM_TREC_CAP) {                                    // the list was full: the tile's other records are in the spill list
-        const int nsp = a.tcnt[(size_t)a.B * ntiles + b];
-        const TexSpill* sp = a.tspill + (size_t)b * 4 * a.H * a.W;
-        for (int r = tid; r < nsp; r += 256) if (sp[r].tile == T) tex_accumulate(a, s_acc, sp[r].r, tx0, ty0);
+    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    MM_PP_MARK(1);
+    float inv = 0.f;
+    if (mx > 0.f && mx < INFINITY) {                             // workgroup-uniform; nothing to add up otherwise (about half of all tiles)
+        int e;
+        (void)frexpf((float)nrec * mx, &e);                      // records * max < 2^e
+        const int k = min(max(30 - e, -100), 120);
+        const float scale = ldexpf(1.f, k);
+        inv = ldexpf(1.f, -k);
+        if (tid < ncap) tex_accumulate(a, s_acc, first, tx0, ty0, scale);
+        for (int r = tid + 256; r < ncap; r += 256) tex_accumulate(a, s_acc, recs[r], tx0, ty0, scale);
+        for (int r = tid; r < nsp; r += 256) if (sp[r].tile == T) tex_accumulate(a, s_acc, sp[r].r, tx0, ty0, scale);
+        __syncthreads();
     }
-    __syncthreads();
+    MM_PP_MARK(2);
+    MM_PP_COUNT(nrec, 0);
     // write the tile once (also where nothing landed: no separate zero-fill of grad_textures)
     for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) {
         const int c = i / (MM_TS * MM_TS), r = i - c * (MM_TS * MM_TS);
         const int ly = r / MM_TS, lx = r - ly * MM_TS;
         const int x = tx0 + lx, y = ty0 + ly;
-        if (x < a.Wt && y < a.Ht) a.grad_textures[(((size_t)b * 3 + c) * a.Ht + y) * a.Wt + x] = s_acc[c][r];
+        if (x < a.Wt && y < a.Ht) a.grad_textures[(((size_t)b * 3 + c) * a.Ht + y) * a.Wt + x] = (float)s_acc[c][r] * inv;
     }
+    MM_PP_MARK(3);
+    MM_PP_FLUSH(gather_tex, (long long)block * 4 + (threadIdx.x >> 6));
 }
 
 // 2b. per-face gradients: MM_FL lanes per (image, face) sweep the face's inflated box; pixels it owns give the K2 barycentric
-//     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The two kinds of hits are
-//     ballot-compacted per wave (four faces) and finished by all 64 lanes into per-face LDS accumulators; one plain store
-//     per face at the end.
-__device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage* s_stage) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / MM_FL, sl = lane % MM_FL;
-    SweepStage* st = &s_stage[wave];
-    // a wave sweeps MM_FPW faces of consecutive area rank of ONE image (same camera: similar box sizes, so its groups finish
-    // together); waves walk the images round-robin and the ranks with the biggest boxes start first
-#ifdef MM_GATHER_PROF
-    unsigned long long gp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    GP_T(t_begin);
-    const long long wid = (long long)block * 4 + wave;            // wave index over (rank octet, image)
-    const int b = (int)(wid % a.B);
-    const int rk_raw = (int)(wid / a.B) * MM_FPW + grp;
-    const bool live = rk_raw < a.F;
-    const int rk = live ? rk_raw : 0;
-    const int f = a.face_order ? a.face_order[rk] : rk;
-    const size_t o = (size_t)b * a.F + f, hw = (size_t)a.H * a.W;
+//     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The hits of a trip are
+//     ballot-compacted over the whole wave and finished by all 64 lanes (one round of loads per trip) into the per-face
+//     fixed-point LDS sums.  This lane's face is `f` of image `b`, and its group sweeps box pixels [lo, hi) of it.
+__device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f, int lane, const FaceBox& fb, int lo, int hi, float scale MM_PP_ARG) {
+    const int grp = lane / MM_FL, sl = lane % MM_FL;
+    const size_t hw = (size_t)a.H * a.W;
     const float s2 = a.mult * a.mult;
-    FaceBox fb = face_box(a, o);
-    if (!live) fb.npx = 0;
     if (sl == 0) {
         FaceSlot& fs = st->slot[grp];
         fs.p0 = fb.p0; fs.p1 = fb.p1; fs.box[0] = fb.xmin; fs.box[1] = fb.ymin; fs.box[2] = fb.xmax; fs.box[3] = fb.ymax;
-        fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f;
+        fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f; fs.lo = lo;
     }
-    for (int k = sl; k < 9; k += MM_FL) st->slot[grp].acc[k] = 0.f;
-    int nmax = fb.npx;
+    for (int k = sl; k < 9; k += MM_FL) st->slot[grp].acc[k] = 0ll;
+    int nmax = hi - lo;
 #pragma unroll
     for (int o = MM_FL; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
     wave_sync_lds();
-    GP_T(t_setup); GP_ACC(0, t_begin, t_setup);
+    MM_PP_MARK(0);
 
     for (int base = 0; base < nmax; base += MM_FL * MM_SWEEP) {
-        GP_T(t0);
         bool own[MM_SWEEP], opn[MM_SWEEP];
 #pragma unroll
         for (int i = 0; i < MM_SWEEP; ++i) {
-            const int idx = base + i * MM_FL + sl;
+            const int idx = lo + base + i * MM_FL + sl;
             int px, py;
             box_pixel(idx, fb.px0, fb.py0, fb.bw, fb.inv_bw, px, py);
-            const int fi = idx < fb.npx ? a.face_idx[(size_t)b * hw + (size_t)py * a.W + px] : -2;
+            const int fi = idx < hi ? a.face_idx[(size_t)b * hw + (size_t)py * a.W + px] : -2;
             own[i] = fi == f; opn[i] = fi == -1;
         }
+        MM_PP_MARK(1);
         // one compacted item list for both kinds of hit: pixels these faces own (K2: add the pixel pass's contributions)
         // and uncovered pixels that may hold one of these faces among their first knum soft-mask faces (K4, Appendix A.2)
-        GP_T(t1); GP_ACC(1, t0, t1);                             // sweep: box walk + face_idx loads
-        const int n = compact4(own, opn, lane, st->items);
+        const int n = compact_hits(own, opn, lane, st->items);
         wave_sync_lds();
-        GP_T(t2); GP_ACC(2, t1, t2);                             // compaction
-#ifdef MM_GATHER_PROF
-        gp[4] += n; gp[5] += 1;
-#endif
+        MM_PP_MARK(2);
+        MM_PP_COUNT(1, n);
         for (int j = lane; j < n; j += 64) {
-            int g, px, py;
             const unsigned it = st->items[j];
-            item_pixel(st, it, base, g, px, py);
+            const int l = it & 63, i = (it >> 6) & 0x1FF, g = l / MM_FL;
             FaceSlot& fs = st->slot[g];
+            int px, py;
+            box_pixel(fs.lo + base + i * MM_FL + (l % MM_FL), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
             const size_t pix = (size_t)b * hw + (size_t)py * a.W + px;   // every group of the wave sweeps the same image
             // the sweep already knows which kind of hit this is: only the three loads that kind needs are issued
             const bool owned = (it & 0x8000u) != 0;
@@ -512,10 +541,11 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
             int lf = 0;
             if (owned) { q0 = a.gp[pix * 2 + 0]; q1 = a.gp[pix * 2 + 1]; }
             else { const float2 sl2 = a.soft[pix]; sq = sl2.x; lf = __float_as_int(sl2.y); }
+            MM_PP_MARK(3);
             if (owned) {
-                atomicAdd(&fs.acc[0], q0.x); atomicAdd(&fs.acc[1], q0.y); atomicAdd(&fs.acc[2], q0.z); atomicAdd(&fs.acc[3], q0.w);
-                atomicAdd(&fs.acc[4], q1.x); atomicAdd(&fs.acc[5], q1.y); atomicAdd(&fs.acc[6], q1.z); atomicAdd(&fs.acc[7], q1.w);
-                atomicAdd(&fs.acc[8], q2);
+                fixed_add(&fs.acc[0], q0.x, scale); fixed_add(&fs.acc[1], q0.y, scale); fixed_add(&fs.acc[2], q0.z, scale);
+                fixed_add(&fs.acc[3], q0.w, scale); fixed_add(&fs.acc[4], q1.x, scale); fixed_add(&fs.acc[5], q1.y, scale);
+                fixed_add(&fs.acc[6], q1.z, scale); fixed_add(&fs.acc[7], q1.w, scale); fixed_add(&fs.acc[8], q2, scale);
                 continue;
             }
             const float ga = q2;                                 // uncovered pixels: the pixel pass left dL/dalpha here
@@ -541,37 +571,59 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
                     const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;
                     const float cu = -2.f * (1.f - h.t) * gd, cv = -2.f * h.t * gd;
                     const f2 gu = cu * h.q, gv = cv * h.q;
-                    atomicAdd(&fs.acc[iu], gu.x); atomicAdd(&fs.acc[iu + 1], gu.y);
-                    atomicAdd(&fs.acc[iv], gv.x); atomicAdd(&fs.acc[iv + 1], gv.y);
+                    fixed_add(&fs.acc[iu], gu.x, scale); fixed_add(&fs.acc[iu + 1], gu.y, scale);
+                    fixed_add(&fs.acc[iv], gv.x, scale); fixed_add(&fs.acc[iv + 1], gv.y, scale);
                 }
             }
         }
         wave_sync_lds();
-        GP_T(t3); GP_ACC(3, t2, t3);                             // items
+        MM_PP_MARK(4);
     }
-    if (live) {
-        for (int k = sl; k < 9; k += MM_FL) {
-            const float v = st->slot[grp].acc[k];
-            if (k < 6) a.dfxy[o * 6 + k] = v; else a.dfn[o * 3 + (k - 6)] = v;
-        }
-    }
-#ifdef MM_GATHER_PROF
-    GP_T(t_end);
-    gp[6] = t_end - t_begin; gp[7] = nmax;
-    if (lane == 0 && wid < 16384) for (int k = 0; k < 8; ++k) g_gprof[wid][k] = gp[k];
-#endif
+}
+
+// a wave takes MM_FPW consecutive sweep items of ONE image (consecutive faces, or consecutive chunks of a big face: neighbours on
+// the screen); waves walk the images round-robin.  The item's partial sums go to part[item]; the vertex backward adds the items
+// of a face up.
+__device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage* s_stage) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / MM_FL, sl = lane % MM_FL;
+    SweepStage* st = &s_stage[wave];
+    const long long wid = (long long)block * 4 + wave;            // wave index over (item octet, image)
+    const int b = (int)(wid % a.B);
+    const int item = (int)(wid / a.B) * MM_FPW + grp;
+    const int2 ni = a.nitems[b];                                  // items of the image, pixels per chunk
+    if ((int)(wid / a.B) * MM_FPW >= ni.x) return;                // wave-uniform: the image has fewer items (the grid is sized for the cap)
+    const bool live = item < ni.x;
+    const int2 e = a.items[(size_t)b * a.item_cap + (live ? item : 0)];      // face, chunk
+    const size_t o = (size_t)b * a.F + e.x;
+    const FaceBox fb = face_box(a, o);
+    const int lo = e.y * ni.y;
+    const int hi = live ? min(fb.npx, lo + ni.y) : lo;
+    MM_PP_BEGIN();
+    float inv;
+    const float scale = face_sum_scale(a, b, inv);
+    face_sweep(a, st, b, e.x, lane, fb, lo, hi, scale MM_PP_PASS);
+    if (live) for (int k = sl; k < 9; k += MM_FL) a.part[((size_t)b * a.item_cap + item) * 12 + k] = (float)st->slot[grp].acc[k] * inv;
+    MM_PP_MARK(5);
+    MM_PP_FLUSH(gather_face, wid);
 }
 
 // One launch for both gathers: they only depend on the pixel pass, and each is latency-bound with a long tail, so their
 // workgroups are interleaved in a single grid (texture tiles first: they are the heavier ones).
-__global__ __launch_bounds__(256) void gather_bwd_kernel(BwdArgs a, int ntex) {
+#ifndef MM_GATHER_LB
+#define MM_GATHER_LB 6            // waves per SIMD the register allocation is held to (80 VGPRs, no spills; 7 would spill)
+#endif
+__global__ __launch_bounds__(256, MM_GATHER_LB) void gather_bwd_kernel(BwdArgs a, int ntex, int dbg_skip) {
     MM_TIMELINE_BEGIN();
+#ifdef MM_PHASE_PROF                                            // timing experiments only (results are wrong): leave one kind of workgroup out
+    if ((dbg_skip & 1) && (int)blockIdx.x < ntex) return;
+    if ((dbg_skip & 2) && (int)blockIdx.x >= ntex) return;
+#endif
     // the two kinds of workgroup never coexist in one workgroup: their LDS is overlaid (more workgroups per CU)
     constexpr size_t kLds = sizeof(float) * 3 * MM_TS * MM_TS > sizeof(SweepStage) * 4 ? sizeof(float) * 3 * MM_TS * MM_TS : sizeof(SweepStage) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLds];
-    float (*s_acc)[MM_TS * MM_TS] = reinterpret_cast<float (*)[MM_TS * MM_TS]>(s_raw);
+    int (*s_acc)[MM_TS * MM_TS] = reinterpret_cast<int (*)[MM_TS * MM_TS]>(s_raw);
     SweepStage* s_stage = reinterpret_cast<SweepStage*>(s_raw);
-    if (a.gt && a.loss && blockIdx.x == 0 && threadIdx.x < 64) {  // fused recon_data value: fixed-order sum over images
+    if (a.gt && a.loss && blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {  // fused recon_data value: fixed-order sum over images
         float l1 = 0.f, iou = 0.f;
         for (int bb = threadIdx.x; bb < a.B; bb += 64) { float s0, s1, s2; loss_totals(a.ltot, bb, s0, s1, s2); l1 += s0; iou += s1 / (s2 + 1e-10f); }
         l1 = wave_sum(l1); iou = wave_sum(iou);
@@ -592,13 +644,14 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.geo = w.geo; a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.face_idx = d->face_idx; a.soft = w.soft; a.grad_rgba = g->grad_rgba;
     a.gp = w.gp; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
-    a.dTacc = w.dTacc; a.ticket = w.ticket;
+    a.ticket = w.ticket;
     a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;
+    a.gmax = (unsigned*)(w.tcnt + (size_t)d->B * w.ntiles + d->B);    // (B, MM_GSHARD, 8): two maxima per 32-byte sector
     a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
     a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
-    a.face_order = d->face_order;
+    a.items = w.items; a.nitems = w.nitems; a.part = w.part; a.item_cap = w.item_cap;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
-    a.grad_textures = g->grad_textures; a.dfxy = w.dfxy; a.dfn = w.dfn;
+    a.grad_textures = g->grad_textures;
     // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)
     {
         ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
@@ -610,9 +663,13 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     {
         ProfScope p(d->prof_events, MM_PROF_GATHER_BWD, s);
         const int ntex = a.ntx * a.nty * d->B;
-        const long long nwaves = (long long)d->B * ((d->F + MM_FPW - 1) / MM_FPW);   // (rank octet, image)
-        const unsigned nface = (unsigned)((nwaves + 3) / 4);
-        hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex);
+        const long long nwaves = (long long)d->B * ((w.item_cap + MM_FPW - 1) / MM_FPW);   // (item octet, image), sized for the cap: waves
+        const unsigned nface = (unsigned)((nwaves + 3) / 4);                                // beyond an image's item count exit at once
+        int dbg_skip = 0;
+#ifdef MM_PHASE_PROF
+        if (const char* e = getenv("MM_DBG_GATHER")) dbg_skip = atoi(e);
+#endif
+        hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex, dbg_skip);
     }
     return launch_ok("raster_bwd");
 }

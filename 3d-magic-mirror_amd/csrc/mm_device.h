@@ -17,6 +17,9 @@
 #define MM_BLOCK_WAVES 4
 #define MM_LSUB 8             // sub-accumulators per image for the fused loss sums (one 32-byte row each: spreads same-address atomics)
 #define MM_UV_TILE 32         // texture-gradient tiles: 32x32 texels, one workgroup and one record list each
+#define MM_GSHARD 16          // per image, the pixel backward's maxima are spread over this many words (see mm_backward.hip)
+#define MM_CHUNK_PX 256       // the backward sweeps every face's inflated pixel box in chunks of this many pixels, one 8-lane group each:
+                              // an even load whatever the box sizes (perspective blow-ups, close-ups at high resolution)
 #define MM_GROUP_WORDS 16     // bin-mask words (of 64 faces) expanded per step: 1024 faces -> 2 KiB of uint16 ids per wave
 
 namespace mm {
@@ -54,9 +57,7 @@ struct Workspace {
     uint64_t* binmask;     // (B,nbins,ceil(F/64)) bit f: the pixel box of face f, inflated by the soft-mask margin, touches the bin
     float2* soft;          // (B,H,W)    .x = soft-mask product state of uncovered pixels: +prod(1-p) if no factor is 0,
                            //            -prod(non-zero factors) if exactly one factor is 0, 0 if two or more are
-    float* dfxy;           // (B,F,3,2)  backward accumulator: dL/d face_vertices_image (unscaled NDC)
-    float* dfn;            // (B,F,3)    backward accumulator: dL/d unit face normal (from the rasterised normals)
-    float* dTacc;          // (B,12)     backward accumulator: dL/d camera transform (zeroed by the pixel backward)
+    float* dTpart;         // (B,ceil(V/32),12) per-workgroup partial sums of dL/d camera transform (vertex backward; summed in index order)
     unsigned* ticket;      // (B)        arrival counter of the vertex-backward workgroups of an image (same)
                            //            .y (as int bits) = id of the knum-th soft-mask face taken, INT_MAX if fewer were
     float4* gp;            // (B,H,W,2)  covered pixels: K2 contributions of the pixel to its face {d/d(ax,ay,bx,by)} {d/d(cx,cy), d/d(nx,ny)}:
@@ -65,11 +66,20 @@ struct Workspace {
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
+    int* nheavy;           // (B)        how many of an image's first tiles (in that order) are walked by four waves together
     long long* ltot;       // (B,MM_LSUB,4) fused loss: per image {sum|pi-gi|, sum p*g, sum p+g-p*g, -} in 2^-32 fixed point, spread over
                            //            MM_LSUB sub-accumulators (64-bit integer atomics of the raster waves: exact, order-free); zeroed by vertex_fwd
-    int* tcnt;             // (B,ntiles)+(B) records appended per texture tile, then per-image spill counts (zeroed every backward)
+    int* tcnt;             // (B,ntiles)+(B)+(B,MM_GSHARD,8) records appended per texture tile, per-image spill counts, per-image maxima of the pixel
+                           //            backward (float bits: max |K2 number|, max |dL/dalpha|); zeroed by the vertex stage of the forward and by every
+                           //            vertex backward for the next one
     TexRecord* trec;       // (B,ntiles,MM_TREC_CAP)
     TexSpill* tspill;      // (B,4*H*W)   records of tiles whose list is full (worst case: every pixel, 2x2 tiles)
+    int2* chunkmap;        // (B,F)      {first sweep item, number of items} of every face (plan kernel, every forward)
+    int2* items;           // (B,item_cap) sweep items {face, chunk of its box; -1: the whole box}
+    int2* nitems;          // (B)        {items listed, pixels per chunk in this image (MM_CHUNK_PX << k)}
+    float* part;           // (B,item_cap,12) per-item partial sums of dL/d(face xy) (6) and dL/d(unit normal) (3); the vertex backward adds a
+                           //            face's items up in index order
+    int item_cap;          // F + 16 H W / MM_CHUNK_PX: every face has an item, and sixteen screens' worth of box pixels are cut into chunks
     int ntiles;
     int bin_shift, nbx, nby, words;
     size_t binmask_bytes;
@@ -78,7 +88,7 @@ struct Workspace {
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-__host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, int H, int W, int Ht, int Wt) {
+__host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, int F, int H, int W, int Ht, int Wt) {
     Workspace w;
     char* p = (char*)base;
     size_t o = 0;
@@ -91,9 +101,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.geo = (float4*)(p + o);       o += align256((size_t)B * F * 3 * sizeof(float4));
     w.binmask = (uint64_t*)(p + o); o += align256(w.binmask_bytes);
     w.soft = (float2*)(p + o);      o += align256((size_t)B * H * W * sizeof(float2));
-    w.dfxy = (float*)(p + o);       o += align256((size_t)B * F * 6 * sizeof(float));
-    w.dfn = (float*)(p + o);        o += align256((size_t)B * F * 3 * sizeof(float));
-    w.dTacc = (float*)(p + o);      o += align256((size_t)B * 12 * sizeof(float));
+    w.dTpart = (float*)(p + o);     o += align256((size_t)B * ((V + 31) / 32) * 12 * sizeof(float));
     w.ticket = (unsigned*)(p + o);  o += align256((size_t)B * sizeof(unsigned));
     w.gp = (float4*)(p + o);        o += align256((size_t)B * H * W * 2 * sizeof(float4));
     w.gp2 = (float*)(p + o);        o += align256((size_t)B * H * W * sizeof(float));
@@ -101,10 +109,16 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int F, i
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
     w.ltot = (long long*)(p + o);   o += align256((size_t)B * MM_LSUB * 4 * sizeof(long long));
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
+    w.nheavy = (int*)(p + o);       o += align256((size_t)B * sizeof(int));
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
-    w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + B) * sizeof(int));
+    w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + (size_t)B + (size_t)B * MM_GSHARD * 8) * sizeof(int));
     w.tspill = (TexSpill*)(p + o);  o += align256((size_t)B * 4 * H * W * sizeof(TexSpill));
     w.trec = (TexRecord*)(p + o);   o += align256((size_t)B * w.ntiles * MM_TREC_CAP * sizeof(TexRecord));
+    w.item_cap = F + (int)(((size_t)16 * H * W + MM_CHUNK_PX - 1) / MM_CHUNK_PX);
+    w.chunkmap = (int2*)(p + o);    o += align256((size_t)B * F * sizeof(int2));
+    w.items = (int2*)(p + o);       o += align256((size_t)B * w.item_cap * sizeof(int2));
+    w.nitems = (int2*)(p + o);      o += align256((size_t)B * sizeof(int2));
+    w.part = (float*)(p + o);       o += align256((size_t)B * w.item_cap * 12 * sizeof(float));
     w.bytes = o;
     return w;
 }
@@ -302,6 +316,46 @@ struct ProfScope {
 #define MM_TIMELINE_END(name) do { } while (0)
 #endif
 
+// -DMM_PHASE_PROF (debug builds, profiles/tools/phase_prof.py): per-wave wall-clock totals of a kernel's phases.  A PhaseProf object
+// accumulates the time between successive mark(i) calls into slot i (every mark first waits for everything the wave has issued,
+// so a phase is charged with the latency of its own loads; that serialisation is why this is a debug build only) and flush()
+// stores the slots + the wave's total + two free counters.  MM_PP_STORAGE(name) in the kernel's translation unit defines the
+// buffer and its C getter mm_debug_pp_<name>(out[MM_PP_MAX][MM_PP_SLOTS + 3]).  Compiles to nothing otherwise.
+#ifdef MM_PHASE_PROF
+#define MM_PP_MAX 16384
+#define MM_PP_SLOTS 8
+#define MM_PP_STORAGE(name)                                                                                               \
+    namespace mm { __device__ unsigned long long g_pp_##name[MM_PP_MAX][MM_PP_SLOTS + 3]; }                                  \
+    extern "C" int mm_debug_pp_##name(unsigned long long* out) {                                                             \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm::g_pp_##name), sizeof(unsigned long long) * MM_PP_MAX * (MM_PP_SLOTS + 3)) == hipSuccess ? 0 : -1; \
+    }
+struct PhaseProf {
+    unsigned long long t0, t, acc[MM_PP_SLOTS], c0, c1;
+    __device__ PhaseProf() : c0(0), c1(0) {
+        for (int i = 0; i < MM_PP_SLOTS; ++i) acc[i] = 0;
+        t0 = t = wall_clock64();
+    }
+    __device__ void mark(int i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long n = wall_clock64(); acc[i] += n - t; t = n; }
+    __device__ void count(unsigned long long a, unsigned long long b) { c0 += a; c1 += b; }
+};
+#define MM_PP_BEGIN() mm::PhaseProf pp_
+#define MM_PP_MARK(i) pp_.mark(i)
+#define MM_PP_COUNT(a, b) pp_.count(a, b)
+#define MM_PP_ARG , mm::PhaseProf& pp_
+#define MM_PP_PASS , pp_
+#define MM_PP_FLUSH(name, wave_index) do { const long long wi_ = (wave_index); if ((threadIdx.x & 63) == 0 && wi_ < MM_PP_MAX) {     \
+    for (int i_ = 0; i_ < MM_PP_SLOTS; ++i_) mm::g_pp_##name[wi_][i_] = pp_.acc[i_];                                          \
+    mm::g_pp_##name[wi_][MM_PP_SLOTS] = wall_clock64() - pp_.t0; mm::g_pp_##name[wi_][MM_PP_SLOTS + 1] = pp_.c0; mm::g_pp_##name[wi_][MM_PP_SLOTS + 2] = pp_.c1; } } while (0)
+#else
+#define MM_PP_STORAGE(name)
+#define MM_PP_BEGIN() do { } while (0)
+#define MM_PP_MARK(i) do { } while (0)
+#define MM_PP_COUNT(a, b) do { } while (0)
+#define MM_PP_ARG
+#define MM_PP_PASS
+#define MM_PP_FLUSH(name, wave_index) do { } while (0)
+#endif
+
 // launch check shared by every launcher: the HIP error (if any) is kept per host thread for mm_last_error_detail()
 struct LaunchError { hipError_t code; const char* what; };
 inline LaunchError& last_launch_error() { static thread_local LaunchError e = {hipSuccess, ""}; return e; }
@@ -394,10 +448,25 @@ __device__ inline void loss_totals(const long long* ltot, int b, float& l1, floa
     l1 = (float)s0 * (1.f / 4294967296.f); up = (float)s1 * (1.f / 4294967296.f); un = (float)s2 * (1.f / 4294967296.f);   // one rounding each
 }
 
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide sum / max, the result in every lane.  Four DPP steps (VALU cross-lane operands: no LDS crossbar traffic, no
+// ds_bpermute latency chain) leave every 16-lane row holding its own total; the four row totals are read as scalars.  Fixed order.
+template <int CTRL>
+__device__ inline float dpp_move(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)); }
+__device__ inline float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);       // row_half_mirror
+    v += dpp_move<0x140>(v);       // row_mirror
     return v;
+}
+__device__ inline float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ inline float wave_sum(float v) {
+    v = row16_sum(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ inline float wave_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v)); v = fmaxf(v, dpp_move<0x4E>(v)); v = fmaxf(v, dpp_move<0x141>(v)); v = fmaxf(v, dpp_move<0x140>(v));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 }  // namespace mm

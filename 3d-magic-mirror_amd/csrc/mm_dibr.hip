@@ -18,7 +18,7 @@
 namespace mm {
 
 struct DibrWorkspace {
-    float4* geo; uint64_t* binmask; unsigned short* order; float2* soft; int32_t* fidx;
+    float4* geo; uint64_t* binmask; unsigned short* order; int* nheavy; float2* soft; int32_t* fidx;
     int bin_shift, nbx, nby, words, blocks_per_image;
     size_t bytes;
 };
@@ -35,6 +35,7 @@ static DibrWorkspace carve_dibr(void* base, int B, int F, int H, int W) {
     w.geo = (float4*)(p + o);            o += align256((size_t)B * F * 3 * sizeof(float4));
     w.binmask = (uint64_t*)(p + o);      o += align256((size_t)B * w.nbx * w.nby * w.words * sizeof(uint64_t));
     w.order = (unsigned short*)(p + o);  o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
+    w.nheavy = (int*)(p + o);            o += align256((size_t)B * sizeof(int));
     w.soft = (float2*)(p + o);           o += align256((size_t)B * H * W * sizeof(float2));
     w.fidx = (int32_t*)(p + o);          o += align256((size_t)B * H * W * sizeof(int32_t));
     w.bytes = o;
@@ -69,13 +70,23 @@ __global__ __launch_bounds__(256) void dibr_pack_kernel(PackArgs a) {
     bin_wave_faces(a.mask, b, a.nbx, a.nby, a.words, a.bin_shift, c, tid & 63, bx0, by0, bw, bh);
 }
 
-// the fused kernel's walk, the generic epilogue
-__global__ __launch_bounds__(64) void raster_dibr_kernel(RasterArgs a) {
-    __shared__ WaveStage s_stage;
-    const TileCtx t = make_tile(a);
+// the fused kernel's walk (four tiles per workgroup, or one heavy tile walked by its four waves), the generic epilogue
+template <bool kBlock>
+__global__ __launch_bounds__(kBlock ? 256 : 64) void raster_dibr_kernel(RasterArgs a) {
+    __shared__ WaveStage s_stage[kBlock ? 4 : 1];
+    const int wv = kBlock ? threadIdx.x >> 6 : 0;
+    bool valid, coop;
+    const TileCtx t = make_tile<kBlock>(a, wv, valid, coop);
     Hit h;
     SoftState ss;
-    tile_walk(a, t, &s_stage, h, ss);
+    MM_PP_BEGIN();
+    if (kBlock && coop) {
+        tile_walk_coop(a, t, s_stage, wv, h, ss);
+        if (wv != 0) return;
+    } else {
+        if (!valid) return;
+        tile_walk(a, t, &s_stage[wv], h, ss MM_PP_PASS);
+    }
     if (!t.in_img) return;
     const size_t pix = ((size_t)t.b * a.H + t.py) * a.W + t.px;
     a.face_idx[pix] = h.f;
@@ -247,8 +258,11 @@ int mm_dibr_rasterization_forward(const MMDibrDesc* d, mm_stream_t stream) {
     a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.face_idx = w.fidx; a.options = d->options;
     a.feats = d->face_features; a.D = d->D; a.interp = d->interpolated_features; a.soft_out = d->soft_mask;
     a.face_idx64 = (long long*)d->face_idx;
-    a.order = launch_order(a, w.order, d->B, nullptr, s);
-    hipLaunchKernelGGL(raster_dibr_kernel, dim3(a.blocks_per_image * d->B * 4), dim3(64), 0, s, a);
+    a.order = launch_order(a, w.order, w.nheavy, d->B, nullptr, s);
+    a.nheavy = w.nheavy;
+    const bool block = walk_block_mode(a);
+    if (block) hipLaunchKernelGGL(raster_dibr_kernel<true>, dim3(walk_grid(a, true)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(raster_dibr_kernel<false>, dim3(walk_grid(a, false)), dim3(64), 0, s, a);
     return launch_ok("raster_dibr");
 }
 

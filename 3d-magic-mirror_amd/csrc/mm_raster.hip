@@ -23,26 +23,39 @@
 #include "mm_raster_walk.h"
 
 MM_TIMELINE_STORAGE(raster_fwd)
+MM_PP_STORAGE(raster_fwd)       // 0 tile setup, 1 mask -> id list, 2 fetch + stage + box tests + transposes, 3 colour pairs, 4 silhouette pairs, 5 shade + store
 
 namespace mm {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool kNoMask>
-__global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
+template <bool kNoMask, bool kBlock>
+__global__ __launch_bounds__(kBlock ? 256 : 64, kBlock ? 5 : 1) void raster_fwd_kernel(RasterArgs a) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
     MM_TIMELINE_BEGIN();
-    __shared__ WaveStage s_stage;
-    const TileCtx t = make_tile(a);
+    __shared__ WaveStage s_stage[kBlock ? 4 : 1];
+    MM_PP_BEGIN();
+    const int wv = kBlock ? threadIdx.x >> 6 : 0;
+    bool valid, coop;
+    const TileCtx t = make_tile<kBlock>(a, wv, valid, coop);     // coop is workgroup-uniform; !valid only in the last light workgroup of an image
     Hit h;
     SoftState ss;
-    tile_walk(a, t, &s_stage, h, ss);
+    MM_PP_MARK(0);
+    if (kBlock && coop) {
+        tile_walk_coop(a, t, s_stage, wv, h, ss);
+        if (wv != 0) return;                                     // the tile's pixels are shaded once
+    } else {
+        if (!valid) return;
+        tile_walk(a, t, &s_stage[wv], h, ss MM_PP_PASS);
+    }
     float n0 = 0.f, n1 = 0.f, n2 = 0.f;
     if (h.f >= 0) {
         const float* nn = a.fn + ((size_t)t.b * a.F + h.f) * 3;
         n0 = nn[0]; n1 = nn[1]; n2 = nn[2];
     }
     shade_store<kNoMask>(a, t, h, n0, n1, n2, ss);
+    MM_PP_MARK(5);
+    MM_PP_FLUSH(raster_fwd, (long long)blockIdx.x * (kBlock ? 4 : 1) + wv);
     MM_TIMELINE_END(raster_fwd);
 }
 
@@ -50,11 +63,47 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(RasterArgs a) {
 // sort in LDS (keys clipped to 1023; slots per image <= 1024), linear in the slots.  Only the launch ORDER of raster_fwd
 // depends on it -- slots with equal counts may come out in any order, no result does.  Bit 15 of an entry marks a tile that no
 // face can touch (count 0), which raster_fwd then never walks.
-__global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short* order) {
+__global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short* order, int* nheavy) {
     __shared__ int s_key[1024];
     __shared__ int s_start[1024];          // histogram, then the first output position of every key
     __shared__ int s_wave[4];
     const int b = blockIdx.x, tid = threadIdx.x, nslot = 4 * a.blocks_per_image;
+    // (b) sweep items of the backward: every face's inflated pixel box cut into chunks of MM_CHUNK_PX pixels, numbered in face
+    //     order by an exclusive scan of the chunk counts.  Thread t owns the contiguous faces [t*per, (t+1)*per): it adds up
+    //     their counts (independent loads), ONE block scan gives its first item, and it numbers its faces' chunks from there.
+    //     Should the items run out (more than sixteen screens' worth of box pixels in one image), the image's chunk size doubles
+    //     until they fit (item_cap >= F, so it ends).
+    if (a.chunkmap) {
+        const int per = (a.F + 255) / 256, f0 = min(a.F, tid * per), f1 = min(a.F, f0 + per);
+        auto box_px = [&](int f) {
+            const unsigned ext = __float_as_uint(a.geo[((size_t)b * a.F + f) * 3 + 2].w);
+            return (int)(ext & 0xFFFFu) * (int)(ext >> 16);      // 0: the box misses the image
+        };
+        int shift = 0, first = 0, total = 0;
+        for (;; ++shift) {
+            const int chunk = MM_CHUNK_PX << shift;
+            int mine = 0;
+            for (int f = f0; f < f1; ++f) mine += (box_px(f) + chunk - 1) / chunk;
+            int wtot;
+            first = wave_prefix_excl(mine, tid & 63, wtot);
+            __syncthreads();                                     // (s_wave of the previous round has been read)
+            if ((tid & 63) == 63) s_wave[tid >> 6] = wtot;
+            __syncthreads();
+            for (int w = 0; w < (tid >> 6); ++w) first += s_wave[w];
+            total = ((s_wave[0] + s_wave[1]) + s_wave[2]) + s_wave[3];
+            if (total <= a.item_cap || shift >= 20) break;       // workgroup-uniform
+        }
+        const int chunk = MM_CHUNK_PX << shift;
+        for (int f = f0; f < f1; ++f) {
+            const int nch = (box_px(f) + chunk - 1) / chunk;
+            a.chunkmap[(size_t)b * a.F + f] = make_int2(first, nch);
+            for (int c = 0; c < nch; ++c) a.items[(size_t)b * a.item_cap + first + c] = make_int2(f, c);
+            first += nch;
+        }
+        if (tid == 0) a.nitems[b] = make_int2(total, chunk);
+        __syncthreads();
+    }
+    if (!order) return;
     for (int i = tid; i < 1024; i += 256) s_start[i] = 0;
     __syncthreads();
     for (int slot = tid; slot < nslot; slot += 256) {
@@ -88,6 +137,9 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s_start[1023 - (4 * tid + j)] = before; before += h[j]; }
     __syncthreads();
+    // tiles with at least MM_HEAVY_CAND candidates come first: the slots in front of key MM_HEAVY_CAND - 1
+    if (tid == 0) nheavy[b] = min(s_start[MM_HEAVY_CAND - 1], MM_HEAVY_MAX);
+    __syncthreads();
     for (int slot = tid; slot < nslot; slot += 256)
         order[(size_t)b * nslot + atomicAdd(&s_start[s_key[slot]], 1)] = (unsigned short)(slot | (s_key[slot] == 0 ? 0x8000 : 0));
 }
@@ -103,26 +155,36 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     a.order = nullptr;
+    a.nheavy = nullptr;
     a.feats = nullptr; a.D = 0; a.interp = nullptr; a.soft_out = nullptr; a.face_idx64 = nullptr; a.options = d->options;
+    a.chunkmap = w.chunkmap; a.items = w.items; a.nitems = w.nitems; a.item_cap = w.item_cap;
     return a;
 }
 
-const unsigned short* launch_order(const RasterArgs& a_in, unsigned short* order, int B, void** prof_events, hipStream_t s) {
-    if (!(4 * a_in.blocks_per_image <= 1024 && a_in.words <= 64)) return nullptr;   // skipped where the sort would not pay
+const unsigned short* launch_order(const RasterArgs& a_in, unsigned short* order, int* nheavy, int B, void** prof_events, hipStream_t s) {
+    const bool sort = 4 * a_in.blocks_per_image <= 1024 && a_in.words <= 64;        // the tile sort is skipped where it would not pay
+    if (!sort && !a_in.chunkmap) return nullptr;
     RasterArgs a = a_in;
     a.order = nullptr;
     ProfScope po(prof_events, MM_PROF_ORDER, s);
-    hipLaunchKernelGGL(order_kernel, dim3(B), dim3(256), 0, s, a, order);
-    return order;
+    hipLaunchKernelGGL(order_kernel, dim3(B), dim3(256), 0, s, a, sort ? order : nullptr, nheavy);
+    return sort ? order : nullptr;
 }
 
 int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     RasterArgs a = make_raster_args(d, w);
-    dim3 grid(a.blocks_per_image * d->B * 4);
-    a.order = launch_order(a, w.order, d->B, d->prof_events, s);     // heavy-first launch order
+    a.order = launch_order(a, w.order, w.nheavy, d->B, d->prof_events, s);     // heavy-first launch order + sweep items of the backward
+    a.nheavy = w.nheavy;
+    const bool block = walk_block_mode(a);
+    const dim3 grid(walk_grid(a, block));
     ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
-    if (d->no_mask) hipLaunchKernelGGL(raster_fwd_kernel<true>, grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(raster_fwd_kernel<false>, grid, dim3(64), 0, s, a);
+    if (block) {
+        if (d->no_mask) hipLaunchKernelGGL((raster_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((raster_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
+    } else {
+        if (d->no_mask) hipLaunchKernelGGL((raster_fwd_kernel<true, false>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((raster_fwd_kernel<false, false>), grid, dim3(64), 0, s, a);
+    }
     return launch_ok("raster_fwd");
 }
 

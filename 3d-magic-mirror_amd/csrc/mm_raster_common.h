@@ -21,6 +21,7 @@ struct RasterArgs {
     float2* soft;                           // per pixel {soft-mask product state, id of the knum-th face taken (int bits)}
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
+    const int* nheavy;                      // (B) how many of an image's first tiles are walked cooperatively (plan kernel)
     // outputs
     float* rgba;
     int32_t* face_idx;
@@ -29,9 +30,13 @@ struct RasterArgs {
     const float* feats; int D;              // (B,F,3,D) per-corner features
     float* interp; float* soft_out; long long* face_idx64;
     int options;                            // MM_OPT_* bits
+    // plan kernel outputs for the backward (fused path only; nullptr: not wanted)
+    int2* chunkmap; int2* items; int2* nitems; int item_cap;
 };
 
 #define MM_PAIR_ROUND 512
+#define MM_HEAVY_CAND 192     // a tile with at least this many candidates (three batches) is walked by four waves together ...
+#define MM_HEAVY_MAX 32       // ... if it is among the image's MM_HEAVY_MAX heaviest
 
 struct TileCtx {
     int b, blk, px, py, tx0, ty0, lane, wave;   // wave = quadrant of the 16x16 block `blk`
@@ -141,7 +146,7 @@ struct Hit { int f; float w0, w1, w2; };
 // K1, one (candidate j, pixel l) pair of the staged batch: barycentrics, inside test, depth -> 64-bit LDS max.
 // straight-line on purpose (two of these are interleaved per trip): the IEEE divisions the oracle takes
 template <class Stage>
-__device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* st, int j, int l, bool live) {
+__device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* st, Stage* acc, int j, int l, bool live) {   // st: staged candidates; acc: the tile's results
     const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
     const float4 p0 = st->p0[j], p1 = st->p1[j], p2 = st->p2[j];
     float w0, w1, w2, nrm;
@@ -149,7 +154,7 @@ __device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* s
     w0 /= nrm; w1 /= nrm; w2 /= nrm;
     const float z0 = (w0 * p1.z + w1 * p1.w) + w2 * p2.x;
     if (live && !(w0 < 0.f || w1 < 0.f || w2 < 0.f) && z0 > -INFINITY)
-        atomicMax(&st->key[l], depth_key(z0, __float_as_int(p2.z)));
+        atomicMax(&acc->key[l], depth_key(z0, __float_as_int(p2.z)));
 }
 
 // The silhouette is held to 1e-4, not to the bit (only face_idx is), and its pair evaluations are most of the forward's
@@ -167,19 +172,19 @@ __device__ inline float seg_dist2_fast(float px, float py, float ux, float uy, f
 // K3, one (pixel l, candidate j) pair: factor q = 1 - exp(-sigma d^2) folded into the pixel's integer log2 sum.
 // sig2 = sigmainv / multiplier^2 (d is in multiplier units).
 template <class Stage>
-__device__ inline void soft_pair(const RasterArgs& a, const TileCtx& t, Stage* st, float sig2, int l, int j, bool live) {
+__device__ inline void soft_pair(const RasterArgs& a, const TileCtx& t, Stage* st, Stage* acc, float sig2, int l, int j, bool live) {
     const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
     const float4 p0 = st->p0[j], p1 = st->p1[j];
     const float d = fminf(fminf(seg_dist2_fast(x0, y0, p0.x, p0.y, p0.z, p0.w), seg_dist2_fast(x0, y0, p0.z, p0.w, p1.x, p1.y)),
                           seg_dist2_fast(x0, y0, p1.x, p1.y, p0.x, p0.y));
     const float q = 1.f - __builtin_amdgcn_exp2f(-(d * sig2) * 1.4426950408889634f);
     if (live) {
-        if (q == 0.f) atomicAdd(&st->zeros[l], 1);
+        if (q == 0.f) atomicAdd(&acc->zeros[l], 1);
         else {                                                   // log2(q) in 2^-32 fixed point: floor part and 32 fraction bits
             const float x = __builtin_amdgcn_logf(q);
             const float hi = floorf(x);
             const unsigned lo = (unsigned)((x - hi) * 4294967296.f);
-            atomicAdd((unsigned long long*)&st->logsum[l], ((unsigned long long)(long long)(int)hi << 32) + lo);
+            atomicAdd((unsigned long long*)&acc->logsum[l], ((unsigned long long)(long long)(int)hi << 32) + lo);
         }
     }
 }
@@ -306,8 +311,22 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
 
 // launch plumbing shared by the kernels' translation units
 RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w);
-// heavy-first tile order for the walk kernels (mm_raster.hip); returns the order buffer to put in RasterArgs::order, or nullptr
-// where the sort does not pay (then the natural order is used)
-const unsigned short* launch_order(const RasterArgs& a, unsigned short* order, int B, void** prof_events, hipStream_t s);
+// plan kernel (mm_raster.hip), one workgroup per image between the vertex stage and the walk: (a) heavy-first tile order for the
+// walk kernels, (b) the sweep items (face, box chunk) of the backward.  Returns the order buffer to put in
+// RasterArgs::order, or nullptr where the sort does not pay (then the natural order is used).
+const unsigned short* launch_order(const RasterArgs& a, unsigned short* order, int* nheavy, int B, void** prof_events, hipStream_t s);
+// The walk kernels come in two workgroup shapes with identical results: 256 threads (four tiles per workgroup, heavy tiles walked by
+// the four waves together) and 64 threads (one tile per workgroup).  The first wins where single tiles are heavy enough to be the
+// kernel's tail (small screens: the whole mesh folds into a few 8x8 tiles), the second where tiles are many and even.
+// MM_OPT_WALK_BLOCK / MM_OPT_WALK_WAVE force one (tuning / tests); default: by bin size.
+inline bool walk_block_mode(const RasterArgs& a) {
+    if (a.options & MM_OPT_WALK_BLOCK) return true;
+    if (a.options & MM_OPT_WALK_WAVE) return false;
+    return a.bin_shift == 3;                                     // 8-pixel bins = screens up to ~128x128 for the reference's meshes
+}
+inline unsigned walk_grid(const RasterArgs& a, bool block) {
+    if (!block) return (unsigned)a.B * (unsigned)a.blocks_per_image * 4u;
+    return a.order ? (unsigned)a.B * (unsigned)(MM_HEAVY_MAX + (4 * a.blocks_per_image + 3) / 4) : (unsigned)a.B * (unsigned)a.blocks_per_image;
+}
 
 }  // namespace mm

@@ -18,23 +18,39 @@ struct __attribute__((aligned(16))) WaveStage {
     unsigned long long key[64];             // per pixel: best (orderable z << 32 | ~face) so far; 0 = none
     long long logsum[64];                   // per pixel: sum of log2(1-p) in 2^-32 fixed point (integer adds commute)
     int zeros[64];                          // per pixel: number of factors (1-p) that are exactly 0
+    int cnt[64];                            // cooperative walk: per pixel, inflated-box hits of this wave's batch of the current round
+    int lastf[64];                          // cooperative walk: per pixel, id of the knum-th silhouette face taken
 };
+static_assert(sizeof(WaveStage) <= 8192, "four of them must fit 32 KiB: five workgroups per CU");
 
-__device__ inline TileCtx make_tile(const RasterArgs& a) {
+// Work of a 256-thread workgroup: FOUR tiles, one per wave (nothing shared), or ONE heavy tile walked by its four waves together
+// (tile_walk_coop).  With the plan kernel's order (tiles of an image by decreasing candidate count, the first nheavy of them heavy):
+// workgroup j of image b takes heavy tile j, or -- behind the heavy ones -- the four tiles nheavy + 4 (j - nheavy) + wave.  Launch
+// order = heavy first, images interleaved (workgroup i -> image i % B): the kernel's duration is set by its slowest waves, so they
+// must not start last.  Without an order (huge meshes / screens): the 2x2 tiles of a 16x16 pixel block.
+//   valid: this wave has a tile;  coop: the workgroup's waves share it (wv = this wave's index among them).
+//   kBlock = false: the one-wave workgroup variant of the same kernels (one tile per workgroup, never cooperative): a slow tile
+//   then never pins the LDS and the wave slots of finished neighbours -- better where tiles are many and none is heavy.
+template <bool kBlock>
+__device__ inline TileCtx make_tile(const RasterArgs& a, int wv, bool& valid, bool& coop) {
     TileCtx t;
     int blk;
-    // one wave per workgroup (a slow tile then never pins the LDS of finished neighbours).  Launch order: the tiles with
-    // the most candidates first (order_kernel), images interleaved -- the kernel's duration is set by its slowest waves, so
-    // they must not start last.  Workgroup i -> image i % B (XCD i % 8 = image % 8 when 8 | B), rank i / B.
+    valid = true; coop = false;
     if (a.order) {
+        const int nslot = 4 * a.blocks_per_image;
         t.b = blockIdx.x % a.B;
-        const unsigned e = a.order[(size_t)t.b * 4 * a.blocks_per_image + blockIdx.x / a.B];
+        const int j = blockIdx.x / a.B, nh = kBlock ? a.nheavy[t.b] : 0;
+        int idx;
+        if (!kBlock) idx = j;
+        else if (j < nh) { idx = j; coop = true; }
+        else { idx = nh + (j - nh) * 4 + wv; valid = idx < nslot; }
+        const unsigned e = a.order[(size_t)t.b * nslot + (valid ? idx : 0)];
         const int slot = (int)(e & 0x7FFFu);
-        t.empty = (e >> 15) != 0;                                // the order kernel counted no candidate at all for this tile
+        t.empty = (e >> 15) != 0;                                // the plan kernel counted no candidate at all for this tile
         blk = slot >> 2; t.wave = slot & 3;
     } else {
-        map_block(blockIdx.x >> 2, a.B, a.blocks_per_image, t.b, blk);
-        t.wave = blockIdx.x & 3;
+        map_block(kBlock ? blockIdx.x : blockIdx.x >> 2, a.B, a.blocks_per_image, t.b, blk);
+        t.wave = kBlock ? wv : (int)(blockIdx.x & 3);
         t.empty = false;
     }
     t.blk = blk;
@@ -50,25 +66,44 @@ __device__ inline TileCtx make_tile(const RasterArgs& a) {
     return t;
 }
 
+// this lane's share of the bin's mask group -> ordered id list in st->ids; returns the number of candidates of the group
+__device__ inline int expand_ids(const RasterArgs& a, const TileCtx& t, WaveStage* st, int wbase) {
+    uint64_t w = 0;
+    if (t.lane < MM_GROUP_WORDS && wbase + t.lane < a.words) w = t.mask[wbase + t.lane];
+    int total;
+    int pos = wave_prefix_excl(__popcll(w), t.lane, total);
+    while (w) {                                                  // <= MM_GROUP_WORDS lanes, <= 64 iterations
+        const int bit = __ffsll((unsigned long long)w) - 1;
+        w &= w - 1;
+        st->ids[pos++] = (unsigned short)(t.lane * 64 + bit);
+    }
+    return total;
+}
+
+// candidate of this lane staged in LDS + its two pixel masks (front-face box: colour; inflated box: silhouette), candidate-major
+__device__ inline void stage_candidate(const RasterArgs& a, const TileCtx& t, WaveStage* st, int f, const float4& g0, const float4& g1, const float4& g2,
+                                       bool soft, uint64_t& mh, uint64_t& ms) {
+    st->p0[t.lane] = g0; st->p1[t.lane] = g1;
+    st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), __int_as_float(f));   // cz, nz, rank, face id
+    const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
+    const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
+    if (g2.y >= 0.f) mh = box_pixels(t, xmin - 0.f, ymin - 0.f, xmax + 0.f, ymax + 0.f);
+    if (soft) ms = box_pixels(t, xmin - a.infl, ymin - a.infl, xmax + a.infl, ymax + a.infl);
+}
+
 // Walk the bin's candidates in face order, 64 at a time.  For every batch the candidates are staged in st->p0/p1/p2[0..n)
 // and body(n, ph, ps) receives the batch's two hit matrices pixel-major (this lane's pixel, bit j = candidate j):
 //   ph  front faces whose box contains the pixel (colour);   ps  all faces whose inflated box contains it (silhouette;
 //   0 when want_soft() -- wave-uniform, asked once per batch -- says no pixel can take another silhouette face).
 template <class WantSoft, class Body>
-__device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, WantSoft&& want_soft, Body&& body) {
+__device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, WantSoft&& want_soft, Body&& body MM_PP_ARG) {
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
     for (int wbase = 0; wbase < a.words; wbase += MM_GROUP_WORDS) {
-        uint64_t w = 0;
-        if (t.lane < MM_GROUP_WORDS && wbase + t.lane < a.words) w = t.mask[wbase + t.lane];
-        int total;
-        int pos = wave_prefix_excl(__popcll(w), t.lane, total);
+        const int total = expand_ids(a, t, st, wbase);
         if (total == 0) continue;
-        while (w) {                                              // <= MM_GROUP_WORDS lanes, <= 64 iterations
-            const int bit = __ffsll((unsigned long long)w) - 1;
-            w &= w - 1;
-            st->ids[pos++] = (unsigned short)(t.lane * 64 + bit);
-        }
         wave_lds_sync();
+        MM_PP_MARK(1);
+        MM_PP_COUNT(total, 0);
         // batches of 64; the face records of batch k+1 are requested before batch k is evaluated (a tile with hundreds of
         // candidates would otherwise pay a dependent trip to memory per batch)
         float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
@@ -87,17 +122,12 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
             if (k0 + 64 < total) fetch(k0 + 64);
             const bool soft = want_soft();
             uint64_t mh = 0, ms = 0;                             // candidate-major: lane j = candidate j, bit p = pixel p
-            if (t.lane < n) {
-                st->p0[t.lane] = g0; st->p1[t.lane] = g1;
-                st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), __int_as_float(f));   // cz, nz, rank, face id
-                const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
-                const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
-                if (g2.y >= 0.f) mh = box_pixels(t, xmin - 0.f, ymin - 0.f, xmax + 0.f, ymax + 0.f);
-                if (soft) ms = box_pixels(t, xmin - a.infl, ymin - a.infl, xmax + a.infl, ymax + a.infl);
-            }
+            if (t.lane < n) stage_candidate(a, t, st, f, g0, g1, g2, soft, mh, ms);
             const uint64_t ph = __ballot(mh != 0) ? wave_transpose64(mh, t.lane) : 0ull;
             const uint64_t ps = __ballot(ms != 0) ? wave_transpose64(ms, t.lane) : 0ull;
             wave_lds_sync();
+            MM_PP_MARK(2);
+            MM_PP_COUNT(0, 1);
             body(n, ph, ps);
             wave_lds_sync();
         }
@@ -126,7 +156,7 @@ __device__ inline void winner(const RasterArgs& a, const TileCtx& t, unsigned lo
 // zeros.  A pixel takes silhouette faces while no face of the batches SO FAR covers it: for a pixel that stays
 // uncovered that is every batch, in order -- exactly the two-pass result; whatever a pixel gathered before a later
 // batch covered it is never looked at.
-__device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h, SoftState& ss) {
+__device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h, SoftState& ss MM_PP_ARG) {
     h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
     ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
     if (t.empty) return;                                         // wave-uniform: more than half of all tiles are empty
@@ -137,19 +167,76 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
     bool open = t.in_img;
     for_each_batch(a, t, st, [&]() { return __ballot(open && cnt < a.knum) != 0; }, [&](int n, uint64_t ph, uint64_t ps) {
         if (__ballot(ph != 0)) {
-            pair_parallel(t, st, ph, [&](int l, int j, bool live) { hard_pair(a, t, st, j, l, live); });   // pixel l, candidate j
+            pair_parallel(t, st, ph, [&](int l, int j, bool live) { hard_pair(a, t, st, st, j, l, live); });   // pixel l, candidate j
             open = t.in_img && st->key[t.lane] == 0ull;
+            MM_PP_MARK(3);
         }
         const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
         cnt += __popcll(sm);
         if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].w);   // knum-th face taken
-        if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, s2, l, j, live); });
-    });
+        if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, st, s2, l, j, live); });
+        MM_PP_MARK(4);
+    } MM_PP_PASS);
     wave_lds_sync();
     winner(a, t, st->key[t.lane], h);
     ss.zeros = st->zeros[t.lane];
     ss.qnz = exp2f((float)((double)st->logsum[t.lane] * (1.0 / 4294967296.0)));
     ss.lastf = lastf;
+}
+
+// A HEAVY tile (hundreds of candidates: a far-away mesh folded into a few tiles) walked by the four waves of its workgroup.  Alone,
+// its wave would be the kernel's tail: one wave issues a vector instruction every ~5 cycles at best, and ~8 batches of staging,
+// box tests, transposes and pair rounds added up to 40+ us while the chip drained.  Here the batches of a ROUND of four go to the
+// four waves; colour pairs are order-free (64-bit max in the workgroup's LDS), and the silhouette's "first knum faces in index
+// order" rule is kept exactly: every wave publishes its batch's per-pixel inflated-box hit counts, and a batch takes what is left
+// of knum after the batches before it -- for a pixel that stays uncovered that is the sequential result bit for bit (what a pixel
+// gathered before it was covered is never read, as in tile_walk).  stage[0] holds the tile's results; every wave stages in its own.
+__device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, WaveStage* stage, int wv, Hit& h, SoftState& ss) {
+    WaveStage* st = &stage[wv];
+    WaveStage* acc = &stage[0];
+    h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
+    ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
+    if (wv == 0) { acc->key[t.lane] = 0ull; acc->logsum[t.lane] = 0ll; acc->zeros[t.lane] = 0; acc->lastf[t.lane] = 0x7FFFFFFF; }
+    __syncthreads();
+    const float s2 = a.sigmainv / (a.mult * a.mult);
+    const float4* geo = a.geo + (size_t)t.b * a.F * 3;
+    int base_cnt = 0;                                            // this pixel's inflated-box hits in the rounds so far
+    bool open = t.in_img;
+    for (int wbase = 0; wbase < a.words; wbase += MM_GROUP_WORDS) {
+        const int total = expand_ids(a, t, st, wbase);           // every wave expands the same list into its own stage
+        if (total == 0) continue;                                // (the same in the four waves)
+        wave_lds_sync();
+        for (int r0 = 0; r0 < total; r0 += 4 * 64) {
+            const int k0 = r0 + wv * 64;
+            const int n = max(0, min(64, total - k0));
+            const bool soft = __ballot(open && base_cnt < a.knum) != 0;      // the same in the four waves
+            uint64_t mh = 0, ms = 0;
+            if (t.lane < n) {
+                const int f = wbase * 64 + st->ids[k0 + t.lane];
+                stage_candidate(a, t, st, f, geo[(size_t)f * 3 + 0], geo[(size_t)f * 3 + 1], geo[(size_t)f * 3 + 2], soft, mh, ms);
+            }
+            const uint64_t ph = __ballot(mh != 0) ? wave_transpose64(mh, t.lane) : 0ull;
+            const uint64_t ps = __ballot(ms != 0) ? wave_transpose64(ms, t.lane) : 0ull;
+            st->cnt[t.lane] = __popcll(ps);
+            __syncthreads();
+            int before = base_cnt, round_total = 0;              // hits of the batches before this wave's, in index order
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) { const int c = stage[w2].cnt[t.lane]; before += w2 < wv ? c : 0; round_total += c; }
+            if (__ballot(ph != 0)) pair_parallel(t, st, ph, [&](int l, int j, bool live) { hard_pair(a, t, st, acc, j, l, live); });
+            const uint64_t sm = soft_take(ps, open, a.knum - before);
+            if (sm != 0 && before + __popcll(sm) >= a.knum) acc->lastf[t.lane] = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].w);
+            if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, acc, s2, l, j, live); });
+            base_cnt += round_total;
+            __syncthreads();
+            open = t.in_img && acc->key[t.lane] == 0ull;
+        }
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    winner(a, t, acc->key[t.lane], h);
+    ss.zeros = acc->zeros[t.lane];
+    ss.qnz = exp2f((float)((double)acc->logsum[t.lane] * (1.0 / 4294967296.0)));
+    ss.lastf = acc->lastf[t.lane];
 }
 
 }  // namespace mm

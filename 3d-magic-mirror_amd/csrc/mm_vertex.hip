@@ -97,10 +97,11 @@ struct VertexBwdArgs {
     const float* vertices;
     const float *azim, *elev, *dist, *bias;
     const float* T;         // (B,12) saved by the forward
-    const float* dfxy;      // (B,F,3,2)
-    const float* dfn;       // (B,F,3)
+    const int2* chunkmap;   // (B,F) {first sweep item, items} of every face
+    const float* part;      // (B,item_cap,12) the items' partial sums: dL/d(face xy) (6), dL/d(unit normal) (3)
+    int item_cap;
     const float* gfn;       // (B,F,3) external gradient of attributes['face_normals'] or NULL
-    float* dTacc;           // (B,12) zeroed accumulator
+    float* dTpart;          // (B,groups,12) per-workgroup partial sums of dL/dT
     unsigned* ticket;       // (B) zeroed arrival counter
     int* tcnt; int ntcnt;   // texture-record counters, consumed by the gather before this kernel: cleared for the next backward
     const float* dl_part;   // (B,blocks,12) partial dL/dlights of the pixel backward
@@ -144,13 +145,19 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             const int item = a.vc_items[it];
             const int f = item / 3, k = item - f * 3;
             const size_t o = (size_t)b * a.F + f;
+            // the face's gradients = its sweep items' partial sums, added in index order (one item for most faces)
+            float gx = 0.f, gy = 0.f, g[3] = {0.f, 0.f, 0.f};
+            const int2 cm = a.chunkmap[o];
+            const float* part = a.part + ((size_t)b * a.item_cap + cm.x) * 12;
+            for (int c = 0; c < cm.y; ++c) {
+                gx += part[c * 12 + k * 2]; gy += part[c * 12 + k * 2 + 1];
+                g[0] += part[c * 12 + 6]; g[1] += part[c * 12 + 7]; g[2] += part[c * 12 + 8];
+            }
             // through face_vertices_image
-            const float gx = a.dfxy[o * 6 + k * 2], gy = a.dfxy[o * 6 + k * 2 + 1];
             d[0] += gx * a.proj0 * ipz;
             d[1] += gy * a.proj1 * ipz;
             d[2] += -(gx * xi + gy * yi) * a.proj2 * ipz;
             // through the unit face normal
-            float g[3] = {a.dfn[o * 3], a.dfn[o * 3 + 1], a.dfn[o * 3 + 2]};
             if (a.gfn) { g[0] += a.gfn[o * 3]; g[1] += a.gfn[o * 3 + 1]; g[2] += a.gfn[o * 3 + 2]; }
             if (g[0] != 0.f || g[1] != 0.f || g[2] != 0.f) {
                 const int i0 = a.faces[f * 3], i1 = a.faces[f * 3 + 1], i2 = a.faces[f * 3 + 2];
@@ -202,19 +209,19 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
     }
     __syncthreads();
     if (tid < 12) {
-        // RETURNING atomic: its value only comes back once the add has been performed where agent-scope atomics live, so the
-        // wait below really orders it before this workgroup's ticket
-        const float old = atomicAdd(a.dTacc + b * 12 + tid, ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid]);
-        asm volatile("" :: "v"(old));
+        // This workgroup's partial of dL/dT, WRITE-THROUGH (agent-scope relaxed atomic store = sc1: it lands at the memory side, not in
+        // this XCD's L2), so that the image's last workgroup can read it with agent-scope loads and NO fence on either side
+        // (cdna_hip_programming.md G16, form "sc1 stores and sc1 loads on both sides").  No float atomics: the sum below runs
+        // over the workgroups in index order, so the camera gradients are bitwise reproducible.
+        __hip_atomic_store(a.dTpart + ((size_t)b * gridDim.x + blockIdx.x) * 12 + tid,
+                           ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- publish, take a ticket; the last workgroup of this image finishes the camera chain
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the storing wave drains its stores before the ticket is drawn
     __syncthreads();
     if (tid == 0) {
         // No agent-scope fences here: a release fence writes back the XCD's whole L2 and an acquire invalidates it, once per
-        // workgroup.  What the last workgroup reads from the others is dTacc only, and that is written with agent-scope
-        // atomics (performed at the memory side, never resident dirty in an L2) that have been waited for (vmcnt) before
-        // the ticket is taken, and read back with agent-scope atomic loads.
+        // workgroup (removing them took this kernel from 213 to 53 us at B=384).
         const unsigned prev = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (prev == gridDim.x - 1) ? 1 : 0;
     }
@@ -233,9 +240,16 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         }
     }
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
+    if (tid < 12) {                                              // dL/dT = sum of the workgroups' partials, in index order
+        float sum = 0.f;
+        for (unsigned g = 0; g < gridDim.x; ++g)
+            sum += __hip_atomic_load(a.dTpart + ((size_t)b * gridDim.x + g) * 12 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_red[0][tid] = sum;
+    }
+    __syncthreads();
     if (tid == 0) {
         float dT[12];
-        for (int i = 0; i < 12; ++i) dT[i] = __hip_atomic_load(a.dTacc + b * 12 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 12; ++i) dT[i] = s_red[0][i];
         float dd, de, da, db[2];
         camera_backward(a.dist[b], s_cam, dT, &dd, &de, &da, db);
         a.grad_dist[b] = dd; a.grad_elev[b] = de; a.grad_azim[b] = da;
@@ -250,7 +264,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.faces = d->faces; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.geo = w.geo; a.face_normals = d->face_normals;
-    a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B;
+    a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B + d->B * MM_GSHARD * 8;
     a.ltot = w.ltot; a.nltot = d->B * MM_LSUB * 4;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mask = w.binmask;
@@ -266,9 +280,9 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2];
     a.faces = d->faces; a.vc_offsets = d->vc_offsets; a.vc_items = d->vc_items; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
-    a.T = w.T; a.dfxy = w.dfxy; a.dfn = w.dfn; a.gfn = g->grad_face_normals;
-    a.dTacc = w.dTacc; a.ticket = w.ticket;
-    a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B;
+    a.T = w.T; a.chunkmap = w.chunkmap; a.part = w.part; a.item_cap = w.item_cap; a.gfn = g->grad_face_normals;
+    a.dTpart = w.dTpart; a.ticket = w.ticket;
+    a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B + d->B * MM_GSHARD * 8;
     a.dl_part = w.dl_part; a.blocks_per_image = w.blocks_per_image; a.grad_lights = g->grad_lights;
     a.grad_vertices = g->grad_vertices;
     a.grad_azim = g->grad_azimuths; a.grad_elev = g->grad_elevations; a.grad_dist = g->grad_distances; a.grad_bias = g->grad_biases;

@@ -166,10 +166,6 @@ class DiffRender(object):
             self.sign_init = self.sign_init.cuda()
         self.render_height = round(self.ratio * self.image_size)                                  # :298
         self._vc_offsets, self._vc_items = template.vertex_corner_adjacency(self.num_vertices, self.faces)
-        # faces by decreasing template area: the backward sweeps big screen boxes first (launch order only)
-        tri = self.vertices_init[self.faces]
-        area = torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=1).norm(dim=1)
-        self._face_order = torch.argsort(area, descending=True)
         self._static_cache = {}
         # dibr_rasterization defaults (kaolin v0.12.0): sigmainv=7000, boxlen=0.02, knum=30, multiplier=1000, eps=1e-8
         self.sigmainv, self.boxlen, self.knum, self.multiplier, self.eps = 7000.0, 0.02, 30, 1000.0, 1e-8
@@ -186,8 +182,7 @@ class DiffRender(object):
             st = {"faces": self.faces.to(device=device, dtype=torch.int32).contiguous(),
                   "face_uvs": self.face_uvs.to(device=device, dtype=torch.float32).reshape(-1, 3, 2).contiguous(),
                   "vc_offsets": self._vc_offsets.to(device=device, dtype=torch.int32).contiguous(),
-                  "vc_items": self._vc_items.to(device=device, dtype=torch.int32).contiguous(),
-                  "face_order": self._face_order.to(device=device, dtype=torch.int32).contiguous()}
+                  "vc_items": self._vc_items.to(device=device, dtype=torch.int32).contiguous()}
             self._static_cache[key] = st
         return st
 
@@ -203,7 +198,6 @@ class DiffRender(object):
         d.vertices, d.textures, d.lights, d.bg = N.ptr(vertices), N.ptr(textures), N.ptr(lights), N.ptr(bg)
         d.azimuths, d.elevations, d.distances, d.biases = N.ptr(azimuths), N.ptr(elevations), N.ptr(distances), N.ptr(biases)
         d.rgba, d.face_idx, d.face_normals, d.imnormal = N.ptr(rgba), N.ptr(face_idx), N.ptr(fn), N.ptr(imn)
-        d.face_order = N.ptr(st["face_order"])
         d.options = self.options
         return d
 

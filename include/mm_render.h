@@ -61,8 +61,6 @@ typedef struct MMRenderDesc {
     const float* face_uvs;      /* (F,3,2) raw OBJ uv of every corner (networks.py:196-202) */
     const int32_t* vc_offsets;  /* (V+1) CSR: vertex -> incident corners ...        (backward only; may be NULL forward) */
     const int32_t* vc_items;    /* (3F)  ... each item = face*3 + corner, ascending (backward only) */
-    const int32_t* face_order;  /* (F) optional: faces sorted by decreasing template area; only the ORDER in which the
-                                 *     backward visits faces depends on it (big screen boxes first); NULL = index order */
     /* per-sample attributes (device), the 'attributes' dict of networks.py:259-270 */
     const float* vertices;      /* (B,V,3) */
     const float* textures;      /* (B,3,Ht,Wt) */
@@ -98,7 +96,9 @@ typedef struct MMRenderDesc {
  * one by one, the choices that SURVEY.md Appendix C lists as recalled from kaolin's sources and not re-verifiable here
  * (kaolin is not vendored): a maintainer with a CUDA box and real kaolin can pin the path by flipping a bit instead of
  * editing kernels.  oracle/mm_oracle.inc takes the same bits, and tests/ hold HIP == oracle for every one of them. */
-enum { MM_OPT_CULL_STRICT = 1 << 4,        /* rasterise faces with face_normals_z > 0 instead of >= 0                    (App. C-1) */
+enum { MM_OPT_WALK_BLOCK = 1 << 1,         /* tuning: force the 256-thread / cooperative-heavy-tile shape of the walk kernels ...          */
+       MM_OPT_WALK_WAVE = 1 << 2,          /* ... or the one-wave-per-tile shape (identical results; default: chosen by screen-bin size)   */
+       MM_OPT_CULL_STRICT = 1 << 4,        /* rasterise faces with face_normals_z > 0 instead of >= 0                    (App. C-1) */
        MM_OPT_SOFT_SKIP_CULLED = 1 << 5,   /* the soft mask skips the faces the colour pass culls                          (App. C-1) */
        MM_OPT_BBOX_HALF_OPEN = 1 << 6,     /* a pixel centre exactly on a face's bbox edge is outside (<= / >= reject)     (App. C-4) */
        MM_OPT_BARY_ONE_MINUS = 1 << 7,     /* barycentrics as w1 = k1/(S+eps), w2 = k2/(S+eps), w0 = 1 - w1 - w2 (eps added, not

@@ -1,0 +1,53 @@
+"""Per-wave wall-clock phase totals of the instrumented kernels (library variant built with -DMM_PHASE_PROF as lib/libmm_pp.so; the
+product library is untouched):   python profiles/tools/phase_prof.py [config2|config3|config5]
+Every mark waits for the wave's outstanding memory operations, so a phase is charged with the latency of its own loads (and the
+kernel as a whole runs slower than the product build: read the SHARES, not the absolute times)."""
+import sys, importlib, os, ctypes, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+cfg = sys.argv[1] if len(sys.argv) > 1 else "config2"
+name, B, S, ratio = bench.CONFIGS[cfg]
+bn = importlib.import_module("3d-magic-mirror_amd.build_native")
+var = os.path.join(os.path.dirname(bn.LIB), "libmm_pp.so")
+bn.build(out=var, extra_flags=["-DMM_PHASE_PROF"])
+pkg = importlib.import_module("3d-magic-mirror_amd"); stepmod = importlib.import_module("3d-magic-mirror_amd.step")
+pkg._native.LIB_PATH = var
+bn.needs_build = lambda: False
+dev = torch.device("cuda:0")
+dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio, emit_imnormal=False)
+H, W = dr.render_height, dr.image_size
+att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W)
+datt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}
+st = stepmod.RenderLossStep(dr, datt, gt.to(dev), fused=True)
+for _ in range(4): st.run()
+torch.cuda.synchronize()
+L = ctypes.CDLL(var)
+KERNELS = {
+    "gather_face": (["setup", "sweep: face_idx loads", "compaction", "item loads", "item math + LDS adds", "stores"], ("trips", "items")),
+    "gather_tex": (["count + first record", "clear LDS", "records", "tile store"], ("records", "-")),
+    "raster_fwd": (["tile setup", "mask -> id list", "geo fetch + stage + box tests + transposes", "colour pairs", "silhouette pairs", "winner + shade + store"], ("candidates", "batches")),
+}
+SL, MAXW = 8, 16384
+print("== %s: %s B=%d %dx%d (100 MHz ticks -> us)" % (cfg, name, B, H, W))
+for kn, (phases, cn) in KERNELS.items():
+    fn = getattr(L, "mm_debug_pp_" + kn, None)
+    if fn is None:
+        continue
+    out = (ctypes.c_ulonglong * (MAXW * (SL + 3)))()
+    assert fn(out) == 0
+    m = np.frombuffer(out, dtype=np.uint64).reshape(MAXW, SL + 3).astype(np.float64)
+    m = m[m[:, SL] > 0]
+    if not len(m):
+        continue
+    tot = m[:, SL] / 100.0
+    print("%s: %d waves recorded; wave time mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (kn, len(m), tot.mean(), np.median(tot), np.percentile(tot, 90), np.percentile(tot, 99), tot.max()))
+    for i, ph in enumerate(phases):
+        v = m[:, i] / 100.0
+        print("   %-46s mean %6.2f  p90 %6.2f  max %6.1f us   %5.1f %% of all wave time" % (ph, v.mean(), np.percentile(v, 90), v.max(), 100 * v.sum() / tot.sum()))
+    acc = m[:, :len(phases)].sum(1) / 100.0
+    print("   %-46s mean %6.2f us" % ("(unaccounted)", (tot - acc).mean()))
+    print("   %s: mean %.2f max %d;  %s: mean %.1f max %d" % (cn[0], m[:, SL + 1].mean(), m[:, SL + 1].max(), cn[1], m[:, SL + 2].mean(), m[:, SL + 2].max()))
+    heavy = np.argsort(-tot)[:4]
+    for h in heavy:
+        print("   slowest wave: total %.1f us | " % tot[h] + "  ".join("%s %.1f" % (ph.split(":")[0].split(" ")[0], m[h, i] / 100.0) for i, ph in enumerate(phases)) + " | %s %d %s %d" % (cn[0], m[h, SL + 1], cn[1], m[h, SL + 2]))

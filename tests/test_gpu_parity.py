@@ -70,6 +70,37 @@ def test_render_loss_backward_matches_oracle(pkg, oracle, name, B, S, ratio, no_
         assert np.abs(g_o[k]).max() > 0
 
 
+@pytest.mark.parametrize("name,B,S,ratio,no_mask,seed,dist", [
+    ("sphere", 4, 64, 1, True, 0, None),
+    ("smpl_uv_642", 3, 32, 2, False, 2, None),      # H = 2W, white background
+    ("sphere", 2, 50, 1, True, 4, None),            # ragged
+    ("smpl_uv_642", 48, 128, 1, True, 0, None),     # BASELINE config 2, full size
+    ("smpl_uv_642", 6, 128, 1, True, 3, 8.0),       # far camera: the whole mesh in a handful of tiles -> cooperative heavy-tile walk
+    ("ellipsoid", 5, 200, 1, True, 9, None),
+])
+def test_the_two_walk_kernel_shapes_agree_bit_for_bit(pkg, name, B, S, ratio, no_mask, seed, dist):
+    """MM_OPT_WALK_BLOCK (four tiles per 256-thread workgroup, heavy tiles walked by the four waves together) and MM_OPT_WALK_WAVE (one
+    tile per one-wave workgroup) evaluate the same expressions and combine them with exact, commutative LDS atomics: every forward
+    output must be identical, and so must the backward they feed."""
+    N = pkg._native
+    res = {}
+    for tag, opt in (("block", N.OPT_WALK_BLOCK), ("wave", N.OPT_WALK_WAVE)):
+        dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, ratio=ratio, seed=seed, no_mask=no_mask)
+        if dist is not None:
+            with torch.no_grad():
+                datt["distances"].fill_(dist)
+        dr.options = opt
+        rgbs, out = dr.render(no_mask=no_mask, **datt)
+        dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask).backward()
+        res[tag] = (rgbs.detach().clone(), dr.last_face_idx.clone(), out["face_normals"].detach().clone(), out["imnormal"].clone(),
+                    {k: datt[k].grad.clone() for k in LEAVES if datt[k].grad is not None})
+    a, b = res["block"], res["wave"]
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert float((a[1] >= 0).float().mean()) > 0.01
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k                  # integer fixed-point sums: the backward is bitwise reproducible
+
+
 @pytest.mark.parametrize("knum,boxlen,sigmainv,dist", [
     (3, 0.02, 7000.0, None),      # knum far below the candidates per pixel: the "first knum faces in index order" rule
     (30, 0.02, 7000.0, 9.0),      # far camera: the whole mesh in a few tiles, > 30 candidates per silhouette pixel
@@ -93,6 +124,29 @@ def test_soft_mask_truncation_and_margins_match_oracle(pkg, oracle, knum, boxlen
     assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
     alpha = rgba_o[..., 3]
     assert ((alpha > 0.01) & (alpha < 0.99)).mean() > 0.005          # there is a silhouette band to get wrong
+    _close(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
+    for k in LEAVES:
+        _close(datt[k].grad.cpu().numpy(), g_o[k])
+
+
+@pytest.mark.parametrize("name,B,S,dist", [("sphere", 6, 128, 1.45), ("smpl_uv_642", 4, 200, 1.6)])
+def test_close_camera_huge_face_boxes_match_oracle(pkg, oracle, name, B, S, dist):
+    """Camera almost inside the mesh: perspective blows single faces up to thousands of box pixels.  The backward sweeps such faces
+    in chunks on dedicated waves (plan kernel -> chunk list -> partial sums added by the vertex backward); same bar as everywhere."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, seed=31)
+    with torch.no_grad():
+        datt["distances"].fill_(dist)
+    inp["distances"] = np.full_like(inp["distances"], dist)
+    rgbs, out = dr.render(no_mask=True, **datt)
+    dr.recon_data(rgbs, gt.to(dev), no_mask=True).backward()
+    rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, True, proj)
+    loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+    g_o = oracle.render_backward(inp, H, W, True, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None)
+    assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
+    # faces with more than 512 box pixels exist (what the chunk path is for)
+    fvi = oracle.prepare_vertices(inp["vertices"], inp["faces"], oracle.camera(inp["distances"], inp["elevations"], inp["azimuths"], inp["biases"]), proj)[1]
+    ext = (fvi.max(2) - fvi.min(2)) * np.asarray([W, H], np.float32) / 2.0
+    assert int(((ext[..., 0] * ext[..., 1]) > 512).sum()) > 10
     _close(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
     for k in LEAVES:
         _close(datt[k].grad.cpu().numpy(), g_o[k])

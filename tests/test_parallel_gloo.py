@@ -46,11 +46,29 @@ def _worker(rank, world, port, out):
     extra = torch.full((3,), float(rank + 1))
     par.allreduce_mean_([gW, None, extra], bucket_bytes=64)   # tiny bucket: forces several flushes
     lt = torch.tensor([loss]); par.allreduce_mean_([lt])
+    # the bench's per-step gradient all-reduce (bench.py --grad-mb): one flat buffer, chunked, launched asynchronously and waited for
+    # before the buffer is touched again; two steps back to back
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red = par.GradAllReducer(flat, chunk_bytes=1024)              # 256 floats per chunk: four collectives per step
+    red.launch()
+    overlap = torch.ones(10).sum()                                # "the next step's render" would run here
+    red.wait()
+    step1 = flat.clone()
+    flat.mul_(rank + 1.0)
+    red.launch(); red.launch()                                    # a second launch first waits for the one in flight
+    red.wait()
+    # unequal shards (B % world != 0): weighting by the local batch size gives the global-batch mean of per-rank batch means
+    lo5, hi5 = par.shard_bounds(5, rank, world)
+    per_image = torch.arange(5, dtype=torch.float32) + 1.0       # "per-image gradient"
+    local_mean = per_image[lo5:hi5].mean().reshape(1)
+    unweighted = local_mean.clone(); par.allreduce_mean_([unweighted])
+    par.allreduce_mean_([local_mean], local_weight=hi5 - lo5)
     tmax = par.max_over_ranks(0.5 + rank)
     v = torch.full((2,), float(rank)); par.broadcast_(v, src=1)
     par.barrier()
     if rank == 0:
-        torch.save({"gW": gW, "loss": lt, "extra": extra, "tmax": tmax, "bc": v}, out)
+        torch.save({"gW": gW, "loss": lt, "extra": extra, "tmax": tmax, "bc": v, "step1": step1, "step2": flat, "launched": red.launched,
+                    "bytes": red.bytes_per_step(), "wmean": local_mean, "umean": unweighted}, out)
     torch.distributed.destroy_process_group()
 
 
@@ -71,6 +89,14 @@ def test_two_rank_sharding_matches_single_process(oracle, tmp_path):
     assert abs(float(got["loss"]) - loss) < 1e-6
     np.testing.assert_allclose(got["gW"].numpy(), gW.numpy(), rtol=1e-4, atol=1e-8)
     assert got["extra"].tolist() == [1.5, 1.5, 1.5] and got["tmax"] == 1.5 and got["bc"].tolist() == [1.0, 1.0]
+    base = torch.arange(1000, dtype=torch.float32)
+    torch.testing.assert_close(got["step1"], base * 1.5)                       # mean of x and 2x
+    # rank 0's buffer after step 1 is 1.5x; scaled by (rank+1): 1.5x and 3x -> mean 2.25x; reduced once more (second launch): both
+    # ranks hold 2.25x, mean unchanged
+    torch.testing.assert_close(got["step2"], base * 2.25)
+    assert got["launched"] == 3 and got["bytes"] == 4000
+    assert abs(float(got["wmean"]) - 3.0) < 1e-6                               # mean of 1..5
+    assert abs(float(got["umean"]) - 3.25) < 1e-6                              # (2 + 4.5) / 2: what unweighted averaging would give
 
 
 def test_shard_bounds_cover_everything():

@@ -316,13 +316,15 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w);
 // RasterArgs::order, or nullptr where the sort does not pay (then the natural order is used).
 const unsigned short* launch_order(const RasterArgs& a, unsigned short* order, int* nheavy, int B, void** prof_events, hipStream_t s);
 // The walk kernels come in two workgroup shapes with identical results: 256 threads (four tiles per workgroup, heavy tiles walked by
-// the four waves together) and 64 threads (one tile per workgroup).  The first wins where single tiles are heavy enough to be the
-// kernel's tail (small screens: the whole mesh folds into a few 8x8 tiles), the second where tiles are many and even.
-// MM_OPT_WALK_BLOCK / MM_OPT_WALK_WAVE force one (tuning / tests); default: by bin size.
+// the four waves together) and 64 threads (one tile per workgroup).  Measured (profiles/r02_walk_shapes.md), raster_fwd us, block /
+// wave: 128x128 1280 faces 45.6 / 55.3; 128x64 38.4 / 51.5; 512x512 13 776 faces (no tile sort: a workgroup = the 2x2 tiles of a
+// block) 546 / 613; 256x256 1280 faces 147 / 134.  The first wins where single tiles are heavy enough to be the kernel's tail
+// (8-pixel bins: the mesh folds into few tiles) or where the four tiles are neighbours (unsorted); the second where tiles are many,
+// even and taken in sorted order.  MM_OPT_WALK_BLOCK / MM_OPT_WALK_WAVE force one (tuning / tests).
 inline bool walk_block_mode(const RasterArgs& a) {
     if (a.options & MM_OPT_WALK_BLOCK) return true;
     if (a.options & MM_OPT_WALK_WAVE) return false;
-    return a.bin_shift == 3;                                     // 8-pixel bins = screens up to ~128x128 for the reference's meshes
+    return a.bin_shift == 3 || !(4 * a.blocks_per_image <= 1024 && a.words <= 64);   // 8-pixel bins, or no tile sort
 }
 inline unsigned walk_grid(const RasterArgs& a, bool block) {
     if (!block) return (unsigned)a.B * (unsigned)a.blocks_per_image * 4u;

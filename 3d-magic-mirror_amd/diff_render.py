@@ -17,6 +17,25 @@ from . import _native as N
 from . import att_loss, mesh_reg, obj_io, template
 
 
+class _PooledWorkspace(object):
+    """A render workspace borrowed from its DiffRender's pool for as long as the autograd node that owns it lives (forward ->
+    last backward, retain_graph included); it goes back when the node is freed.  Five or six renders of a trainer iteration thus
+    cycle through a handful of buffers instead of allocating ~200 MB each (the library never allocates; the host side owns scratch)."""
+
+    def __init__(self, pool, key, nbytes, device):
+        self.pool, self.key = pool, key
+        free = pool.setdefault(key, [])
+        self.buf = free.pop() if free else torch.empty(nbytes, device=device, dtype=torch.uint8)
+
+    def __del__(self):
+        try:
+            free = self.pool.setdefault(self.key, [])
+            if len(free) < 8:
+                free.append(self.buf)
+        except Exception:                                        # interpreter shutdown
+            pass
+
+
 class _RenderFn(torch.autograd.Function):
     """rgba (B,H,W,4), face_normals (B,F,3), imnormal (B,H,W,3), face_idx (B,H,W) = render(attributes)."""
 
@@ -46,11 +65,14 @@ class _RenderFn(torch.autograd.Function):
         fn = torch.empty((B, dr.num_faces, 3), device=dev, dtype=torch.float32)
         imn = torch.empty((B, H, W, 3), device=dev, dtype=torch.float32) if want_imnormal else None
         d = dr._desc(st, B, no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases, rgba, face_idx, fn, imn)
-        ws = torch.empty(N.lib().mm_query_workspace(ctypes.byref(d)), device=dev, dtype=torch.uint8)
+        nbytes = N.lib().mm_query_workspace(ctypes.byref(d))
+        holder = _PooledWorkspace(dr._ws_pool, (str(dev), nbytes), nbytes, dev)
+        ws = holder.buf
         d.workspace, d.workspace_bytes = N.ptr(ws), ws.numel()
         N.check(N.lib().mm_render_forward(ctypes.byref(d), N.current_stream(dev)), "mm_render_forward")
         ctx.dr, ctx.no_mask = dr, bool(no_mask)
-        ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, ws)
+        ctx.ws_holder = holder                                   # returned to the pool when this node dies
+        ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn)
         ctx.mark_non_differentiable(face_idx)
         if imn is None:
             imn = torch.empty(0, device=dev)
@@ -59,7 +81,8 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgba, g_fn, _g_imn, _g_idx):
-        vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, ws = ctx.saved_tensors
+        vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn = ctx.saved_tensors
+        ws = ctx.ws_holder.buf
         dr, dev = ctx.dr, azimuths.device
         B = azimuths.shape[0]
         H, W = dr.render_height, dr.image_size
@@ -167,6 +190,7 @@ class DiffRender(object):
         self.render_height = round(self.ratio * self.image_size)                                  # :298
         self._vc_offsets, self._vc_items = template.vertex_corner_adjacency(self.num_vertices, self.faces)
         self._static_cache = {}
+        self._ws_pool = {}                                       # (device, bytes) -> free render workspaces (see _PooledWorkspace)
         # dibr_rasterization defaults (kaolin v0.12.0): sigmainv=7000, boxlen=0.02, knum=30, multiplier=1000, eps=1e-8
         self.sigmainv, self.boxlen, self.knum, self.multiplier, self.eps = 7000.0, 0.02, 30, 1000.0, 1e-8
         if verbose:

@@ -235,7 +235,13 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream(device):
+    """The current HIP stream of ``device`` as a void* (the raw-handle query when torch offers it: the Stream object costs microseconds)."""
+    if _raw_stream is not None and device.index is not None:
+        return ctypes.c_void_p(_raw_stream(device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -27,7 +27,7 @@ MM_PP_STORAGE(pixel_bwd)        // 0 loss totals + g4, 1 shading recompute + sto
 namespace mm {
 
 struct BwdArgs {
-    int B, H, W, F, Ht, Wt, knum, blocks_x, blocks_per_image;
+    int B, H, W, F, Ht, Wt, knum, blocks_x, blocks_per_image, options;
     float mult, eps, sigmainv, infl;
     const float4* geo;
     const float* face_uvs;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     const bool any_covered = __ballot(in_img && hf >= 0) != 0;   // wave-uniform
     if (!any_covered) {
         if (kNoMask && in_img) {
-            const float* L = a.lights + b * 9;
+            const float* L = a.lights + b * 9;                   // (bands 0 and 6 only: the same lights whatever the band order)
             const float coef = MM_SH_C0 * L[0] + (0.f - MM_SH_C6B) * L[6];
             float dc = 0.f;
 #pragma unroll
@@ -136,9 +136,8 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
         if (hf >= 0) {
             const float4* geo = a.geo + ((size_t)b * a.F + hf) * 3;
             p0 = geo[0]; p1 = geo[1];
-            edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
-            const float inrm = 1.f / nrm;
-            w0 *= inrm; w1 *= inrm; w2 *= inrm;
+            // (MM_OPT_BARY_ONE_MINUS changes the weights by O(eps); the derivative below stays that of the default form)
+            bary_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, (a.options & MM_OPT_BARY_ONE_MINUS) != 0, w0, w1, w2, nrm);
             const float* fuv = a.face_uvs + (size_t)hf * 6;
 #pragma unroll
             for (int i = 0; i < 6; ++i) fu[i] = fuv[i];
@@ -156,7 +155,10 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
         const bool isw = s.x0 < a.Wt && s.y1 < a.Ht, ise = s.x1 < a.Wt && s.y1 < a.Ht;
         float bnd[9];
         sh_bands(nx, ny, nz, bnd);
-        const float* L = a.lights + b * 9;
+        float L[9];                                              // lights in sh_bands' order (see shade_store)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) L[i] = a.lights[b * 9 + i];
+        if (a.options & MM_OPT_SH_ORDER_XYZ) { const float tmp = L[2]; L[2] = L[3]; L[3] = tmp; }
         float coef = 0.f;
 #pragma unroll
         for (int i = 0; i < 9; ++i) coef += bnd[i] * L[i];
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     } else { dl[0] = wave_sum(dl[0]); dl[6] = wave_sum(dl[6]); }     // the other seven are zero
     m2 = wave_max(m2); m4 = wave_max(m4);
     if (lane == 0) {
+        if (a.options & MM_OPT_SH_ORDER_XYZ) { const float tmp = dl[2]; dl[2] = dl[3]; dl[3] = tmp; }   // back to the user's light order
 #pragma unroll
         for (int i = 0; i < 9; ++i) s_dl[wave][i] = dl[i];
         s_gm[wave][0] = m2; s_gm[wave][1] = m4;
@@ -323,7 +326,7 @@ __device__ inline SegHit seg_nearest(f2 p, f2 u, f2 v) {
     return h;
 }
 
-struct FaceBox { float4 p0, p1; float xmin, ymin, xmax, ymax; int px0, py0, bw, npx; float inv_bw; };
+struct FaceBox { float4 p0, p1; float xmin, ymin, xmax, ymax; int px0, py0, bw, npx; float inv_bw, nz; };
 
 __device__ inline FaceBox face_box(const BwdArgs& a, size_t o) {
     FaceBox fb;
@@ -336,6 +339,7 @@ __device__ inline FaceBox face_box(const BwdArgs& a, size_t o) {
     fb.bw = (int)(ext & 0xFFFFu);
     fb.npx = fb.bw * (int)(ext >> 16);
     fb.inv_bw = 1.f / (float)(fb.bw > 0 ? fb.bw : 1);
+    fb.nz = g2.y;
     return fb;
 }
 
@@ -500,7 +504,7 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
     if (sl == 0) {
         FaceSlot& fs = st->slot[grp];
         fs.p0 = fb.p0; fs.p1 = fb.p1; fs.box[0] = fb.xmin; fs.box[1] = fb.ymin; fs.box[2] = fb.xmax; fs.box[3] = fb.ymax;
-        fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.f = f; fs.lo = lo;
+        fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.lo = lo; fs.f = f;
     }
     for (int k = sl; k < 9; k += MM_FL) st->slot[grp].acc[k] = 0ll;
     int nmax = hi - lo;
@@ -550,8 +554,10 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
             }
             const float ga = q2;                                 // uncovered pixels: the pixel pass left dL/dalpha here
             const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
-            if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= lf &&
-                !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl)) {
+            const bool inbox = (a.options & MM_OPT_BBOX_HALF_OPEN)
+                ? !(x0 <= fs.box[0] - a.infl || x0 >= fs.box[2] + a.infl || y0 <= fs.box[1] - a.infl || y0 >= fs.box[3] + a.infl)
+                : !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl);
+            if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= lf && inbox) {
                 const float4 p0 = fs.p0, p1 = fs.p1;
                 const f2 pp = {x0, y0}, ca = {p0.x, p0.y}, cb = {p0.z, p0.w}, cc = {p1.x, p1.y};
                 SegHit h = seg_nearest(pp, ca, cb);               // edge 0: corner a -> b
@@ -597,7 +603,9 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     const size_t o = (size_t)b * a.F + e.x;
     const FaceBox fb = face_box(a, o);
     const int lo = e.y * ni.y;
-    const int hi = live ? min(fb.npx, lo + ni.y) : lo;
+    // MM_OPT_SOFT_SKIP_CULLED: a culled face owns no pixel and took no part in the soft mask -> nothing to sweep
+    const bool front = (a.options & MM_OPT_CULL_STRICT) ? fb.nz > 0.f : fb.nz >= 0.f;
+    const int hi = live && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED)) ? min(fb.npx, lo + ni.y) : lo;
     MM_PP_BEGIN();
     float inv;
     const float scale = face_sum_scale(a, b, inv);
@@ -639,7 +647,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     BwdArgs a;
     a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.Ht = d->Ht; a.Wt = d->Wt; a.knum = d->knum;
     a.blocks_x = (d->W + MM_BLOCK_PX - 1) / MM_BLOCK_PX;
-    a.blocks_per_image = w.blocks_per_image;
+    a.blocks_per_image = w.blocks_per_image; a.options = d->options;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.geo = w.geo; a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.face_idx = d->face_idx; a.soft = w.soft; a.grad_rgba = g->grad_rgba;

@@ -52,6 +52,8 @@ struct TexSpill { TexRecord r; int tile; int pad; };
 // ---- workspace carving (all offsets multiples of 256 bytes) ---------------------------------------------------------
 struct Workspace {
     float* T;              // (B,12)     camera transform [R;t], row-major (4,3)
+    float* cam;            // (B,48)     the forward's whole Camera record (36 floats used): the backward's camera chain starts from it
+                           //            instead of redoing the fp64 trigonometry and the look-at on its critical path
     float4* geo;           // (B,F,3)    {ax,ay,bx,by} {cx,cy,az,bz} {cz, unit normal z, box origin, box extent}; xy in multiplier
                            //            units; box = inflated pixel box px0 | py0 << 16, w | h << 16 (as int bits)
     uint64_t* binmask;     // (B,nbins,ceil(F/64)) bit f: the pixel box of face f, inflated by the soft-mask margin, touches the bin
@@ -98,6 +100,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.words = (F + 63) / 64;
     w.binmask_bytes = (size_t)B * w.nbx * w.nby * w.words * sizeof(uint64_t);
     w.T = (float*)(p + o);          o += align256((size_t)B * 12 * sizeof(float));
+    w.cam = (float*)(p + o);        o += align256((size_t)B * 48 * sizeof(float));
     w.geo = (float4*)(p + o);       o += align256((size_t)B * F * 3 * sizeof(float4));
     w.binmask = (uint64_t*)(p + o); o += align256(w.binmask_bytes);
     w.soft = (float2*)(p + o);      o += align256((size_t)B * H * W * sizeof(float2));
@@ -129,6 +132,7 @@ struct Camera {
     float cam[3], zv[3], zl, z[3], xv[3], xl, x[3], y[3];
     float T[12];
 };
+static_assert(sizeof(Camera) == 36 * sizeof(float), "stored as 36 floats per image (Workspace::cam)");
 
 __device__ inline void cross3(const float* a, const float* b, float* c) {
     c[0] = a[1] * b[2] - a[2] * b[1];
@@ -218,6 +222,22 @@ __device__ inline void edge_weights(float ax, float ay, float bx, float by, floa
     w2 = aex * bey - aey * bex;
     nrm = (w0 + w1) + w2;
     nrm += copysignf(eps, nrm);
+}
+
+// normalised barycentrics.  Default: kaolin's three edge functions over their copysign(eps)-padded sum (edge_weights above + IEEE
+// divisions: the expressions the oracle evaluates).  MM_OPT_BARY_ONE_MINUS: w1, w2 over (sum + eps), w0 = 1 - w1 - w2.
+__device__ inline void bary_weights(float ax, float ay, float bx, float by, float cx, float cy, float x0, float y0, float eps, bool one_minus,
+                                    float& w0, float& w1, float& w2, float& nrm) {
+    if (!one_minus) {
+        edge_weights(ax, ay, bx, by, cx, cy, x0, y0, eps, w0, w1, w2, nrm);
+        w0 /= nrm; w1 /= nrm; w2 /= nrm;
+        return;
+    }
+    float aex = ax - x0, aey = ay - y0, bex = bx - x0, bey = by - y0, cex = cx - x0, cey = cy - y0;
+    const float k0 = bex * cey - bey * cex, k1 = cex * aey - cey * aex, k2 = aex * bey - aey * bex;
+    nrm = (k0 + k1) + k2;
+    nrm += eps;
+    w1 = k1 / nrm; w2 = k2 / nrm; w0 = (1.f - w1) - w2;
 }
 
 // ---- bilinear texture fetch = grid_sample(align_corners=False, padding_mode='border') -------------

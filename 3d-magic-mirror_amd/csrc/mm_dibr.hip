@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) void raster_dibr_kernel(RasterAr
 // backward
 // ---------------------------------------------------------------------------------------------------------------------
 struct DibrBwdArgs {
-    int B, H, W, F, D;
+    int B, H, W, F, D, options;
     float mult, eps, sigmainv, infl;
     const float4* geo; const int32_t* fidx; const float2* soft; const float* feats;
     const float* g_interp; const float* g_soft;
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
     const float4 p0 = a.geo[o * 3 + 0], p1 = a.geo[o * 3 + 1], g2 = a.geo[o * 3 + 2];
     const unsigned org = __float_as_uint(g2.z), ext = __float_as_uint(g2.w);
     const int px0 = (int)(org & 0xFFFFu), py0 = (int)(org >> 16), bw = (int)(ext & 0xFFFFu);
-    const int npx = live ? bw * (int)(ext >> 16) : 0;
+    const bool front = (a.options & MM_OPT_CULL_STRICT) ? g2.y > 0.f : g2.y >= 0.f;     // g2.y = face_normals_z
+    const int npx = live && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED)) ? bw * (int)(ext >> 16) : 0;
     const float xmin = fminf(fminf(p0.x, p0.z), p1.x), ymin = fminf(fminf(p0.y, p0.w), p1.y);
     const float xmax = fmaxf(fmaxf(p0.x, p0.z), p1.x), ymax = fmaxf(fmaxf(p0.y, p0.w), p1.y);
     const float s2 = a.mult * a.mult;
@@ -162,8 +163,7 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
         if (fi == f && a.g_interp) {
             // K2 (Appendix A.1)
             float w0, w1, w2, nrm;
-            edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
-            w0 /= nrm; w1 /= nrm; w2 /= nrm;
+            bary_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, (a.options & MM_OPT_BARY_ONE_MINUS) != 0, w0, w1, w2, nrm);
             const float* g = a.g_interp + pix * a.D;
             const float* ff = a.feats + o * 3 * a.D;
             float G0 = 0.f, G1 = 0.f, G2 = 0.f;
@@ -187,8 +187,10 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
             const float2 st = a.soft[pix];
             const float sq = st.x;
             const int lf = __float_as_int(st.y);
-            if (sq != 0.f && sq != 1.f && ga != 0.f && f <= lf &&
-                !(x0 < xmin - a.infl || x0 > xmax + a.infl || y0 < ymin - a.infl || y0 > ymax + a.infl)) {
+            const bool inbox = (a.options & MM_OPT_BBOX_HALF_OPEN)
+                ? !(x0 <= xmin - a.infl || x0 >= xmax + a.infl || y0 <= ymin - a.infl || y0 >= ymax + a.infl)
+                : !(x0 < xmin - a.infl || x0 > xmax + a.infl || y0 < ymin - a.infl || y0 > ymax + a.infl);
+            if (sq != 0.f && sq != 1.f && ga != 0.f && f <= lf && inbox) {
                 float qx, qy, d2, qx1, qy1, d21;
                 float t = seg_nearest_t(x0, y0, p0.x, p0.y, p0.z, p0.w, qx, qy, d2);        // edge 0: a -> b
                 int e = 0;
@@ -273,7 +275,7 @@ int mm_dibr_rasterization_backward(const MMDibrDesc* d, const MMDibrGrads* g, mm
     if (!g || !g->grad_face_vertices_image) return MM_ERR_NULL_POINTER;
     const DibrWorkspace w = carve_dibr(d->workspace, d->B, d->F, d->H, d->W);
     DibrBwdArgs a;
-    a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.D = d->D;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.D = d->D; a.options = d->options;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.geo = w.geo; a.fidx = w.fidx; a.soft = w.soft; a.feats = d->face_features;
     a.g_interp = g->grad_interpolated_features; a.g_soft = g->grad_soft_mask;

@@ -67,13 +67,16 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
     __shared__ int s_key[1024];
     __shared__ int s_start[1024];          // histogram, then the first output position of every key
     __shared__ int s_wave[4];
-    const int b = blockIdx.x, tid = threadIdx.x, nslot = 4 * a.blocks_per_image;
+    // two workgroups per image, side by side: the even one sorts the tiles, the odd one lists the backward's sweep items
+    const int b = blockIdx.x >> 1, tid = threadIdx.x, nslot = 4 * a.blocks_per_image;
+    const bool do_items = (blockIdx.x & 1) != 0;
     // (b) sweep items of the backward: every face's inflated pixel box cut into chunks of MM_CHUNK_PX pixels, numbered in face
     //     order by an exclusive scan of the chunk counts.  Thread t owns the contiguous faces [t*per, (t+1)*per): it adds up
     //     their counts (independent loads), ONE block scan gives its first item, and it numbers its faces' chunks from there.
     //     Should the items run out (more than sixteen screens' worth of box pixels in one image), the image's chunk size doubles
     //     until they fit (item_cap >= F, so it ends).
-    if (a.chunkmap) {
+    if (do_items) {
+        if (!a.chunkmap) return;
         const int per = (a.F + 255) / 256, f0 = min(a.F, tid * per), f1 = min(a.F, f0 + per);
         auto box_px = [&](int f) {
             const unsigned ext = __float_as_uint(a.geo[((size_t)b * a.F + f) * 3 + 2].w);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
             first += nch;
         }
         if (tid == 0) a.nitems[b] = make_int2(total, chunk);
-        __syncthreads();
+        return;
     }
     if (!order) return;
     for (int i = tid; i < 1024; i += 256) s_start[i] = 0;
@@ -167,7 +170,7 @@ const unsigned short* launch_order(const RasterArgs& a_in, unsigned short* order
     RasterArgs a = a_in;
     a.order = nullptr;
     ProfScope po(prof_events, MM_PROF_ORDER, s);
-    hipLaunchKernelGGL(order_kernel, dim3(B), dim3(256), 0, s, a, sort ? order : nullptr, nheavy);
+    hipLaunchKernelGGL(order_kernel, dim3(2 * B), dim3(256), 0, s, a, sort ? order : nullptr, nheavy);
     return sort ? order : nullptr;
 }
 

@@ -80,12 +80,20 @@ __device__ inline void wave_lds_sync() {
 
 // box-vs-tile for ONE candidate (this lane's): bit (r*8+c) set iff pixel (row r, column c) of the tile passes the
 // separable closed-box test  !(x < lo || x > hi)  -- the same comparisons on the same floats as the per-pixel test.
-__device__ inline uint64_t box_pixels(const TileCtx& t, float xlo, float ylo, float xhi, float yhi) {
+__device__ inline uint64_t box_pixels(const TileCtx& t, float xlo, float ylo, float xhi, float yhi, bool half_open) {
     unsigned col = 0, row = 0;
+    if (half_open) {                                             // MM_OPT_BBOX_HALF_OPEN: a centre exactly on the box edge is outside
 #pragma unroll
-    for (int i = 0; i < MM_TILE; ++i) {
-        col |= (unsigned)(!(t.xs[i] < xlo || t.xs[i] > xhi)) << i;
-        row |= (unsigned)(!(t.ys[i] < ylo || t.ys[i] > yhi)) << i;
+        for (int i = 0; i < MM_TILE; ++i) {
+            col |= (unsigned)(!(t.xs[i] <= xlo || t.xs[i] >= xhi)) << i;
+            row |= (unsigned)(!(t.ys[i] <= ylo || t.ys[i] >= yhi)) << i;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MM_TILE; ++i) {
+            col |= (unsigned)(!(t.xs[i] < xlo || t.xs[i] > xhi)) << i;
+            row |= (unsigned)(!(t.ys[i] < ylo || t.ys[i] > yhi)) << i;
+        }
     }
     unsigned lo = 0, hi = 0;
 #pragma unroll
@@ -150,8 +158,7 @@ __device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* s
     const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
     const float4 p0 = st->p0[j], p1 = st->p1[j], p2 = st->p2[j];
     float w0, w1, w2, nrm;
-    edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, w0, w1, w2, nrm);
-    w0 /= nrm; w1 /= nrm; w2 /= nrm;
+    bary_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, (a.options & MM_OPT_BARY_ONE_MINUS) != 0, w0, w1, w2, nrm);
     const float z0 = (w0 * p1.z + w1 * p1.w) + w2 * p2.x;
     if (live && !(w0 < 0.f || w1 < 0.f || w2 < 0.f) && z0 > -INFINITY)
         atomicMax(&acc->key[l], depth_key(z0, __float_as_int(p2.z)));
@@ -230,7 +237,10 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
     }
     float nx = 0.f, ny = 0.f, nz = 0.f;
     float out[4];
-    const float* L = a.lights + t.b * 9;
+    float L[9];                                                  // lights in the order of sh_bands (x, z, y): MM_OPT_SH_ORDER_XYZ pairs
+#pragma unroll                                                   // the user's lights 2 / 3 with the y / z bands instead
+    for (int i = 0; i < 9; ++i) L[i] = a.lights[t.b * 9 + i];
+    if (a.options & MM_OPT_SH_ORDER_XYZ) { const float tmp = L[2]; L[2] = L[3]; L[3] = tmp; }
     if (__ballot(h.f >= 0) == 0) {
         // No lane of the tile is covered (more than half of all tiles).  The general path below then computes, per lane,
         //   m = 0, n = 0  ->  coef = C0*L0 + (0 - C6B)*L6   (the other seven bands are products with 0)

@@ -87,8 +87,12 @@ __device__ inline void stage_candidate(const RasterArgs& a, const TileCtx& t, Wa
     st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), __int_as_float(f));   // cz, nz, rank, face id
     const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
     const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
-    if (g2.y >= 0.f) mh = box_pixels(t, xmin - 0.f, ymin - 0.f, xmax + 0.f, ymax + 0.f);
-    if (soft) ms = box_pixels(t, xmin - a.infl, ymin - a.infl, xmax + a.infl, ymax + a.infl);
+    // kaolin rasterises the faces with face_normals_z >= 0 (MM_OPT_CULL_STRICT: > 0); its soft mask looks at ALL faces
+    // (MM_OPT_SOFT_SKIP_CULLED: only at those)  -- SURVEY Appendix C-1
+    const bool front = (a.options & MM_OPT_CULL_STRICT) ? g2.y > 0.f : g2.y >= 0.f;
+    const bool half_open = (a.options & MM_OPT_BBOX_HALF_OPEN) != 0;
+    if (front) mh = box_pixels(t, xmin - 0.f, ymin - 0.f, xmax + 0.f, ymax + 0.f, half_open);
+    if (soft && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED))) ms = box_pixels(t, xmin - a.infl, ymin - a.infl, xmax + a.infl, ymax + a.infl, half_open);
 }
 
 // Walk the bin's candidates in face order, 64 at a time.  For every batch the candidates are staged in st->p0/p1/p2[0..n)
@@ -141,8 +145,7 @@ __device__ inline void winner(const RasterArgs& a, const TileCtx& t, unsigned lo
         const float4* geo = a.geo + ((size_t)t.b * a.F + h.f) * 3;
         const float4 p0 = geo[0], p1 = geo[1];
         float nrm;
-        edge_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, t.x0, t.y0, a.eps, h.w0, h.w1, h.w2, nrm);
-        h.w0 /= nrm; h.w1 /= nrm; h.w2 /= nrm;
+        bary_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, t.x0, t.y0, a.eps, (a.options & MM_OPT_BARY_ONE_MINUS) != 0, h.w0, h.w1, h.w2, nrm);
     }
 }
 

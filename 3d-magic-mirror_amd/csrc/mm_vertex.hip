@@ -9,6 +9,9 @@
 //   gradients are gathered in a fixed order (no atomics), reduces dT in LDS and finishes with the camera chain.
 #include "mm_device.h"
 
+MM_PP_STORAGE(vertex_fwd)       // 0 counters cleared, 1 camera (fp64 trig + look-at), 2 face records, 3 binning
+MM_PP_STORAGE(vertex_bwd)       // 0 loads of T + vertex, 1 corner gather, 2 group / wave reductions + partial store, 3 ticket, 4 last workgroup: lights, 5 camera chain
+
 namespace mm {
 
 struct VertexFwdArgs {
@@ -18,6 +21,7 @@ struct VertexFwdArgs {
     const float* vertices;
     const float *azim, *elev, *dist, *bias;
     float* T;
+    float* cam;
     float4* geo;
     float* face_normals;
     int* tcnt; int ntcnt;    // texture-record counters of the backward: cleared here for the first backward after this forward
@@ -43,10 +47,14 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     __shared__ float s_trig[4];
     __shared__ Camera s_cam;
     const int b = blockIdx.y, tid = threadIdx.x;
+    MM_PP_BEGIN();
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nltot; i += gridDim.x * gridDim.y * 256) a.ltot[i] = 0;
+    MM_PP_MARK(0);
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
+    MM_PP_MARK(1);
     if (blockIdx.x == 0 && tid < 12) a.T[b * 12 + tid] = s_cam.T[tid];
+    if (blockIdx.x == 0 && tid >= 64 && tid < 100) a.cam[b * 48 + tid - 64] = reinterpret_cast<const float*>(&s_cam)[tid - 64];
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_cam.T[i];
@@ -83,9 +91,11 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     }
 
     // ---- screen binning: this wave's 64 faces are exactly mask word c (bin_wave_faces, mm_device.h) ---------------------------
+    MM_PP_MARK(2);
     const int c = blockIdx.x * 4 + (tid >> 6);
-    if (a.mask == nullptr || c >= a.words) return;
-    bin_wave_faces(a.mask, b, a.nbx, a.nby, a.words, a.bin_shift, c, tid & 63, bx0, by0, bw, bh);
+    if (a.mask != nullptr && c < a.words) bin_wave_faces(a.mask, b, a.nbx, a.nby, a.words, a.bin_shift, c, tid & 63, bx0, by0, bw, bh);
+    MM_PP_MARK(3);
+    MM_PP_FLUSH(vertex_fwd, (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6));
 }
 
 struct VertexBwdArgs {
@@ -97,6 +107,7 @@ struct VertexBwdArgs {
     const float* vertices;
     const float *azim, *elev, *dist, *bias;
     const float* T;         // (B,12) saved by the forward
+    const float* cam;       // (B,48) the forward's Camera record
     const int2* chunkmap;   // (B,F) {first sweep item, items} of every face
     const float* part;      // (B,item_cap,12) the items' partial sums: dL/d(face xy) (6), dL/d(unit normal) (3)
     int item_cap;
@@ -116,11 +127,11 @@ struct VertexBwdArgs {
 // workgroup of an image to arrive (agent-scope release / ticket / acquire, cdna_hip_programming.md G16) runs the
 // camera chain.
 __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
-    __shared__ float s_trig[4];
     __shared__ Camera s_cam;
     __shared__ float s_red[4][12];
     __shared__ int s_last;
     const int b = blockIdx.y, tid = threadIdx.x;
+    MM_PP_BEGIN();
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
     float T[12];
 #pragma unroll
@@ -141,6 +152,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         const float xi = (me.x * a.proj0) * ipz, yi = (me.y * a.proj1) * ipz;
         float d[3] = {0.f, 0.f, 0.f};
         const int beg = a.vc_offsets[v], end = a.vc_offsets[v + 1];
+        MM_PP_MARK(0);
         for (int it = beg + cl; it < end; it += 8) {
             const int item = a.vc_items[it];
             const int f = item / 3, k = item - f * 3;
@@ -185,6 +197,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
                 }
             }
         }
+        MM_PP_MARK(1);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             d[j] += __shfl_xor(d[j], 4, 8); d[j] += __shfl_xor(d[j], 2, 8); d[j] += __shfl_xor(d[j], 1, 8);
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
     // ---- publish, take a ticket; the last workgroup of this image finishes the camera chain
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the storing wave drains its stores before the ticket is drawn
     __syncthreads();
+    MM_PP_MARK(2);
     if (tid == 0) {
         // No agent-scope fences here: a release fence writes back the XCD's whole L2 and an acquire invalidates it, once per
         // workgroup (removing them took this kernel from 213 to 53 us at B=384).
@@ -226,7 +240,8 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         s_last = (prev == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (!s_last) return;
+    MM_PP_MARK(3);
+    if (!s_last) { MM_PP_FLUSH(vertex_bwd, (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6)); return; }
     {   // dL/dlights: sum of the pixel-backward workgroup partials; waves 1..3 take 3 components each, lanes stride over
         // the partials (independent loads), fixed butterfly order
         const int wv = tid >> 6, ln = tid & 63;
@@ -239,7 +254,8 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             }
         }
     }
-    block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
+    MM_PP_MARK(4);
+    if (tid >= 64 && tid < 100) reinterpret_cast<float*>(&s_cam)[tid - 64] = a.cam[b * 48 + tid - 64];   // the forward's camera (no trig here)
     if (tid < 12) {                                              // dL/dT = sum of the workgroups' partials, in index order
         float sum = 0.f;
         for (unsigned g = 0; g < gridDim.x; ++g)
@@ -255,6 +271,8 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         a.grad_dist[b] = dd; a.grad_elev[b] = de; a.grad_azim[b] = da;
         a.grad_bias[2 * b] = db[0]; a.grad_bias[2 * b + 1] = db[1];
     }
+    MM_PP_MARK(5);
+    MM_PP_FLUSH(vertex_bwd, (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6));
 }
 
 int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
@@ -263,7 +281,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2]; a.mult = d->multiplier; a.infl = d->boxlen * d->multiplier;
     a.faces = d->faces; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
-    a.T = w.T; a.geo = w.geo; a.face_normals = d->face_normals;
+    a.T = w.T; a.cam = w.cam; a.geo = w.geo; a.face_normals = d->face_normals;
     a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B + d->B * MM_GSHARD * 8;
     a.ltot = w.ltot; a.nltot = d->B * MM_LSUB * 4;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
@@ -280,7 +298,7 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2];
     a.faces = d->faces; a.vc_offsets = d->vc_offsets; a.vc_items = d->vc_items; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
-    a.T = w.T; a.chunkmap = w.chunkmap; a.part = w.part; a.item_cap = w.item_cap; a.gfn = g->grad_face_normals;
+    a.T = w.T; a.cam = w.cam; a.chunkmap = w.chunkmap; a.part = w.part; a.item_cap = w.item_cap; a.gfn = g->grad_face_normals;
     a.dTpart = w.dTpart; a.ticket = w.ticket;
     a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B + d->B * MM_GSHARD * 8;
     a.dl_part = w.dl_part; a.blocks_per_image = w.blocks_per_image; a.grad_lights = g->grad_lights;

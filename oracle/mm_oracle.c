@@ -9,6 +9,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Appendix-C switches (include/mm_render.h MM_OPT_*: the choices recalled from kaolin's sources that cannot be re-verified here),
+ * mirrored bit for bit by the HIP path.  Process-wide on purpose: this is test infrastructure, set before a call, never concurrently. */
+enum { MMO_OPT_CULL_STRICT = 1 << 4, MMO_OPT_SOFT_SKIP_CULLED = 1 << 5, MMO_OPT_BBOX_HALF_OPEN = 1 << 6, MMO_OPT_BARY_ONE_MINUS = 1 << 7,
+       MMO_OPT_SH_ORDER_XYZ = 1 << 8 };
+static int mmo_options = 0;
+static const uint8_t* mmo_soft_valid = NULL;   /* (B,F) faces the soft mask may use when MMO_OPT_SOFT_SKIP_CULLED is set (NULL: all) */
+void mmo_set_options(int bits) { mmo_options = bits; }
+int mmo_get_options(void) { return mmo_options; }
+void mmo_set_soft_valid(const uint8_t* v) { mmo_soft_valid = v; }
+
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 

@@ -33,6 +33,25 @@ def lib():
     return _LIB
 
 
+OPT_CULL_STRICT, OPT_SOFT_SKIP_CULLED, OPT_BBOX_HALF_OPEN, OPT_BARY_ONE_MINUS, OPT_SH_ORDER_XYZ = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
+
+
+class options(object):
+    """``with oracle.options(bits): ...`` -- the SURVEY Appendix C switches (include/mm_render.h MM_OPT_*), mirrored by the HIP path."""
+
+    def __init__(self, bits):
+        self.bits = int(bits)
+
+    def __enter__(self):
+        self.old = lib().mmo_get_options()
+        lib().mmo_set_options(self.bits)
+        return self
+
+    def __exit__(self, *exc):
+        lib().mmo_set_options(self.old)
+        return False
+
+
 def num_threads():
     return lib().mmo_num_threads()
 
@@ -122,8 +141,11 @@ def rasterize_backward(dinterp, face_idx, fvi, feats, mult=1000.0, eps=1e-8, dty
     return dfvi, dfeats
 
 
-def soft_mask(H, W, fvi, face_idx, sigmainv=7000.0, boxlen=0.02, knum=30, mult=1000.0, dtype=np.float32, aux=True):
+def soft_mask(H, W, fvi, face_idx, sigmainv=7000.0, boxlen=0.02, knum=30, mult=1000.0, dtype=np.float32, aux=True, valid=None):
+    """``valid`` (B,F) uint8: the faces the colour pass rasterises; only read under OPT_SOFT_SKIP_CULLED."""
     fvi = _c(fvi, dtype); face_idx = _c(face_idx, np.int32)
+    valid = None if valid is None else _c(valid, np.uint8)
+    lib().mmo_set_soft_valid(_p(valid))
     B, F = fvi.shape[:2]
     soft = np.zeros((B, H, W), dtype)
     prob = np.zeros((B, H, W, knum), dtype) if aux else None
@@ -131,6 +153,7 @@ def soft_mask(H, W, fvi, face_idx, sigmainv=7000.0, boxlen=0.02, knum=30, mult=1
     typ = np.zeros((B, H, W, knum), np.uint8) if aux else None
     r = _real(dtype)
     getattr(lib(), "mmo_soft_mask_" + _sfx(dtype))(B, H, W, F, _p(fvi), _p(face_idx), r(sigmainv), r(boxlen), knum, r(mult), _p(soft), _p(prob), _p(idx), _p(typ))
+    lib().mmo_set_soft_valid(None)
     return soft, prob, idx, typ
 
 

@@ -24,6 +24,8 @@ for _ in range(4): st.run()
 torch.cuda.synchronize()
 L = ctypes.CDLL(var)
 KERNELS = {
+    "vertex_fwd": (["clear counters", "camera (fp64 trig + look-at)", "face records", "binning"], ("-", "-")),
+    "vertex_bwd": (["T + vertex loads", "corner gather", "reductions + partial store", "ticket", "last WG: lights", "last WG: camera chain"], ("-", "-")),
     "gather_face": (["setup", "sweep: face_idx loads", "compaction", "item loads", "item math + LDS adds", "stores"], ("trips", "items")),
     "gather_tex": (["count + first record", "clear LDS", "records", "tile store"], ("records", "-")),
     "raster_fwd": (["tile setup", "mask -> id list", "geo fetch + stage + box tests + transposes", "colour pairs", "silhouette pairs", "winner + shade + store"], ("candidates", "batches")),

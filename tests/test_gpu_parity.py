@@ -152,6 +152,55 @@ def test_close_camera_huge_face_boxes_match_oracle(pkg, oracle, name, B, S, dist
         _close(datt[k].grad.cpu().numpy(), g_o[k])
 
 
+@pytest.mark.parametrize("bit", ["OPT_CULL_STRICT", "OPT_SOFT_SKIP_CULLED", "OPT_BBOX_HALF_OPEN", "OPT_BARY_ONE_MINUS", "OPT_SH_ORDER_XYZ", "ALL"])
+def test_appendix_c_switches_match_the_oracle(pkg, oracle, bit):
+    """the choices recalled from kaolin's sources (cull >= / >, soft mask over culled faces, closed / half-open
+    bbox, copysign(eps) / (1 - w1 - w2) barycentrics, SH band order) are switches of MMRenderDesc.options, mirrored bit for bit by
+    the oracle: whoever can run real kaolin pins the path by flipping a bit.  Every switch alone and all together:
+      (1) forward + backward at the full bar on the usual seeded input;
+      (2) forward (face_idx bit-exact, RGBA 1e-4) on an input built to make the switch BITE -- vertices snapped to a coarse grid and
+          an axis-aligned camera put pixel centres exactly on edges and box borders and give exactly edge-on faces (normal z == 0):
+          gradients are not compared there (1 / area of a zero-area face), the switches only touch the forward's decisions."""
+    N = pkg._native
+    names = ["OPT_CULL_STRICT", "OPT_SOFT_SKIP_CULLED", "OPT_BBOX_HALF_OPEN", "OPT_BARY_ONE_MINUS", "OPT_SH_ORDER_XYZ"]
+    bits = sum(getattr(N, n) for n in names) if bit == "ALL" else getattr(N, bit)
+    assert bits == (sum(getattr(oracle, n) for n in names) if bit == "ALL" else getattr(oracle, bit))
+    # (1)
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "sphere", 4, 64, seed=17)
+    with torch.no_grad():
+        base_rgbs, _ = dr.render(no_mask=True, **datt)
+    dr.options = bits
+    rgbs, out = dr.render(no_mask=True, **datt)
+    dr.recon_data(rgbs, gt.to(dev), no_mask=True).backward()
+    with oracle.options(bits):
+        rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, True, proj)
+        loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+        g_o = oracle.render_backward(inp, H, W, True, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None)
+    assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
+    _close(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
+    for k in LEAVES:
+        _close(datt[k].grad.cpu().numpy(), g_o[k])
+    if bit in ("OPT_SOFT_SKIP_CULLED", "OPT_SH_ORDER_XYZ", "ALL"):             # these change every silhouette pixel / every lit pixel
+        assert float((base_rgbs - rgbs.detach()).abs().max()) > 1e-3
+    # (2)
+    dr2, att2, datt2, gt2, inp2, proj2, H, W, dev = _setup(pkg, "sphere", 4, 64, seed=17)
+    with torch.no_grad():
+        datt2["vertices"].copy_(torch.round(datt2["vertices"] * 16) / 16)
+        datt2["azimuths"].fill_(0.0); datt2["elevations"].fill_(0.0); datt2["biases"].zero_(); datt2["distances"].fill_(2.5)
+        for k in ("vertices", "azimuths", "elevations", "biases", "distances"):
+            inp2[k] = datt2[k].detach().cpu().numpy().copy()
+        base2, _ = dr2.render(no_mask=True, **datt2)
+        base_idx = dr2.last_face_idx.clone()
+        dr2.options = bits
+        r2, _ = dr2.render(no_mask=True, **datt2)
+    with oracle.options(bits):
+        rgba2_o, fidx2_o, _, _ = oracle.render_forward(inp2, H, W, True, proj2)
+    got_idx = dr2.last_face_idx.cpu().numpy()
+    assert (got_idx == fidx2_o).all(), int((got_idx != fidx2_o).sum())
+    _close(r2.permute(0, 2, 3, 1).cpu().numpy(), rgba2_o)
+    assert (not torch.equal(base_idx, dr2.last_face_idx)) or float((base2 - r2).abs().max()) > 1e-6, bit   # the switch changed something
+
+
 def test_backward_twice_after_one_forward(pkg):
     """retain_graph: the backward leaves its scratch counters the way it found them (the library clears them in-kernel)."""
     dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 4, 96, seed=21)

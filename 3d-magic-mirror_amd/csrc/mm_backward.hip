@@ -56,8 +56,11 @@ struct BwdArgs {
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. pixel-major pass
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef MM_PIXEL_LB
+#define MM_PIXEL_LB 4
+#endif
 template <bool kNoMask>
-__global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) {
     MM_TIMELINE_BEGIN();
     __shared__ float s_dl[MM_BLOCK_WAVES][9];
     __shared__ float s_gm[MM_BLOCK_WAVES][2];
@@ -72,6 +75,15 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
     const size_t pix = (size_t)b * hw + pin;
     if (blk == 0 && threadIdx.x == 0) a.ticket[b] = 0u;           // arrival counter of the vertex backward, used after this kernel
 
+    // The pass is a chain of dependent trips to memory; it is written so that four remain: (1) everything addressed by the pixel
+    // alone -- face_idx, prediction, ground truth, background; (2) what the winner's id addresses -- geometry, normal, corner uvs;
+    // (3) the twelve texels, unconditionally from clamped addresses; (4) the record-slot atomics.  (Loads left inside per-lane
+    // branches or behind stores that might alias them each cost the wave a trip of their own.)
+    float bgv[3] = {0.f, 0.f, 0.f};
+    if (kNoMask && in_img) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bgv[c] = a.bg[((size_t)b * 3 + c) * hw + pin];
+    }
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int hf = -1;
     if (a.gt) {
@@ -120,10 +132,9 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             float dc = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float bgv = a.bg[((size_t)b * 3 + c) * hw + pin];
-                const float pre = bgv * coef;
+                const float pre = bgv[c] * coef;
                 const float g = (pre >= 0.f && pre <= 1.f) ? gin[c] : 0.f;      // torch.clamp backward mask
-                dc += g * bgv;
+                dc += g * bgv[c];
                 a.grad_bg[((size_t)b * 3 + c) * hw + pin] = g * coef;
             }
             dl[0] = dc * MM_SH_C0; dl[6] = dc * (0.f - MM_SH_C6B);
@@ -133,16 +144,23 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
         float w0 = 0.f, w1 = 0.f, w2 = 0.f, nrm = 1.f, m = 0.f, u = 0.f, v = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
         float fu[6] = {0, 0, 0, 0, 0, 0}, n0 = 0.f, n1 = 0.f, n2 = 0.f;
         float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+        {   // trip 2 (uncovered lanes of a covered tile read face 0's records and ignore them)
+            const int fs = max(hf, 0);
+            const float4* geo = a.geo + ((size_t)b * a.F + fs) * 3;
+            const float4 q0 = geo[0], q1 = geo[1];
+            const float2* fuv = (const float2*)(a.face_uvs + (size_t)fs * 6);
+            const float2 u0 = fuv[0], u1 = fuv[1], u2 = fuv[2];
+            const float* nn = a.fn + ((size_t)b * a.F + fs) * 3;
+            const float m0 = nn[0], m1 = nn[1], m2 = nn[2];
+            if (hf >= 0) {
+                p0 = q0; p1 = q1;
+                fu[0] = u0.x; fu[1] = u0.y; fu[2] = u1.x; fu[3] = u1.y; fu[4] = u2.x; fu[5] = u2.y;
+                n0 = m0; n1 = m1; n2 = m2;
+            }
+        }
         if (hf >= 0) {
-            const float4* geo = a.geo + ((size_t)b * a.F + hf) * 3;
-            p0 = geo[0]; p1 = geo[1];
             // (MM_OPT_BARY_ONE_MINUS changes the weights by O(eps); the derivative below stays that of the default form)
             bary_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, (a.options & MM_OPT_BARY_ONE_MINUS) != 0, w0, w1, w2, nrm);
-            const float* fuv = a.face_uvs + (size_t)hf * 6;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) fu[i] = fuv[i];
-            const float* nn = a.fn + ((size_t)b * a.F + hf) * 3;
-            n0 = nn[0]; n1 = nn[1]; n2 = nn[2];
             m = (w0 + w1) + w2;
             u = (w0 * fu[0] + w1 * fu[2]) + w2 * fu[4];
             v = (w0 * fu[1] + w1 * fu[3]) + w2 * fu[5];
@@ -153,6 +171,18 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
         const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
         const bool inw = s.x0 < a.Wt && s.y0 < a.Ht, ine = s.x1 < a.Wt && s.y0 < a.Ht;
         const bool isw = s.x0 < a.Wt && s.y1 < a.Ht, ise = s.x1 < a.Wt && s.y1 < a.Ht;
+        // trip 3: twelve loads in flight together
+        float tq[3][4];
+        {
+            const int cx0 = min(max(s.x0, 0), a.Wt - 1), cx1 = min(max(s.x1, 0), a.Wt - 1);
+            const int cy0 = min(max(s.y0, 0), a.Ht - 1), cy1 = min(max(s.y1, 0), a.Ht - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* tex = a.textures + ((size_t)b * 3 + c) * a.Ht * a.Wt;
+                tq[c][0] = tex[(size_t)cy0 * a.Wt + cx0]; tq[c][1] = tex[(size_t)cy0 * a.Wt + cx1];
+                tq[c][2] = tex[(size_t)cy1 * a.Wt + cx0]; tq[c][3] = tex[(size_t)cy1 * a.Wt + cx1];
+            }
+        }
         float bnd[9];
         sh_bands(nx, ny, nz, bnd);
         float L[9];                                              // lights in sh_bands' order (see shade_store)
@@ -167,9 +197,8 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
         const float ex = 1.f - s.tx, ey = 1.f - s.ty;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float* tex = a.textures + ((size_t)b * 3 + c) * a.Ht * a.Wt;
-            const float tnw = inw ? tex[(size_t)s.y0 * a.Wt + s.x0] : 0.f, tne = ine ? tex[(size_t)s.y0 * a.Wt + s.x1] : 0.f;
-            const float tsw = isw ? tex[(size_t)s.y1 * a.Wt + s.x0] : 0.f, tse = ise ? tex[(size_t)s.y1 * a.Wt + s.x1] : 0.f;
+            const float tnw = inw ? tq[c][0] : 0.f, tne = ine ? tq[c][1] : 0.f;
+            const float tsw = isw ? tq[c][2] : 0.f, tse = ise ? tq[c][3] : 0.f;
             float tc = 0.f;
             if (inw) tc += tnw * s.wnw;
             if (ine) tc += tne * s.wne;
@@ -177,15 +206,15 @@ __global__ __launch_bounds__(256) void pixel_bwd_kernel(BwdArgs a) {
             if (ise) tc += tse * s.wse;
             float pre, dtc;
             if (kNoMask) {
-                const float bgv = a.bg[((size_t)b * 3 + c) * hw + pin];
-                const float base = tc * m + bgv * (1.f - m);
+                const float bgvc = bgv[c];
+                const float base = tc * m + bgvc * (1.f - m);
                 pre = base * coef;
                 const float g = (pre >= 0.f && pre <= 1.f) ? gin[c] : 0.f;      // torch.clamp backward mask
                 dc += g * base;
                 const float dbase = g * coef;
                 dtc = dbase * m;
                 a.grad_bg[((size_t)b * 3 + c) * hw + pin] = dbase * (1.f - m);
-                dm += dbase * (tc - bgv);
+                dm += dbase * (tc - bgvc);
             } else {
                 pre = (tc * m) * coef + 1.f * (1.f - m);
                 const float g = (pre >= 0.f && pre <= 1.f) ? gin[c] : 0.f;
@@ -493,6 +522,48 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s
     MM_PP_FLUSH(gather_tex, (long long)block * 4 + (threadIdx.x >> 6));
 }
 
+struct ItemLoad { float4 q0, q1; float q2, sq; int lf, px, py, g; bool owned, live; };
+
+// one compacted hit of the sweep, its loads done: owned pixel -> add the pixel pass's nine K2 numbers; open pixel -> K4 (Appendix A.2)
+__device__ inline void item_finish(const BwdArgs& a, FaceSlot& fs, const ItemLoad& ld, float s2, float scale) {
+    if (ld.owned) {
+        const float4 q0 = ld.q0, q1 = ld.q1;
+        fixed_add(&fs.acc[0], q0.x, scale); fixed_add(&fs.acc[1], q0.y, scale); fixed_add(&fs.acc[2], q0.z, scale);
+        fixed_add(&fs.acc[3], q0.w, scale); fixed_add(&fs.acc[4], q1.x, scale); fixed_add(&fs.acc[5], q1.y, scale);
+        fixed_add(&fs.acc[6], q1.z, scale); fixed_add(&fs.acc[7], q1.w, scale); fixed_add(&fs.acc[8], ld.q2, scale);
+        return;
+    }
+    const float ga = ld.q2, sq = ld.sq;                           // uncovered pixels: the pixel pass left dL/dalpha here
+    const float x0 = pixel_x(ld.px, a.W, a.mult), y0 = pixel_y(ld.py, a.H, a.mult);
+    const bool inbox = (a.options & MM_OPT_BBOX_HALF_OPEN)
+        ? !(x0 <= fs.box[0] - a.infl || x0 >= fs.box[2] + a.infl || y0 <= fs.box[1] - a.infl || y0 >= fs.box[3] + a.infl)
+        : !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl);
+    if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= ld.lf && inbox) {
+        const float4 p0 = fs.p0, p1 = fs.p1;
+        const f2 pp = {x0, y0}, ca = {p0.x, p0.y}, cb = {p0.z, p0.w}, cc = {p1.x, p1.y};
+        SegHit h = seg_nearest(pp, ca, cb);               // edge 0: corner a -> b
+        int e = 0;
+        const SegHit h1 = seg_nearest(pp, cb, cc);        // edge 1: b -> c
+        if (h1.d2 < h.d2) { h = h1; e = 1; }
+        const SegHit h2 = seg_nearest(pp, cc, ca);        // edge 2: c -> a
+        if (h2.d2 < h.d2) { h = h2; e = 2; }
+        const float p = __builtin_amdgcn_exp2f(-(h.d2 * (a.sigmainv / s2)) * 1.4426950408889634f);
+        const float q = 1.f - p;
+        const float qnz = fabsf(sq);
+        const bool onezero = sq < 0.f;
+        const float excl = (q != 0.f) ? (onezero ? 0.f : qnz * __builtin_amdgcn_rcpf(q)) : (onezero ? qnz : 0.f);
+        const float gd = ga * excl * (-(p * a.sigmainv) / s2) * a.mult;
+        if (gd != 0.f) {
+            // edge e runs from corner e to corner (e+1)%3
+            const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;
+            const float cu = -2.f * (1.f - h.t) * gd, cv = -2.f * h.t * gd;
+            const f2 gu = cu * h.q, gv = cv * h.q;
+            fixed_add(&fs.acc[iu], gu.x, scale); fixed_add(&fs.acc[iu + 1], gu.y, scale);
+            fixed_add(&fs.acc[iv], gv.x, scale); fixed_add(&fs.acc[iv + 1], gv.y, scale);
+        }
+    }
+}
+
 // 2b. per-face gradients: MM_FL lanes per (image, face) sweep the face's inflated box; pixels it owns give the K2 barycentric
 //     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The hits of a trip are
 //     ballot-compacted over the whole wave and finished by all 64 lanes (one round of loads per trip) into the per-face
@@ -530,56 +601,35 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
         wave_sync_lds();
         MM_PP_MARK(2);
         MM_PP_COUNT(1, n);
-        for (int j = lane; j < n; j += 64) {
-            const unsigned it = st->items[j];
-            const int l = it & 63, i = (it >> 6) & 0x1FF, g = l / MM_FL;
-            FaceSlot& fs = st->slot[g];
-            int px, py;
-            box_pixel(fs.lo + base + i * MM_FL + (l % MM_FL), fs.px0, fs.py0, fs.bw, fs.inv_bw, px, py);
-            const size_t pix = (size_t)b * hw + (size_t)py * a.W + px;   // every group of the wave sweeps the same image
-            // the sweep already knows which kind of hit this is: only the three loads that kind needs are issued
-            const bool owned = (it & 0x8000u) != 0;
-            const float q2 = a.gp2[pix];
-            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-            float sq = 0.f;
-            int lf = 0;
-            if (owned) { q0 = a.gp[pix * 2 + 0]; q1 = a.gp[pix * 2 + 1]; }
-            else { const float2 sl2 = a.soft[pix]; sq = sl2.x; lf = __float_as_int(sl2.y); }
-            MM_PP_MARK(3);
-            if (owned) {
-                fixed_add(&fs.acc[0], q0.x, scale); fixed_add(&fs.acc[1], q0.y, scale); fixed_add(&fs.acc[2], q0.z, scale);
-                fixed_add(&fs.acc[3], q0.w, scale); fixed_add(&fs.acc[4], q1.x, scale); fixed_add(&fs.acc[5], q1.y, scale);
-                fixed_add(&fs.acc[6], q1.z, scale); fixed_add(&fs.acc[7], q1.w, scale); fixed_add(&fs.acc[8], q2, scale);
-                continue;
-            }
-            const float ga = q2;                                 // uncovered pixels: the pixel pass left dL/dalpha here
-            const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
-            const bool inbox = (a.options & MM_OPT_BBOX_HALF_OPEN)
-                ? !(x0 <= fs.box[0] - a.infl || x0 >= fs.box[2] + a.infl || y0 <= fs.box[1] - a.infl || y0 >= fs.box[3] + a.infl)
-                : !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl);
-            if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= lf && inbox) {
-                const float4 p0 = fs.p0, p1 = fs.p1;
-                const f2 pp = {x0, y0}, ca = {p0.x, p0.y}, cb = {p0.z, p0.w}, cc = {p1.x, p1.y};
-                SegHit h = seg_nearest(pp, ca, cb);               // edge 0: corner a -> b
-                int e = 0;
-                const SegHit h1 = seg_nearest(pp, cb, cc);        // edge 1: b -> c
-                if (h1.d2 < h.d2) { h = h1; e = 1; }
-                const SegHit h2 = seg_nearest(pp, cc, ca);        // edge 2: c -> a
-                if (h2.d2 < h.d2) { h = h2; e = 2; }
-                const float p = __builtin_amdgcn_exp2f(-(h.d2 * (a.sigmainv / s2)) * 1.4426950408889634f);
-                const float q = 1.f - p;
-                const float qnz = fabsf(sq);
-                const bool onezero = sq < 0.f;
-                const float excl = (q != 0.f) ? (onezero ? 0.f : qnz * __builtin_amdgcn_rcpf(q)) : (onezero ? qnz : 0.f);
-                const float gd = ga * excl * (-(p * a.sigmainv) / s2) * a.mult;
-                if (gd != 0.f) {
-                    // edge e runs from corner e to corner (e+1)%3
-                    const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;
-                    const float cu = -2.f * (1.f - h.t) * gd, cv = -2.f * h.t * gd;
-                    const f2 gu = cu * h.q, gv = cv * h.q;
-                    fixed_add(&fs.acc[iu], gu.x, scale); fixed_add(&fs.acc[iu + 1], gu.y, scale);
-                    fixed_add(&fs.acc[iv], gv.x, scale); fixed_add(&fs.acc[iv + 1], gv.y, scale);
+        // two items per lane and trip where the list is long: their loads are in flight together (each round is a dependent trip to
+        // memory; the heaviest waves have nine rounds)
+        for (int j0 = 0; j0 < n; j0 += 128) {
+            ItemLoad ld[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + u * 64 + lane;
+                ld[u].live = j < n;
+                if (u == 1 && j0 + 64 >= n) break;               // wave-uniform: a short list has no second half
+                const unsigned it = st->items[ld[u].live ? j : 0];
+                const int l = it & 63, i = (it >> 6) & 0x1FF;
+                ld[u].g = l / MM_FL;
+                const FaceSlot& fs = st->slot[ld[u].g];
+                box_pixel(fs.lo + base + i * MM_FL + (l % MM_FL), fs.px0, fs.py0, fs.bw, fs.inv_bw, ld[u].px, ld[u].py);
+                const size_t pix = (size_t)b * hw + (size_t)ld[u].py * a.W + ld[u].px;   // every group of the wave sweeps the same image
+                // the sweep already knows which kind of hit this is: only the three loads that kind needs are issued
+                ld[u].owned = (it & 0x8000u) != 0;
+                ld[u].q0 = make_float4(0.f, 0.f, 0.f, 0.f); ld[u].q1 = ld[u].q0; ld[u].sq = 0.f; ld[u].lf = 0; ld[u].q2 = 0.f;
+                if (ld[u].live) {
+                    ld[u].q2 = a.gp2[pix];
+                    if (ld[u].owned) { ld[u].q0 = a.gp[pix * 2 + 0]; ld[u].q1 = a.gp[pix * 2 + 1]; }
+                    else { const float2 sl2 = a.soft[pix]; ld[u].sq = sl2.x; ld[u].lf = __float_as_int(sl2.y); }
                 }
+            }
+            MM_PP_MARK(3);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && j0 + 64 >= n) break;
+                if (ld[u].live) item_finish(a, st->slot[ld[u].g], ld[u], s2, scale);
             }
         }
         wave_sync_lds();

@@ -77,16 +77,18 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) void raster_dibr_kernel(RasterAr
     const int wv = kBlock ? threadIdx.x >> 6 : 0;
     bool valid, coop;
     const TileCtx t = make_tile<kBlock>(a, wv, valid, coop);
+    unsigned long long key;
     Hit h;
     SoftState ss;
     MM_PP_BEGIN();
     if (kBlock && coop) {
-        tile_walk_coop(a, t, s_stage, wv, h, ss);
+        tile_walk_coop(a, t, s_stage, wv, key, ss MM_PP_PASS);
         if (wv != 0) return;
     } else {
         if (!valid) return;
-        tile_walk(a, t, &s_stage[wv], h, ss MM_PP_PASS);
+        tile_walk(a, t, &s_stage[wv], key, ss MM_PP_PASS);
     }
+    winner(a, t, key, h);
     if (!t.in_img) return;
     const size_t pix = ((size_t)t.b * a.H + t.py) * a.W + t.px;
     a.face_idx[pix] = h.f;

@@ -38,22 +38,17 @@ __global__ __launch_bounds__(kBlock ? 256 : 64, kBlock ? 5 : 1) void raster_fwd_
     const int wv = kBlock ? threadIdx.x >> 6 : 0;
     bool valid, coop;
     const TileCtx t = make_tile<kBlock>(a, wv, valid, coop);     // coop is workgroup-uniform; !valid only in the last light workgroup of an image
-    Hit h;
+    unsigned long long key;
     SoftState ss;
     MM_PP_MARK(0);
     if (kBlock && coop) {
-        tile_walk_coop(a, t, s_stage, wv, h, ss);
+        tile_walk_coop(a, t, s_stage, wv, key, ss MM_PP_PASS);
         if (wv != 0) return;                                     // the tile's pixels are shaded once
     } else {
         if (!valid) return;
-        tile_walk(a, t, &s_stage[wv], h, ss MM_PP_PASS);
+        tile_walk(a, t, &s_stage[wv], key, ss MM_PP_PASS);
     }
-    float n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    if (h.f >= 0) {
-        const float* nn = a.fn + ((size_t)t.b * a.F + h.f) * 3;
-        n0 = nn[0]; n1 = nn[1]; n2 = nn[2];
-    }
-    shade_store<kNoMask>(a, t, h, n0, n1, n2, ss);
+    shade_store<kNoMask>(a, t, key, ss);
     MM_PP_MARK(5);
     MM_PP_FLUSH(raster_fwd, (long long)blockIdx.x * (kBlock ? 4 : 1) + wv);
     MM_TIMELINE_END(raster_fwd);

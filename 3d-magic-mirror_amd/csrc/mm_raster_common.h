@@ -35,8 +35,12 @@ struct RasterArgs {
 };
 
 #define MM_PAIR_ROUND 512
+#ifndef MM_HEAVY_CAND
 #define MM_HEAVY_CAND 192     // a tile with at least this many candidates (three batches) is walked by four waves together ...
+#endif
+#ifndef MM_HEAVY_MAX
 #define MM_HEAVY_MAX 32       // ... if it is among the image's MM_HEAVY_MAX heaviest
+#endif
 
 struct TileCtx {
     int b, blk, px, py, tx0, ty0, lane, wave;   // wave = quadrant of the 16x16 block `blk`
@@ -217,23 +221,44 @@ __device__ inline unsigned long long fixed32(float x) {
 struct SoftState { float qnz; int zeros, lastf; };
 
 // ---- shading (a9-a11), stores, fused recon_data partial sums.  Uncovered pixels carry zero features exactly like kaolin's
-// interpolated_features.  (n0,n1,n2) = unit normal of the winning face (ignored when h.f < 0).
+// interpolated_features.  key = the pixel's depth key after the walk (0: uncovered).
 // (lanes outside a ragged image only stay for the fused loss reduction: they address a clamped pixel and store nothing)
+//
+// The epilogue is a chain of DEPENDENT trips to memory (each ~1-2.5 us under load, and 40 % of this kernel's wave time when
+// every `if (corner inside) tc += tex[..]` was its own branch + wait): it is written so that exactly two remain --
+//   trip 1  everything that depends on the winner's id alone: its geometry, normal and corner uvs, plus background / ground truth
+//   trip 2  the twelve texels, from clamped (always valid) addresses, unconditionally; a corner outside contributes an exact zero
+// The arithmetic (expressions, order, roundings) is unchanged.
 template <bool kNoMask>
-__device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const Hit& h, float n0, float n1, float n2, const SoftState& ss) {
+__device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsigned long long key, const SoftState& ss) {
     if (!t.in_img && !a.gt) return;
     const int cpx = min(t.px, a.W - 1), cpy = min(t.py, a.H - 1);
     const size_t pix = ((size_t)t.b * a.H + cpy) * a.W + cpx;
     const size_t hw = (size_t)a.H * a.W, pin = (size_t)cpy * a.W + cpx;
-    // background and ground truth depend on nothing: issue their loads ahead of the uv -> texel chain
+    Hit h;
+    h.f = key != 0ull ? depth_key_rank(key) : -1; h.w0 = h.w1 = h.w2 = 0.f;
+    const bool any = __ballot(h.f >= 0) != 0;                    // wave-uniform: more than half of all tiles have no covered pixel
+    // ---- trip 1
     float bgv[3] = {0.f, 0.f, 0.f}, gtv[4] = {0.f, 0.f, 0.f, 0.f};
     if (kNoMask) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) bgv[c] = a.bg[((size_t)t.b * 3 + c) * hw + pin];
     }
-    if (a.gt && t.in_img) {
+    if (a.gt) {                                                  // (clamped pixel: a valid address in every lane)
 #pragma unroll
         for (int c = 0; c < 4; ++c) gtv[c] = a.gt[((size_t)t.b * 4 + c) * hw + pin];
+    }
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+    float fu[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    if (any) {                                                   // uncovered lanes read face 0's records and ignore them
+        const int fs = max(h.f, 0);
+        const float4* geo = a.geo + ((size_t)t.b * a.F + fs) * 3;
+        p0 = geo[0]; p1 = geo[1];
+        const float2* fuv = (const float2*)(a.face_uvs + (size_t)fs * 6);
+        const float2 u0 = fuv[0], u1 = fuv[1], u2 = fuv[2];
+        fu[0] = u0.x; fu[1] = u0.y; fu[2] = u1.x; fu[3] = u1.y; fu[4] = u2.x; fu[5] = u2.y;
+        const float* nn = a.fn + ((size_t)t.b * a.F + fs) * 3;
+        n0 = nn[0]; n1 = nn[1]; n2 = nn[2];
     }
     float nx = 0.f, ny = 0.f, nz = 0.f;
     float out[4];
@@ -241,8 +266,8 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
 #pragma unroll                                                   // the user's lights 2 / 3 with the y / z bands instead
     for (int i = 0; i < 9; ++i) L[i] = a.lights[t.b * 9 + i];
     if (a.options & MM_OPT_SH_ORDER_XYZ) { const float tmp = L[2]; L[2] = L[3]; L[3] = tmp; }
-    if (__ballot(h.f >= 0) == 0) {
-        // No lane of the tile is covered (more than half of all tiles).  The general path below then computes, per lane,
+    if (!any) {
+        // No lane of the tile is covered.  The general path below then computes, per lane,
         //   m = 0, n = 0  ->  coef = C0*L0 + (0 - C6B)*L6   (the other seven bands are products with 0)
         //   no_mask: (tc*0 + g*(1-0)) * coef = g * coef;   white: (tc*0)*coef + 1*(1-0) = 1        (finite texels / lights)
         // -- the same roundings without the uv -> bilinear -> twelve-texel chain.
@@ -254,8 +279,12 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
         }
     } else {
         float m = 0.f, u = 0.f, v = 0.f;
+        {
+            float w0, w1, w2, nrm;                               // barycentrics of the winner (same expressions, same values as the walk's)
+            bary_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, t.x0, t.y0, a.eps, (a.options & MM_OPT_BARY_ONE_MINUS) != 0, w0, w1, w2, nrm);
+            if (h.f >= 0) { h.w0 = w0; h.w1 = w1; h.w2 = w2; }
+        }
         if (h.f >= 0) {
-            const float* fu = a.face_uvs + (size_t)h.f * 6;
             m = (h.w0 + h.w1) + h.w2;
             u = (h.w0 * fu[0] + h.w1 * fu[2]) + h.w2 * fu[4];
             v = (h.w0 * fu[1] + h.w1 * fu[3]) + h.w2 * fu[5];
@@ -266,6 +295,16 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
         const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
         const bool inw = s.x0 < a.Wt && s.y0 < a.Ht, ine = s.x1 < a.Wt && s.y0 < a.Ht;
         const bool isw = s.x0 < a.Wt && s.y1 < a.Ht, ise = s.x1 < a.Wt && s.y1 < a.Ht;
+        // ---- trip 2: twelve loads in flight together
+        const int cx0 = min(max(s.x0, 0), a.Wt - 1), cx1 = min(max(s.x1, 0), a.Wt - 1);
+        const int cy0 = min(max(s.y0, 0), a.Ht - 1), cy1 = min(max(s.y1, 0), a.Ht - 1);
+        float tq[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* tex = a.textures + ((size_t)t.b * 3 + c) * a.Ht * a.Wt;
+            tq[c][0] = tex[(size_t)cy0 * a.Wt + cx0]; tq[c][1] = tex[(size_t)cy0 * a.Wt + cx1];
+            tq[c][2] = tex[(size_t)cy1 * a.Wt + cx0]; tq[c][3] = tex[(size_t)cy1 * a.Wt + cx1];
+        }
         float bnd[9];
         sh_bands(nx, ny, nz, bnd);
         float coef = 0.f;
@@ -273,12 +312,11 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, const 
         for (int i = 0; i < 9; ++i) coef += bnd[i] * L[i];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float* tex = a.textures + ((size_t)t.b * 3 + c) * a.Ht * a.Wt;
-            float tc = 0.f;
-            if (inw) tc += tex[(size_t)s.y0 * a.Wt + s.x0] * s.wnw;
-            if (ine) tc += tex[(size_t)s.y0 * a.Wt + s.x1] * s.wne;
-            if (isw) tc += tex[(size_t)s.y1 * a.Wt + s.x0] * s.wsw;
-            if (ise) tc += tex[(size_t)s.y1 * a.Wt + s.x1] * s.wse;
+            float tc = 0.f;                                      // (x + 0*w = x exactly: a corner outside the texture leaves the sum as it was)
+            tc += (inw ? tq[c][0] : 0.f) * s.wnw;
+            tc += (ine ? tq[c][1] : 0.f) * s.wne;
+            tc += (isw ? tq[c][2] : 0.f) * s.wsw;
+            tc += (ise ? tq[c][3] : 0.f) * s.wse;
             float val;
             if (kNoMask) {
                 const float g = bgv[c];

@@ -20,6 +20,7 @@ struct __attribute__((aligned(16))) WaveStage {
     int zeros[64];                          // per pixel: number of factors (1-p) that are exactly 0
     int cnt[64];                            // cooperative walk: per pixel, inflated-box hits of this wave's batch of the current round
     int lastf[64];                          // cooperative walk: per pixel, id of the knum-th silhouette face taken
+    int npair[4];                           // cooperative walk: this wave's colour / silhouette pair counts of the round
 };
 static_assert(sizeof(WaveStage) <= 8192, "four of them must fit 32 KiB: five workgroups per CU");
 
@@ -66,18 +67,36 @@ __device__ inline TileCtx make_tile(const RasterArgs& a, int wv, bool& valid, bo
     return t;
 }
 
-// this lane's share of the bin's mask group -> ordered id list in st->ids; returns the number of candidates of the group
-__device__ inline int expand_ids(const RasterArgs& a, const TileCtx& t, WaveStage* st, int wbase) {
-    uint64_t w = 0;
-    if (t.lane < MM_GROUP_WORDS && wbase + t.lane < a.words) w = t.mask[wbase + t.lane];
-    int total;
-    int pos = wave_prefix_excl(__popcll(w), t.lane, total);
-    while (w) {                                                  // <= MM_GROUP_WORDS lanes, <= 64 iterations
-        const int bit = __ffsll((unsigned long long)w) - 1;
-        w &= w - 1;
-        st->ids[pos++] = (unsigned short)(t.lane * 64 + bit);
+// The bin's candidate bits -> ordered id lists in st->ids.  A CHUNK is 64 mask words (4096 faces), loaded with one instruction (lane =
+// word); it is walked in WINDOWS of whole words holding at most MM_GROUP_WORDS * 64 ids -- nearly always the whole chunk at once, so
+// a tile pays one trip to memory for its mask and its candidates fill whole batches whatever words they come from.  Ids are relative
+// to the chunk's first face.
+struct IdWindows { uint64_t w; int pc, pre, tot, first, done; };
+__device__ inline void idw_begin(IdWindows& iw, const RasterArgs& a, const TileCtx& t, int cbase) {
+    iw.w = (cbase + t.lane < a.words) ? t.mask[cbase + t.lane] : 0ull;
+    iw.pc = __popcll(iw.w);
+    iw.pre = wave_prefix_excl(iw.pc, t.lane, iw.tot);
+    iw.first = 0; iw.done = 0;
+}
+// next window: number of ids now in st->ids (0: the chunk is exhausted).  Wave-uniform.
+__device__ inline int idw_next(IdWindows& iw, const TileCtx& t, WaveStage* st) {
+    if (iw.done >= iw.tot) return 0;
+    const int end = iw.pre + iw.pc;
+    const bool part = t.lane >= iw.first && end - iw.done <= MM_GROUP_WORDS * 64;   // whole words, contiguous from `first` (a word holds <= 64 ids)
+    const int last = 63 - __clzll((unsigned long long)__ballot(part));
+    const int wend = __shfl(end, last, 64);
+    if (part) {
+        uint64_t w = iw.w;
+        int pos = iw.pre - iw.done;
+        while (w) {                                              // <= 64 iterations
+            const int bit = __ffsll((unsigned long long)w) - 1;
+            w &= w - 1;
+            st->ids[pos++] = (unsigned short)(t.lane * 64 + bit);
+        }
     }
-    return total;
+    const int n = wend - iw.done;
+    iw.done = wend; iw.first = last + 1;
+    return n;
 }
 
 // candidate of this lane staged in LDS + its two pixel masks (front-face box: colour; inflated box: silhouette), candidate-major
@@ -102,9 +121,11 @@ __device__ inline void stage_candidate(const RasterArgs& a, const TileCtx& t, Wa
 template <class WantSoft, class Body>
 __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, WantSoft&& want_soft, Body&& body MM_PP_ARG) {
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
-    for (int wbase = 0; wbase < a.words; wbase += MM_GROUP_WORDS) {
-        const int total = expand_ids(a, t, st, wbase);
-        if (total == 0) continue;
+    for (int cbase = 0; cbase < a.words; cbase += 64) {
+      IdWindows iw;
+      idw_begin(iw, a, t, cbase);
+      for (int total = idw_next(iw, t, st); total != 0; total = idw_next(iw, t, st)) {
+        const int wbase = cbase;
         wave_lds_sync();
         MM_PP_MARK(1);
         MM_PP_COUNT(total, 0);
@@ -135,6 +156,7 @@ __device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, Wav
             body(n, ph, ps);
             wave_lds_sync();
         }
+      }
     }
 }
 
@@ -159,8 +181,8 @@ __device__ inline void winner(const RasterArgs& a, const TileCtx& t, unsigned lo
 // zeros.  A pixel takes silhouette faces while no face of the batches SO FAR covers it: for a pixel that stays
 // uncovered that is every batch, in order -- exactly the two-pass result; whatever a pixel gathered before a later
 // batch covered it is never looked at.
-__device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStage* st, Hit& h, SoftState& ss MM_PP_ARG) {
-    h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
+__device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStage* st, unsigned long long& key, SoftState& ss MM_PP_ARG) {
+    key = 0ull;
     ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
     if (t.empty) return;                                         // wave-uniform: more than half of all tiles are empty
     st->key[t.lane] = 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0;
@@ -181,23 +203,26 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
         MM_PP_MARK(4);
     } MM_PP_PASS);
     wave_lds_sync();
-    winner(a, t, st->key[t.lane], h);
+    key = st->key[t.lane];
     ss.zeros = st->zeros[t.lane];
     ss.qnz = exp2f((float)((double)st->logsum[t.lane] * (1.0 / 4294967296.0)));
     ss.lastf = lastf;
 }
 
 // A HEAVY tile (hundreds of candidates: a far-away mesh folded into a few tiles) walked by the four waves of its workgroup.  Alone,
-// its wave would be the kernel's tail: one wave issues a vector instruction every ~5 cycles at best, and ~8 batches of staging,
-// box tests, transposes and pair rounds added up to 40+ us while the chip drained.  Here the batches of a ROUND of four go to the
-// four waves; colour pairs are order-free (64-bit max in the workgroup's LDS), and the silhouette's "first knum faces in index
-// order" rule is kept exactly: every wave publishes its batch's per-pixel inflated-box hit counts, and a batch takes what is left
-// of knum after the batches before it -- for a pixel that stays uncovered that is the sequential result bit for bit (what a pixel
-// gathered before it was covered is never read, as in tile_walk).  stage[0] holds the tile's results; every wave stages in its own.
-__device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, WaveStage* stage, int wv, Hit& h, SoftState& ss) {
+// its wave would be the kernel's tail: one wave issues a vector instruction every ~5 cycles at best, and the tile's pair evaluations
+// (up to 64 x knum silhouette pairs, most of them in its first batches) added up to 40 us while the chip drained.  Here the batches
+// of a ROUND of four are staged by the four waves (one each), and the round's PAIRS -- whichever batch they come from -- are dealt
+// evenly to all 256 lanes: every pair is (staging wave, candidate, pixel), colour pairs first, and any lane can evaluate any of them
+// because the four stages live in the workgroup's LDS and the results are combined by exact, commutative LDS atomics in stage[0].
+// The silhouette's "first knum faces in index order" rule is kept exactly: every wave publishes its batch's per-pixel inflated-box
+// hit counts, and a batch takes what is left of knum after the batches before it -- for a pixel that stays uncovered that is the
+// sequential result bit for bit (what a pixel gathered before it was covered is never read, as in tile_walk).
+#define MM_COOP_WINDOW (4 * MM_PAIR_ROUND)    // pairs dealt per pass: the four stages' pair buffers side by side
+__device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, WaveStage* stage, int wv, unsigned long long& key, SoftState& ss MM_PP_ARG) {
     WaveStage* st = &stage[wv];
     WaveStage* acc = &stage[0];
-    h.f = -1; h.w0 = h.w1 = h.w2 = 0.f;
+    key = 0ull;
     ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
     if (wv == 0) { acc->key[t.lane] = 0ull; acc->logsum[t.lane] = 0ll; acc->zeros[t.lane] = 0; acc->lastf[t.lane] = 0x7FFFFFFF; }
     __syncthreads();
@@ -205,10 +230,14 @@ __device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, Wav
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
     int base_cnt = 0;                                            // this pixel's inflated-box hits in the rounds so far
     bool open = t.in_img;
-    for (int wbase = 0; wbase < a.words; wbase += MM_GROUP_WORDS) {
-        const int total = expand_ids(a, t, st, wbase);           // every wave expands the same list into its own stage
-        if (total == 0) continue;                                // (the same in the four waves)
+    for (int cbase = 0; cbase < a.words; cbase += 64) {
+      IdWindows iw;
+      idw_begin(iw, a, t, cbase);                                // every wave expands the same lists into its own stage
+      for (int total = idw_next(iw, t, st); total != 0; total = idw_next(iw, t, st)) {   // (the same in the four waves)
+        const int wbase = cbase;
         wave_lds_sync();
+        MM_PP_MARK(1);
+        MM_PP_COUNT(total, 0);
         for (int r0 = 0; r0 < total; r0 += 4 * 64) {
             const int k0 = r0 + wv * 64;
             const int n = max(0, min(64, total - k0));
@@ -221,22 +250,68 @@ __device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, Wav
             const uint64_t ph = __ballot(mh != 0) ? wave_transpose64(mh, t.lane) : 0ull;
             const uint64_t ps = __ballot(ms != 0) ? wave_transpose64(ms, t.lane) : 0ull;
             st->cnt[t.lane] = __popcll(ps);
+            MM_PP_MARK(2);
             __syncthreads();
             int before = base_cnt, round_total = 0;              // hits of the batches before this wave's, in index order
 #pragma unroll
             for (int w2 = 0; w2 < 4; ++w2) { const int c = stage[w2].cnt[t.lane]; before += w2 < wv ? c : 0; round_total += c; }
-            if (__ballot(ph != 0)) pair_parallel(t, st, ph, [&](int l, int j, bool live) { hard_pair(a, t, st, acc, j, l, live); });
             const uint64_t sm = soft_take(ps, open, a.knum - before);
             if (sm != 0 && before + __popcll(sm) >= a.knum) acc->lastf[t.lane] = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].w);
-            if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, acc, s2, l, j, live); });
             base_cnt += round_total;
+            // this wave's pairs of the round: ph (colour) and sm (silhouette), pixel-major; their positions in the round's list
+            int nh, ns;
+            int kh = wave_prefix_excl(__popcll(ph), t.lane, nh);
+            int ks = wave_prefix_excl(__popcll(sm), t.lane, ns);
+            if (t.lane == 0) { st->npair[0] = nh; st->npair[1] = ns; }
             __syncthreads();
+            int TH = 0, TS = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const int c0 = stage[w2].npair[0], c1 = stage[w2].npair[1];
+                if (w2 < wv) { kh += c0; ks += c1; }
+                TH += c0; TS += c1;
+            }
+            ks += TH;                                            // silhouette pairs behind all colour pairs
+            const int T = TH + TS;
+            MM_PP_MARK(6);
+            MM_PP_COUNT(0, T);
+            uint64_t remh = ph, rems = sm;
+            for (int base = 0; base < T; base += MM_COOP_WINDOW) {
+                const int lim = min(MM_COOP_WINDOW, T - base);
+                while (remh && kh < base + lim) {                // every set bit is visited exactly once overall
+                    const int j = __ffsll((unsigned long long)remh) - 1;
+                    remh &= remh - 1;
+                    const int q = kh - base;
+                    stage[q / MM_PAIR_ROUND].pairs[q % MM_PAIR_ROUND] = (unsigned short)((wv << 12) | (j << 6) | t.lane);
+                    ++kh;
+                }
+                while (rems && ks < base + lim) {
+                    const int j = __ffsll((unsigned long long)rems) - 1;
+                    rems &= rems - 1;
+                    const int q = ks - base;
+                    stage[q / MM_PAIR_ROUND].pairs[q % MM_PAIR_ROUND] = (unsigned short)(0x4000 | (wv << 12) | (j << 6) | t.lane);
+                    ++ks;
+                }
+                __syncthreads();
+                MM_PP_MARK(3);
+                for (int q = threadIdx.x; q < lim; q += 256) {
+                    const unsigned pr = stage[q / MM_PAIR_ROUND].pairs[q % MM_PAIR_ROUND];
+                    WaveStage* src = &stage[(pr >> 12) & 3];
+                    const int j = (pr >> 6) & 63, l = pr & 63;
+                    if (pr & 0x4000u) soft_pair(a, t, src, acc, s2, l, j, true);
+                    else hard_pair(a, t, src, acc, j, l, true);
+                }
+                MM_PP_MARK(4);
+                __syncthreads();
+                MM_PP_MARK(7);
+            }
             open = t.in_img && acc->key[t.lane] == 0ull;
         }
+      }
     }
     __syncthreads();
     if (wv != 0) return;
-    winner(a, t, acc->key[t.lane], h);
+    key = acc->key[t.lane];
     ss.zeros = acc->zeros[t.lane];
     ss.qnz = exp2f((float)((double)acc->logsum[t.lane] * (1.0 / 4294967296.0)));
     ss.lastf = acc->lastf[t.lane];

@@ -28,7 +28,8 @@ KERNELS = {
     "vertex_bwd": (["T + vertex loads", "corner gather", "reductions + partial store", "ticket", "last WG: lights", "last WG: camera chain"], ("-", "-")),
     "gather_face": (["setup", "sweep: face_idx loads", "compaction", "item loads", "item math + LDS adds", "stores"], ("trips", "items")),
     "gather_tex": (["count + first record", "clear LDS", "records", "tile store"], ("records", "-")),
-    "raster_fwd": (["tile setup", "mask -> id list", "geo fetch + stage + box tests + transposes", "colour pairs", "silhouette pairs", "winner + shade + store"], ("candidates", "batches")),
+    "raster_fwd": (["tile setup", "mask -> id list", "geo fetch + stage + box tests + transposes", "colour pairs (coop: pair list)", "silhouette pairs (coop: pair evaluation)", "winner + shade + store", "coop: barrier + counts",
+                   "coop: barrier after the pairs"], ("candidates", "batches (coop: pairs)")),
 }
 SL, MAXW = 8, 16384
 print("== %s: %s B=%d %dx%d (100 MHz ticks -> us)" % (cfg, name, B, H, W))
@@ -42,6 +43,8 @@ for kn, (phases, cn) in KERNELS.items():
     m = m[m[:, SL] > 0]
     if not len(m):
         continue
+    if os.environ.get("MM_PP_DUMP"):                             # raw per-wave rows for offline analysis
+        np.save(os.path.join(ROOT, "gpurun_out", "pp_%s_%s.npy" % (cfg, kn)), m)
     tot = m[:, SL] / 100.0
     print("%s: %d waves recorded; wave time mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (kn, len(m), tot.mean(), np.median(tot), np.percentile(tot, 90), np.percentile(tot, 99), tot.max()))
     for i, ph in enumerate(phases):
@@ -50,6 +53,6 @@ for kn, (phases, cn) in KERNELS.items():
     acc = m[:, :len(phases)].sum(1) / 100.0
     print("   %-46s mean %6.2f us" % ("(unaccounted)", (tot - acc).mean()))
     print("   %s: mean %.2f max %d;  %s: mean %.1f max %d" % (cn[0], m[:, SL + 1].mean(), m[:, SL + 1].max(), cn[1], m[:, SL + 2].mean(), m[:, SL + 2].max()))
-    heavy = np.argsort(-tot)[:4]
+    heavy = np.argsort(-tot)[:int(os.environ.get('MM_PP_SLOWEST', '4'))]
     for h in heavy:
         print("   slowest wave: total %.1f us | " % tot[h] + "  ".join("%s %.1f" % (ph.split(":")[0].split(" ")[0], m[h, i] / 100.0) for i, ph in enumerate(phases)) + " | %s %d %s %d" % (cn[0], m[h, SL + 1], cn[1], m[h, SL + 2]))

@@ -68,7 +68,7 @@ struct Workspace {
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
-    int* nheavy;           // (B)        how many of an image's first tiles (in that order) are walked by four waves together
+    int* nheavy;           // (B,2)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty
     long long* ltot;       // (B,MM_LSUB,4) fused loss: per image {sum|pi-gi|, sum p*g, sum p+g-p*g, -} in 2^-32 fixed point, spread over
                            //            MM_LSUB sub-accumulators (64-bit integer atomics of the raster waves: exact, order-free); zeroed by vertex_fwd
     int* tcnt;             // (B,ntiles)+(B)+(B,MM_GSHARD,8) records appended per texture tile, per-image spill counts, per-image maxima of the pixel
@@ -77,7 +77,7 @@ struct Workspace {
     TexRecord* trec;       // (B,ntiles,MM_TREC_CAP)
     TexSpill* tspill;      // (B,4*H*W)   records of tiles whose list is full (worst case: every pixel, 2x2 tiles)
     int2* chunkmap;        // (B,F)      {first sweep item, number of items} of every face (plan kernel, every forward)
-    int2* items;           // (B,item_cap) sweep items {face, chunk of its box; -1: the whole box}
+    int2* items;           // (B,item_cap) sweep items {face, chunk of its box}
     int2* nitems;          // (B)        {items listed, pixels per chunk in this image (MM_CHUNK_PX << k)}
     float* part;           // (B,item_cap,12) per-item partial sums of dL/d(face xy) (6) and dL/d(unit normal) (3); the vertex backward adds a
                            //            face's items up in index order
@@ -112,7 +112,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
     w.ltot = (long long*)(p + o);   o += align256((size_t)B * MM_LSUB * 4 * sizeof(long long));
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
-    w.nheavy = (int*)(p + o);       o += align256((size_t)B * sizeof(int));
+    w.nheavy = (int*)(p + o);       o += align256((size_t)B * 2 * sizeof(int));
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
     w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + (size_t)B + (size_t)B * MM_GSHARD * 8) * sizeof(int));
     w.tspill = (TexSpill*)(p + o);  o += align256((size_t)B * 4 * H * W * sizeof(TexSpill));

@@ -35,7 +35,7 @@ static DibrWorkspace carve_dibr(void* base, int B, int F, int H, int W) {
     w.geo = (float4*)(p + o);            o += align256((size_t)B * F * 3 * sizeof(float4));
     w.binmask = (uint64_t*)(p + o);      o += align256((size_t)B * w.nbx * w.nby * w.words * sizeof(uint64_t));
     w.order = (unsigned short*)(p + o);  o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
-    w.nheavy = (int*)(p + o);            o += align256((size_t)B * sizeof(int));
+    w.nheavy = (int*)(p + o);            o += align256((size_t)B * 2 * sizeof(int));
     w.soft = (float2*)(p + o);           o += align256((size_t)B * H * W * sizeof(float2));
     w.fidx = (int32_t*)(p + o);          o += align256((size_t)B * H * W * sizeof(int32_t));
     w.bytes = o;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) void raster_dibr_kernel(RasterAr
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
     const int wv = kBlock ? threadIdx.x >> 6 : 0;
     bool valid, coop;
-    const TileCtx t = make_tile<kBlock>(a, wv, valid, coop);
+    const TileCtx t = make_tile<kBlock>(a, wv, valid, coop, 4 * a.blocks_per_image);
     unsigned long long key;
     Hit h;
     SoftState ss;

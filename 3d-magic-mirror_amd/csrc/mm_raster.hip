@@ -36,8 +36,22 @@ __global__ __launch_bounds__(kBlock ? 256 : 64, kBlock ? 5 : 1) void raster_fwd_
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
     MM_PP_BEGIN();
     const int wv = kBlock ? threadIdx.x >> 6 : 0;
+    int limit = 4 * a.blocks_per_image;
+    if (a.order) {
+        // workgroups of image b, in launch order: heavy tiles (one each), the other non-empty tiles (four each, or one), then the empty
+        // tiles four per WAVE (shade_empty_tiles); the grid is sized for "no tile is empty", workgroups behind the last one exit
+        const int b = blockIdx.x % a.B, j = blockIdx.x / a.B;
+        const int nh = kBlock ? a.nheavy[2 * b] : 0, nne = a.nheavy[2 * b + 1];
+        const int je = kBlock ? nh + (max(nne - nh, 0) + 3) / 4 : nne;       // first workgroup of the empty tiles
+        limit = nne;
+        if (j >= je) {
+            const int e0 = nne + (j - je) * (kBlock ? 16 : 4) + wv * 4, ne = min(4, 4 * a.blocks_per_image - e0);
+            if (ne > 0) shade_empty_tiles<kNoMask>(a, b, e0, ne, threadIdx.x & 63);
+            return;
+        }
+    }
     bool valid, coop;
-    const TileCtx t = make_tile<kBlock>(a, wv, valid, coop);     // coop is workgroup-uniform; !valid only in the last light workgroup of an image
+    const TileCtx t = make_tile<kBlock>(a, wv, valid, coop, limit);          // coop is workgroup-uniform; !valid only in the last workgroup of the non-empty tiles
     unsigned long long key;
     SoftState ss;
     MM_PP_MARK(0);
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
     for (int j = 0; j < 4; ++j) { s_start[1023 - (4 * tid + j)] = before; before += h[j]; }
     __syncthreads();
     // tiles with at least MM_HEAVY_CAND candidates come first: the slots in front of key MM_HEAVY_CAND - 1
-    if (tid == 0) nheavy[b] = min(s_start[MM_HEAVY_CAND - 1], MM_HEAVY_MAX);
+    if (tid == 0) { nheavy[2 * b] = min(s_start[MM_HEAVY_CAND - 1], MM_HEAVY_MAX); nheavy[2 * b + 1] = s_start[0]; }   // slots in front of key 0: not empty
     __syncthreads();
     for (int slot = tid; slot < nslot; slot += 256)
         order[(size_t)b * nslot + atomicAdd(&s_start[s_key[slot]], 1)] = (unsigned short)(slot | (s_key[slot] == 0 ? 0x8000 : 0));

@@ -21,7 +21,7 @@ struct RasterArgs {
     float2* soft;                           // per pixel {soft-mask product state, id of the knum-th face taken (int bits)}
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
-    const int* nheavy;                      // (B) how many of an image's first tiles are walked cooperatively (plan kernel)
+    const int* nheavy;                      // (B,2) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty
     // outputs
     float* rgba;
     int32_t* face_idx;
@@ -352,6 +352,69 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
             unsigned long long* row = (unsigned long long*)(a.ltot + ((size_t)t.b * MM_LSUB + ((t.blk * 4 + t.wave) & (MM_LSUB - 1))) * 4);
             atomicAdd(row + 0, fixed32(l1));
             if (up != 0.f) atomicAdd(row + 1, fixed32(up));
+            if (down != 0.f) atomicAdd(row + 2, fixed32(down));
+        }
+    }
+}
+
+// Tiles no face can touch (three quarters of all tiles at 128x128; the plan kernel sorts them behind the others), FOUR per wave: a
+// tile of its own wave pays the wave's fixed costs (launch, two dependent trips to memory, the store drain) for ~40 instructions of
+// work.  Here the four tiles' loads are in flight together.  Per pixel exactly what shade_store's uncovered-tile path computes
+// (m = 0, n = 0, soft-mask state "nothing taken"); the four tiles' recon_data terms go to ltot as one exact integer add per sum.
+template <bool kNoMask>
+__device__ inline void shade_empty_tiles(const RasterArgs& a, int b, int e0, int ne, int lane) {
+    const int nslot = 4 * a.blocks_per_image;
+    const size_t hw = (size_t)a.H * a.W;
+    unsigned sl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sl[q] = a.order[(size_t)b * nslot + min(e0 + q, nslot - 1)] & 0x7FFFu;
+    const float coef = MM_SH_C0 * a.lights[b * 9] + (0.f - MM_SH_C6B) * a.lights[b * 9 + 6];   // (bands 0 and 6: the same lights whatever the band order)
+    bool in[4];
+    size_t pin[4];
+    float bgv[4][3], gtv[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int blk = (int)sl[q] >> 2, quad = (int)sl[q] & 3;
+        const int px = (blk % a.blocks_x) * MM_BLOCK_PX + (quad & 1) * MM_TILE + (lane & 7);
+        const int py = (blk / a.blocks_x) * MM_BLOCK_PX + (quad >> 1) * MM_TILE + (lane >> 3);
+        in[q] = q < ne && px < a.W && py < a.H;
+        pin[q] = (size_t)min(py, a.H - 1) * a.W + min(px, a.W - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bgv[q][c] = kNoMask ? a.bg[((size_t)b * 3 + c) * hw + pin[q]] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gtv[q][c] = a.gt ? a.gt[((size_t)b * 4 + c) * hw + pin[q]] : 0.f;
+    }
+    float l1 = 0.f, down = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float out[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float val = kNoMask ? bgv[q][c] * coef : 1.f;
+            out[c] = val < 0.f ? 0.f : (val > 1.f ? 1.f : val);
+        }
+        if (!in[q]) continue;
+        const size_t pix = (size_t)b * hw + pin[q];
+        *(float4*)(a.rgba + pix * 4) = make_float4(out[0], out[1], out[2], 1.f - 1.f);
+        a.face_idx[pix] = -1;
+        a.soft[pix] = make_float2(1.f, __int_as_float(0x7FFFFFFF));
+        if (a.imnormal) { a.imnormal[pix * 3] = 0.f; a.imnormal[pix * 3 + 1] = 0.f; a.imnormal[pix * 3 + 2] = 0.f; }
+        if (a.gt) {
+            const float gm = gtv[q][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gi = gtv[q][c] * gm + 1.f * (1.f - gm);
+                const float pi = out[c] * gm + 1.f * (1.f - gm);
+                l1 += fabsf(pi - gi);
+            }
+            down += (0.f + gm) - 0.f * gm;                       // alpha = 0: up = 0, down = gm
+        }
+    }
+    if (a.gt) {
+        l1 = wave_sum(l1); down = wave_sum(down);
+        if (lane == 0) {
+            unsigned long long* row = (unsigned long long*)(a.ltot + ((size_t)b * MM_LSUB + (sl[0] & (MM_LSUB - 1))) * 4);
+            if (l1 != 0.f) atomicAdd(row + 0, fixed32(l1));
             if (down != 0.f) atomicAdd(row + 2, fixed32(down));
         }
     }

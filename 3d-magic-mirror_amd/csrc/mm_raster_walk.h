@@ -32,19 +32,21 @@ static_assert(sizeof(WaveStage) <= 8192, "four of them must fit 32 KiB: five wor
 //   valid: this wave has a tile;  coop: the workgroup's waves share it (wv = this wave's index among them).
 //   kBlock = false: the one-wave workgroup variant of the same kernels (one tile per workgroup, never cooperative): a slow tile
 //   then never pins the LDS and the wave slots of finished neighbours -- better where tiles are many and none is heavy.
+//   limit: tiles [0, limit) of the order are walked by this mapping (the fused kernel shades the empty ones behind them four per wave)
 template <bool kBlock>
-__device__ inline TileCtx make_tile(const RasterArgs& a, int wv, bool& valid, bool& coop) {
+__device__ inline TileCtx make_tile(const RasterArgs& a, int wv, bool& valid, bool& coop, int limit) {
     TileCtx t;
     int blk;
     valid = true; coop = false;
     if (a.order) {
         const int nslot = 4 * a.blocks_per_image;
         t.b = blockIdx.x % a.B;
-        const int j = blockIdx.x / a.B, nh = kBlock ? a.nheavy[t.b] : 0;
+        const int j = blockIdx.x / a.B, nh = kBlock ? a.nheavy[2 * t.b] : 0;
         int idx;
         if (!kBlock) idx = j;
         else if (j < nh) { idx = j; coop = true; }
-        else { idx = nh + (j - nh) * 4 + wv; valid = idx < nslot; }
+        else idx = nh + (j - nh) * 4 + wv;
+        valid = idx < limit;
         const unsigned e = a.order[(size_t)t.b * nslot + (valid ? idx : 0)];
         const int slot = (int)(e & 0x7FFFu);
         t.empty = (e >> 15) != 0;                                // the plan kernel counted no candidate at all for this tile

@@ -10,7 +10,7 @@
 HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports both in KiB, and on gfx950 FETCH_SIZE counts 128-B requests
 as 64 B (MI355X_MICROARCH.md, HBM section).  Usage: python profiles/summarize_profile.py r02 config2
 """
-import collections, csv, glob, json, os, sys
+import re, collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,7 +27,7 @@ def short(name):
 
 
 def kname(k):
-    return k.replace("_kernel", "").replace("<true>", "").replace("<false>", "")
+    return re.sub(r"<.*>", "", k.replace("_kernel", ""))
 
 
 # ---- PMC passes --------------------------------------------------------------------------------------------------------

@@ -129,6 +129,7 @@ struct VertexBwdArgs {
 __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
     __shared__ Camera s_cam;
     __shared__ float s_red[4][12];
+    __shared__ float s_part[21][12];
     __shared__ int s_last;
     const int b = blockIdx.y, tid = threadIdx.x;
     MM_PP_BEGIN();
@@ -160,6 +161,12 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             // the face's gradients = its sweep items' partial sums, added in index order (one item for most faces)
             float gx = 0.f, gy = 0.f, g[3] = {0.f, 0.f, 0.f};
             const int2 cm = a.chunkmap[o];
+            // the face's corners (static connectivity) ride along with chunkmap, its three vertices with the partial sums: loaded whether or
+            // not the normal gradient below turns out to be zero -- inside that branch they would cost two more dependent trips to memory
+            const int i0 = a.faces[f * 3], i1 = a.faces[f * 3 + 1], i2 = a.faces[f * 3 + 2];
+            float pa[3], pb[3], pc[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
             const float* part = a.part + ((size_t)b * a.item_cap + cm.x) * 12;
             for (int c = 0; c < cm.y; ++c) {
                 gx += part[c * 12 + k * 2]; gy += part[c * 12 + k * 2 + 1];
@@ -172,8 +179,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             // through the unit face normal
             if (a.gfn) { g[0] += a.gfn[o * 3]; g[1] += a.gfn[o * 3 + 1]; g[2] += a.gfn[o * 3 + 2]; }
             if (g[0] != 0.f || g[1] != 0.f || g[2] != 0.f) {
-                const int i0 = a.faces[f * 3], i1 = a.faces[f * 3 + 1], i2 = a.faces[f * 3 + 2];
-                const Float3 A = to_camera(vb + (size_t)i0 * 3, T), Bv = to_camera(vb + (size_t)i1 * 3, T), C = to_camera(vb + (size_t)i2 * 3, T);
+                const Float3 A = to_camera(pa, T), Bv = to_camera(pb, T), C = to_camera(pc, T);
                 const float e0[3] = {Bv.x - A.x, Bv.y - A.y, Bv.z - A.z};
                 const float e1[3] = {C.x - A.x, C.y - A.y, C.z - A.z};
                 float n[3];
@@ -246,21 +252,33 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         // the partials (independent loads), fixed butterfly order
         const int wv = tid >> 6, ln = tid & 63;
         if (wv >= 1) {
-            for (int i = (wv - 1) * 3; i < (wv - 1) * 3 + 3; ++i) {
-                float sum = 0.f;
-                for (int k = ln; k < a.blocks_per_image; k += 64) sum += a.dl_part[((size_t)b * a.blocks_per_image + k) * 12 + i];
-                sum = wave_sum(sum);
-                if (ln == 0) a.grad_lights[b * 9 + i] = sum;
+            float sum[3] = {0.f, 0.f, 0.f};                      // the three components' loads in flight together
+            for (int k = ln; k < a.blocks_per_image; k += 64) {
+                const float* row = a.dl_part + ((size_t)b * a.blocks_per_image + k) * 12 + (wv - 1) * 3;
+                sum[0] += row[0]; sum[1] += row[1]; sum[2] += row[2];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sum[i] = wave_sum(sum[i]);
+                if (ln == 0) a.grad_lights[b * 9 + (wv - 1) * 3 + i] = sum[i];
             }
         }
     }
     MM_PP_MARK(4);
     if (tid >= 64 && tid < 100) reinterpret_cast<float*>(&s_cam)[tid - 64] = a.cam[b * 48 + tid - 64];   // the forward's camera (no trig here)
-    if (tid < 12) {                                              // dL/dT = sum of the workgroups' partials, in index order
+    {   // dL/dT = sum of the workgroups' partials in index order.  The partials are fetched by all threads at once (one trip to memory per 21
+        // workgroups, not one per workgroup), parked in LDS and added up by twelve threads in index order: still bitwise reproducible.
         float sum = 0.f;
-        for (unsigned g = 0; g < gridDim.x; ++g)
-            sum += __hip_atomic_load(a.dTpart + ((size_t)b * gridDim.x + g) * 12 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_red[0][tid] = sum;
+        const int gl = tid / 12, comp = tid - gl * 12;           // 21 partial rows per pass
+        for (unsigned g0 = 0; g0 < gridDim.x; g0 += 21) {
+            const unsigned g = g0 + gl;
+            if (gl < 21 && g < gridDim.x)
+                s_part[gl][comp] = __hip_atomic_load(a.dTpart + ((size_t)b * gridDim.x + g) * 12 + comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid < 12) for (unsigned k = 0; k < 21u && g0 + k < gridDim.x; ++k) sum += s_part[k][tid];
+            __syncthreads();
+        }
+        if (tid < 12) s_red[0][tid] = sum;
     }
     __syncthreads();
     if (tid == 0) {

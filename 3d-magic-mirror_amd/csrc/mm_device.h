@@ -18,7 +18,9 @@
 #define MM_LSUB 8             // sub-accumulators per image for the fused loss sums (one 32-byte row each: spreads same-address atomics)
 #define MM_UV_TILE 32         // texture-gradient tiles: 32x32 texels, one workgroup and one record list each
 #define MM_GSHARD 16          // per image, the pixel backward's maxima are spread over this many words (see mm_backward.hip)
-#define MM_CHUNK_PX 256       // the backward sweeps every face's inflated pixel box in chunks of this many pixels, one 8-lane group each:
+#ifndef MM_CHUNK_PX
+#define MM_CHUNK_PX 128          // (256: gather_bwd +3.5 / +4.6 / +10 us at configs 2 / 3 / 5: the waves full of owned chunks are its tail)
+#endif                        // the backward sweeps every face's inflated pixel box in chunks of this many pixels, one 8-lane group each:
                               // an even load whatever the box sizes (perspective blow-ups, close-ups at high resolution)
 #define MM_GROUP_WORDS 16     // bin-mask words (of 64 faces) expanded per step: 1024 faces -> 2 KiB of uint16 ids per wave
 

@@ -37,15 +37,19 @@ _CSR_CACHE = {}
 
 
 def _faces_tables(faces, dev):
-    """int32 device copy of ``faces`` and its vertex->corner CSR (needed by the gather-formulated backward), cached per tensor."""
+    """int32 device copy of ``faces`` and its vertex->corner CSR (needed by the gather-formulated backward), cached per tensor.
+    The entry HOLDS the tensor it was made from: a key of address + version alone is reused by the allocator for the next template of the
+    same shape once the first is freed (seen as a rare wrong-topology render between two 1280-face templates in the test suite)."""
     key = (faces.data_ptr(), faces._version, tuple(faces.shape), str(faces.device), str(dev))
     hit = _CSR_CACHE.get(key)
+    if hit is not None and hit[4] is not faces and not (hit[4].shape == faces.shape and torch.equal(hit[4], faces)):
+        hit = None                                               # same storage, other tensor object (a view / re-wrap): trust contents only
     if hit is None:
         fh = faces.detach().to("cpu", torch.int64)
         V = int(fh.max()) + 1 if fh.numel() else 0
         off, items = template.vertex_corner_adjacency(V, fh)
         hit = (faces.detach().to(device=dev, dtype=torch.int32).contiguous(), off.to(device=dev, dtype=torch.int32).contiguous(),
-               items.to(device=dev, dtype=torch.int32).contiguous(), V)
+               items.to(device=dev, dtype=torch.int32).contiguous(), V, faces)
         if len(_CSR_CACHE) > 16:
             _CSR_CACHE.clear()
         _CSR_CACHE[key] = hit
@@ -111,7 +115,7 @@ def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans
         camera_transform = torch.cat([rt, -(camera_trans.to(dev).reshape(-1, 1, 3) @ rt)], dim=1)
     if camera_transform.dim() != 3 or camera_transform.shape[1:] != (4, 3) or camera_transform.shape[0] != vertices.shape[0]:
         raise RuntimeError("camera_transform must be (B,4,3), got %s" % (tuple(camera_transform.shape),))
-    faces_i32, off, items, Vf = _faces_tables(faces, dev)
+    faces_i32, off, items, Vf, _ = _faces_tables(faces, dev)
     if Vf > vertices.shape[1]:
         raise RuntimeError("faces index vertex %d but vertices has %d" % (Vf - 1, vertices.shape[1]))
     if Vf < vertices.shape[1]:                                   # trailing vertices no face uses: pad the CSR

@@ -260,7 +260,18 @@ def test_operators_composed_like_the_reference_match_the_fused_render(pkg, kal, 
     T = _dev(Tn, True)
     r1, fn1, fidx1 = _reference_order_render(kal, dr, A1, T, no_mask)
     r2, out2 = dr.render(no_mask=no_mask, **A2)
-    assert torch.equal(fidx1.int(), dr.last_face_idx)                   # the SAME walk serves both boundaries
+    if not torch.equal(fidx1.int(), dr.last_face_idx):                  # the SAME walk serves both boundaries
+        f1, f2 = fidx1.int(), dr.last_face_idx
+        d = (f1 != f2).nonzero()
+        inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att.items()}
+        inp["faces"] = dr.faces.numpy().astype(np.int32); inp["face_uvs"] = dr.face_uvs.numpy()[0]
+        fo = torch.from_numpy(oracle.render_forward(inp, S, S, no_mask, dr.cam_proj.numpy().reshape(3))[1]).to(dev)
+        f2b = dr.render(no_mask=no_mask, **A2)[1] and dr.last_face_idx
+        extra = ""
+        raise AssertionError("face_idx differs between the boundaries at %d pixels; first (b,y,x): %s; dibr %s; fused %s; vs the oracle: dibr %d, "
+                             "fused %d wrong pixels; fused rendered again: %d wrong"
+                             % (d.shape[0], d[:12].tolist(), f1[f1 != f2][:12].tolist(), f2[f1 != f2][:12].tolist(),
+                                int((f1 != fo).sum()), int((f2 != fo).sum()), int((f2b != fo).sum())) + extra)
     assert torch.equal(r1[:, 3], r2[:, 3].detach())                     # ... the soft mask too, bit for bit
     _close(r1, r2.detach().cpu().numpy(), 1e-6)
     w = torch.randn(B, dr.num_faces, 3, device=dev) * 1e-3

@@ -42,7 +42,31 @@ __global__ __launch_bounds__(256) void att_fwd_kernel(AttArgs a) {
     float part[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // the big ones, grid-strided (float4 where the pointers allow it is not worth the alignment cases: the launch is latency bound)
     float s = 0.f;
-    for (size_t i = gid; i < (size_t)a.B * a.T; i += gstride) s += att_term(a.p_te[i] - a.t_te[i], a.l1);
+    {
+        const size_t n = (size_t)a.B * a.T;
+        if ((n & 3) == 0 && ((((size_t)a.p_te) | ((size_t)a.t_te)) & 15) == 0) {          // 16-byte loads (torch tensors always qualify)
+            const float4* p4 = (const float4*)a.p_te; const float4* t4 = (const float4*)a.t_te;
+            const size_t n4 = n >> 2;
+            size_t i = gid;
+            for (; i + gstride < n4; i += 2 * gstride) {         // four 16-byte loads in flight per trip
+                const float4 p0 = p4[i], p1 = p4[i + gstride], t0 = t4[i], t1 = t4[i + gstride];
+                s += ((att_term(p0.x - t0.x, a.l1) + att_term(p0.y - t0.y, a.l1)) + att_term(p0.z - t0.z, a.l1)) + att_term(p0.w - t0.w, a.l1);
+                s += ((att_term(p1.x - t1.x, a.l1) + att_term(p1.y - t1.y, a.l1)) + att_term(p1.z - t1.z, a.l1)) + att_term(p1.w - t1.w, a.l1);
+            }
+            for (; i < n4; i += gstride) {
+                const float4 p0 = p4[i], t0 = t4[i];
+                s += ((att_term(p0.x - t0.x, a.l1) + att_term(p0.y - t0.y, a.l1)) + att_term(p0.z - t0.z, a.l1)) + att_term(p0.w - t0.w, a.l1);
+            }
+        } else {
+            size_t i = gid;
+            for (; i + 3 * gstride < n; i += 4 * gstride) {      // eight loads in flight per trip
+                const float p0 = a.p_te[i], p1 = a.p_te[i + gstride], p2 = a.p_te[i + 2 * gstride], p3 = a.p_te[i + 3 * gstride];
+                const float t0 = a.t_te[i], t1 = a.t_te[i + gstride], t2 = a.t_te[i + 2 * gstride], t3 = a.t_te[i + 3 * gstride];
+                s += att_term(p0 - t0, a.l1); s += att_term(p1 - t1, a.l1); s += att_term(p2 - t2, a.l1); s += att_term(p3 - t3, a.l1);
+            }
+            for (; i < n; i += gstride) s += att_term(a.p_te[i] - a.t_te[i], a.l1);
+        }
+    }
     part[5] = block_sum4(s, s_red);
     s = 0.f;
     for (size_t i = gid; i < (size_t)a.B * a.V * 3; i += gstride) s += att_term(a.p_ve[i] - a.t_ve[i], a.l1);
@@ -76,9 +100,19 @@ __global__ __launch_bounds__(256) void att_fwd_kernel(AttArgs a) {
         if (s_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (!s_last || tid >= 7) return;
+    if (!s_last) return;
+    // the last workgroup adds the partials up: rows strided over its 256 threads (seven agent-scope loads per row, all rows of a thread in
+    // flight together), then a fixed-order block reduction -- reproducible run to run.  (Seven threads walking the up to 1024 rows one
+    // dependent load after the other took 140 of this kernel's 155 us.)
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (unsigned i = tid; i < gridDim.x; i += 256) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[k] += __hip_atomic_load(a.partial + (size_t)i * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     float tot = 0.f;
-    for (unsigned i = 0; i < gridDim.x; ++i) tot += __hip_atomic_load(a.partial + (size_t)i * 8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { const float t = block_sum4(acc[k], s_red); if (k == tid) tot = t; }
+    if (tid >= 7) return;
     const float n[7] = {(float)a.B * 2.f, (float)a.B * 2.f, (float)a.B, (float)a.B * 2.f, (float)a.B * (float)a.V * 3.f,
                         (float)a.B * (float)a.T, (float)a.B * 9.f};
     a.losses[tid] = tot / n[tid];

@@ -144,12 +144,12 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
         int c = 0;
         if (tx0 < a.W && ty0 < a.H) {
             const uint64_t* row = a.binmask + ((size_t)b * a.nbx * a.nby + (size_t)(ty0 >> a.bin_shift) * a.nbx + (tx0 >> a.bin_shift)) * a.words;
-            for (int w0 = 0; w0 < a.words; w0 += 8) {             // eight loads in flight per trip
-                uint64_t r[8];
+            for (int w0 = 0; w0 < a.words; w0 += 24) {            // 24 loads in flight per trip: the 1 280-face templates' rows in ONE trip
+                uint64_t r[24];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) r[k] = (w0 + k < a.words) ? row[w0 + k] : 0ull;
+                for (int k = 0; k < 24; ++k) r[k] = (w0 + k < a.words) ? row[w0 + k] : 0ull;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) c += __popcll(r[k]);
+                for (int k = 0; k < 24; ++k) c += __popcll(r[k]);
             }
         }
         c = min(c, 1023);

@@ -56,6 +56,13 @@ __global__ __launch_bounds__(256) void mesh_reg_fwd_kernel(RegArgs a) {
     __shared__ float s_red[4];
     __shared__ int s_last;
     const int b = blockIdx.x, tid = threadIdx.x;
+    // four workgroups per image, each with its share of the eight terms (every term is a chain of dependent gathers + a block reduction:
+    // one workgroup doing all of them one after the other was 33 us of pure latency for 1.5 MB of operands)
+    const unsigned group = blockIdx.y == 0 ? (1u << MM_REG_LAPLACIAN)
+                         : blockIdx.y == 1 ? (1u << MM_REG_FLAT) | (1u << MM_REG_DEFORM)
+                         : blockIdx.y == 2 ? (1u << MM_REG_EDGE) | (1u << MM_REG_FLIP)
+                                           : (1u << MM_REG_DEPTH) | (1u << MM_REG_DEPTHR) | (1u << MM_REG_DEPTHC);
+    const unsigned terms = a.terms & group;
     const float* dv = a.delta ? a.delta + (size_t)b * a.V * 3 : nullptr;
     const float* vv = a.vertices ? a.vertices + (size_t)b * a.V * 3 : nullptr;
     const float* fn = a.fn ? a.fn + (size_t)b * a.F * 3 : nullptr;
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void mesh_reg_fwd_kernel(RegArgs a) {
 #pragma unroll
     for (int k = 0; k < MM_REG_TERMS; ++k) part[k] = 0.f;
 
-    if (a.terms & (1u << MM_REG_LAPLACIAN)) {
+    if (terms & (1u << MM_REG_LAPLACIAN)) {
         float s = 0.f;
         for (int v = tid; v < a.V; v += 256) {
             float y0 = 0.f, y1 = 0.f, y2 = 0.f;
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void mesh_reg_fwd_kernel(RegArgs a) {
         }
         part[MM_REG_LAPLACIAN] = block_sum(s, s_red);
     }
-    if (a.terms & (1u << MM_REG_FLAT)) {
+    if (terms & (1u << MM_REG_FLAT)) {
         float s = 0.f;
         for (int e = tid; e < a.E; e += 256) {
             const float* n1 = fn + (size_t)a.edge2faces[e * 2] * 3;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void mesh_reg_fwd_kernel(RegArgs a) {
         }
         part[MM_REG_FLAT] = block_sum(s, s_red);
     }
-    if (a.terms & (1u << MM_REG_EDGE)) {
+    if (terms & (1u << MM_REG_EDGE)) {
         float s = 0.f;
         for (int e = tid; e < a.E; e += 256) {
             const float* p = vv + (size_t)a.edges[e * 2] * 3;
@@ -114,19 +121,19 @@ __global__ __launch_bounds__(256) void mesh_reg_fwd_kernel(RegArgs a) {
             const float x = vv[v * 3], y = vv[v * 3 + 1], z = vv[v * 3 + 2];
             s0 += z * z;
             const float zs = z - (a.sign_init[v] >= 0.f ? a.eps : -a.eps);          // (:472, :483) keeps the side of the plane
-            if (a.terms & (1u << MM_REG_DEPTHR)) s1 += (zs * zs) * depth_weight(a, MM_REG_DEPTHR, x, y);
-            if (a.terms & (1u << MM_REG_DEPTHC)) s2 += (zs * zs) * depth_weight(a, MM_REG_DEPTHC, x, y);
+            if (terms & (1u << MM_REG_DEPTHR)) s1 += (zs * zs) * depth_weight(a, MM_REG_DEPTHR, x, y);
+            if (terms & (1u << MM_REG_DEPTHC)) s2 += (zs * zs) * depth_weight(a, MM_REG_DEPTHC, x, y);
         }
-        if (a.terms & (1u << MM_REG_DEPTH)) part[MM_REG_DEPTH] = block_sum(s0, s_red);
-        if (a.terms & (1u << MM_REG_DEPTHR)) part[MM_REG_DEPTHR] = block_sum(s1, s_red);
-        if (a.terms & (1u << MM_REG_DEPTHC)) part[MM_REG_DEPTHC] = block_sum(s2, s_red);
+        if (terms & (1u << MM_REG_DEPTH)) part[MM_REG_DEPTH] = block_sum(s0, s_red);
+        if (terms & (1u << MM_REG_DEPTHR)) part[MM_REG_DEPTHR] = block_sum(s1, s_red);
+        if (terms & (1u << MM_REG_DEPTHC)) part[MM_REG_DEPTHC] = block_sum(s2, s_red);
     }
-    if (a.terms & (1u << MM_REG_DEFORM)) {
+    if (terms & (1u << MM_REG_DEFORM)) {
         float s = 0.f;
         for (int v = tid; v < a.V; v += 256) s += sqrtf((dv[v * 3] * dv[v * 3] + dv[v * 3 + 1] * dv[v * 3 + 1]) + dv[v * 3 + 2] * dv[v * 3 + 2]);
         part[MM_REG_DEFORM] = block_sum(s, s_red);
     }
-    if (a.terms & (1u << MM_REG_FLIP)) {
+    if (terms & (1u << MM_REG_FLIP)) {
         float s = 0.f;
         for (int v = tid; v < a.V; v += 256) {
             const int u = a.flip_index[v];
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256) void mesh_reg_fwd_kernel(RegArgs a) {
 
     // per-image partial sums -> the last workgroup to arrive adds them up in image order.  Agent-scope atomic stores / loads
     // and a returning ticket: no L2-wide fence (see vertex_bwd).
-    if (tid < MM_REG_TERMS) {
+    if (tid < MM_REG_TERMS && (group >> tid & 1u)) {
         float mine = 0.f;
 #pragma unroll
         for (int k = 0; k < MM_REG_TERMS; ++k) if (k == tid) mine = part[k];
@@ -152,13 +159,26 @@ __global__ __launch_bounds__(256) void mesh_reg_fwd_kernel(RegArgs a) {
     __syncthreads();
     if (tid == 0) {
         const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == gridDim.x - 1;
+        s_last = prev == gridDim.x * gridDim.y - 1;
         if (s_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
     }
     __syncthreads();
-    if (!s_last || tid >= MM_REG_TERMS) return;
+    if (!s_last) return;
+    // the partials of all images, fetched by all threads at once (image = thread index, 256 per pass), parked in LDS and added up by one
+    // thread per term in image order: bitwise reproducible, one trip to memory instead of B
+    __shared__ float s_part[256][MM_REG_TERMS + 1];
     float tot = 0.f;
-    for (int i = 0; i < a.B; ++i) tot += __hip_atomic_load(a.partial + i * MM_REG_TERMS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i0 = 0; i0 < a.B; i0 += 256) {
+        if (i0 + tid < a.B) {
+#pragma unroll
+            for (int k = 0; k < MM_REG_TERMS; ++k)
+                s_part[tid][k] = __hip_atomic_load(a.partial + (size_t)(i0 + tid) * MM_REG_TERMS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid < MM_REG_TERMS) for (int i = 0; i < 256 && i0 + i < a.B; ++i) tot += s_part[i][tid];
+        __syncthreads();
+    }
+    if (tid >= MM_REG_TERMS) return;
     const float fb = (float)a.B, fbv = (float)a.B * (float)a.V;
     float out = 0.f;
     if (tid == MM_REG_LAPLACIAN || tid == MM_REG_FLAT) out = tot / fb;       // mean(.)*V*3 and mean(.)*E
@@ -300,7 +320,7 @@ static RegArgs reg_args(const MMMeshRegDesc* d) {
 
 int launch_reg_fwd(const MMMeshRegDesc* d, hipStream_t s) {
     RegArgs a = reg_args(d);
-    hipLaunchKernelGGL(mesh_reg_fwd_kernel, dim3(d->B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mesh_reg_fwd_kernel, dim3(d->B, 4), dim3(256), 0, s, a);
     return launch_ok("mesh_reg_fwd");
 }
 

@@ -53,24 +53,55 @@ __device__ inline Taps flow_taps(const TexFlowArgs& a, int b, int oy, int ox) {
     return t;
 }
 
+// The sixteen taps of a channel are loaded UNCONDITIONALLY from clamped (always valid) addresses and masked afterwards: a tap inside a
+// per-lane `if (in bounds)` is a branch + wait of its own, i.e. up to 48 dependent trips to memory per texel instead of one.
+__device__ inline void tap_window(const TexFlowArgs& a, const Taps& t, int (&xs)[4], int (&ys)[4], bool (&inx)[4], bool (&iny)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = t.x0 + j, y = t.y0 + j;
+        inx[j] = x >= 0 && x < a.W; iny[j] = y >= 0 && y < a.H;
+        xs[j] = min(max(x, 0), a.W - 1); ys[j] = min(max(y, 0), a.H - 1);
+    }
+}
+
+// the four x taps of one row: ONE 16-byte load (4-byte aligned: gfx950 global loads need no more) of the window clamped into the row, the
+// taps picked out of it; a tap outside the image is masked by the caller.  Rows narrower than four texels take four scalar loads.
+struct __attribute__((packed, aligned(4))) Row4 { float v[4]; };
+__device__ inline void load_row(const float* row, int W, int x0, const int (&xs)[4], float (&v)[4]) {
+    if (W >= 4) {
+        const int xw = min(max(x0, 0), W - 4), sh = x0 - xw;     // tap j sits at window slot j + sh (in 0..3 whenever the tap is inside)
+        const Row4 r = *(const Row4*)(row + xw);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = j + sh;
+            v[j] = k <= 0 ? r.v[0] : (k == 1 ? r.v[1] : (k == 2 ? r.v[2] : r.v[3]));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = row[xs[j]];
+    }
+}
+
 __global__ __launch_bounds__(256) void texflow_fwd_kernel(TexFlowArgs a) {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
     if (ox >= a.Wo || oy >= a.Ho) return;
     const Taps t = flow_taps(a, b, oy, ox);
+    int xs[4], ys[4];
+    bool inx[4], iny[4];
+    tap_window(a, t, xs, ys, inx, iny);
     const size_t oplane = (size_t)2 * a.Ho * a.Wo;
     for (int c = 0; c < a.C; ++c) {
         const float* img = a.image + ((size_t)b * a.C + c) * a.H * a.W;
+        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_row(img + (size_t)ys[i] * a.W, a.W, t.x0, xs, v[i]);
         float rows[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int y = t.y0 + i;
-            float v[4];
+            float w[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int x = t.x0 + j;
-                v[j] = (x >= 0 && x < a.W && y >= 0 && y < a.H) ? img[(size_t)y * a.W + x] : 0.f;
-            }
-            rows[i] = ((v[0] * t.cx[0] + v[1] * t.cx[1]) + v[2] * t.cx[2]) + v[3] * t.cx[3];
+            for (int j = 0; j < 4; ++j) w[j] = (inx[j] && iny[i]) ? v[i][j] : 0.f;
+            rows[i] = ((w[0] * t.cx[0] + w[1] * t.cx[1]) + w[2] * t.cx[2]) + w[3] * t.cx[3];
         }
         const float out = ((rows[0] * t.cy[0] + rows[1] * t.cy[1]) + rows[2] * t.cy[2]) + rows[3] * t.cy[3];
         float* o = a.textures + ((size_t)b * a.C + c) * oplane;
@@ -87,22 +118,25 @@ __global__ __launch_bounds__(256) void texflow_bwd_kernel(TexFlowArgs a) {
     cubic_coeffs_grad(t.tx, dx); cubic_coeffs_grad(t.ty, dy);
     const size_t oplane = (size_t)2 * a.Ho * a.Wo;
     float gix = 0.f, giy = 0.f;
+    int xs[4], ys[4];
+    bool inx[4], iny[4];
+    tap_window(a, t, xs, ys, inx, iny);
     for (int c = 0; c < a.C; ++c) {
         const float* g = a.g_tex + ((size_t)b * a.C + c) * oplane;
         const float go = g[(size_t)oy * a.Wo + ox] + g[(size_t)(2 * a.Ho - 1 - oy) * a.Wo + ox];      // both mirrored rows
         const float* img = a.image + ((size_t)b * a.C + c) * a.H * a.W;
         float* gi = a.g_image ? a.g_image + ((size_t)b * a.C + c) * a.H * a.W : nullptr;
+        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_row(img + (size_t)ys[i] * a.W, a.W, t.x0, xs, v[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int y = t.y0 + i;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int x = t.x0 + j;
-                if (x >= 0 && x < a.W && y >= 0 && y < a.H) {
-                    const float v = img[(size_t)y * a.W + x];
-                    gix += go * v * (dx[j] * t.cy[i]);
-                    giy += go * v * (t.cx[j] * dy[i]);
-                    if (gi) atomicAdd(gi + (size_t)y * a.W + x, go * (t.cx[j] * t.cy[i]));
+                if (inx[j] && iny[i]) {
+                    gix += go * v[i][j] * (dx[j] * t.cy[i]);
+                    giy += go * v[i][j] * (t.cx[j] * dy[i]);
+                    if (gi) atomicAdd(gi + (size_t)ys[i] * a.W + xs[j], go * (t.cx[j] * t.cy[i]));
                 }
             }
         }

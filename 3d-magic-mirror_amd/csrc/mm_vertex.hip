@@ -51,6 +51,16 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nltot; i += gridDim.x * gridDim.y * 256) a.ltot[i] = 0;
     MM_PP_MARK(0);
+    // this lane's face: its corner ids and their raw positions depend on nothing the camera produces -- both trips to memory are in
+    // flight while four lanes do the fp64 trigonometry and one builds the look-at
+    const int f = blockIdx.x * 256 + tid;
+    float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f}, pc[3] = {0.f, 0.f, 0.f};
+    if (f < a.F) {
+        const int i0 = a.faces[f * 3 + 0], i1 = a.faces[f * 3 + 1], i2 = a.faces[f * 3 + 2];
+        const float* vb = a.vertices + (size_t)b * a.V * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
+    }
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
     MM_PP_MARK(1);
     if (blockIdx.x == 0 && tid < 12) a.T[b * 12 + tid] = s_cam.T[tid];
@@ -59,14 +69,11 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_cam.T[i];
 
-    const int f = blockIdx.x * 256 + tid;
     int bx0 = 0, by0 = 0, bw = 0, bh = 0;                         // inflated pixel box of this lane's face (none)
     if (f < a.F) {
-    const int i0 = a.faces[f * 3 + 0], i1 = a.faces[f * 3 + 1], i2 = a.faces[f * 3 + 2];
-    const float* vb = a.vertices + (size_t)b * a.V * 3;
-    const Float3 A = to_camera(vb + (size_t)i0 * 3, T);
-    const Float3 Bv = to_camera(vb + (size_t)i1 * 3, T);
-    const Float3 C = to_camera(vb + (size_t)i2 * 3, T);
+    const Float3 A = to_camera(pa, T);
+    const Float3 Bv = to_camera(pb, T);
+    const Float3 C = to_camera(pc, T);
     // perspective_camera: (x*px)/(z*pz), then x multiplier (kaolin rasterises in multiplier units)
     const float apz = A.z * a.proj2, bpz = Bv.z * a.proj2, cpz = C.z * a.proj2;
     const float ax = ((A.x * a.proj0) / apz) * a.mult, ay = ((A.y * a.proj1) / apz) * a.mult;

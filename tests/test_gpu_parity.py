@@ -214,6 +214,20 @@ def test_backward_twice_after_one_forward(pkg):
         assert float(first[k].abs().max()) > 0
 
 
+def test_backward_is_bitwise_reproducible(pkg):
+    """No floating-point atomic anywhere in the backward (integer fixed point in LDS, fixed-order sums): the same step twice gives the
+    same bits for all eight gradients, at the headline size."""
+    grads = []
+    for _ in range(2):
+        dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 48, 128, seed=0, imn=False)
+        rgbs, _ = dr.render(no_mask=True, **datt)
+        dr.recon_data(rgbs, gt.to(dev), no_mask=True).backward()
+        grads.append({k: datt[k].grad.clone() for k in LEAVES})
+    for k in LEAVES:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+        assert float(grads[0][k].abs().max()) > 0
+
+
 def test_recon_data_matches_reference_golden(pkg):
     z = np.load(os.path.join(GOLDEN, "losses.npz"))
     dev = torch.device("cuda:0")

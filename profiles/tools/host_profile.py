@@ -3,7 +3,8 @@ import sys, importlib, cProfile, pstats, torch
 sys.path.insert(0, '/root/repo')
 pkg = importlib.import_module("3d-magic-mirror_amd")
 dev = torch.device("cuda:0")
-dr = pkg.DiffRender("/root/repo/tests/golden/templates/smpl_uv_642.npz", 128, emit_imnormal=False)
+import os
+dr = pkg.DiffRender("/root/repo/tests/golden/templates/smpl_uv_642.npz", 128, emit_imnormal=bool(int(os.environ.get("MM_IMNORMAL", "0"))))
 att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, 48, 128, 128)
 datt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}; gtd = gt.to(dev)
 LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "distances", "biases")
@@ -18,4 +19,4 @@ torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(200): one()
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(18)

@@ -8,6 +8,7 @@ int launch_vertex_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_vertex_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
 int launch_raster_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_raster_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
+int launch_fused_loss(const MMRenderDesc*, const Workspace&, hipStream_t);
 size_t recon_workspace_bytes(const MMReconDesc*);
 int launch_recon_fwd(const MMReconDesc*, hipStream_t);
 int launch_recon_bwd(const MMReconDesc*, hipStream_t);
@@ -52,6 +53,15 @@ int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
     st = mm::launch_vertex_fwd(d, w, s);
     if (st != MM_OK) return st;
     return mm::launch_raster_fwd(d, w, s);      // tile order + raster
+}
+
+int mm_render_fused_loss(const MMRenderDesc* d, mm_stream_t stream) {
+    int st = check_render(d, false);
+    if (st != MM_OK) return st;
+    if (!d->fused_gt || !d->fused_loss) return MM_ERR_NULL_POINTER;
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt);
+    mm::clear_stale_error();
+    return mm::launch_fused_loss(d, w, (hipStream_t)stream);
 }
 
 int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {

@@ -696,6 +696,20 @@ __global__ __launch_bounds__(256, MM_GATHER_LB) void gather_bwd_kernel(BwdArgs a
     MM_TIMELINE_END(gather_bwd);
 }
 
+// the fused recon_data value on its own (mm_render_fused_loss): the same fixed-order sum over images the gather kernel's last
+// workgroup performs, for callers that need the loss before the backward
+__global__ __launch_bounds__(64) void fused_loss_kernel(const long long* ltot, int B, int H, int W, float image_weight, float* loss) {
+    float l1 = 0.f, iou = 0.f;
+    for (int bb = threadIdx.x; bb < B; bb += 64) { float s0, s1, s2; loss_totals(ltot, bb, s0, s1, s2); l1 += s0; iou += s1 / (s2 + 1e-10f); }
+    l1 = wave_sum(l1); iou = wave_sum(iou);
+    if (threadIdx.x == 0) loss[0] = image_weight * (l1 / ((float)B * 3.f * (float)H * (float)W)) + 1.f * (1.f - iou / (float)B);
+}
+
+int launch_fused_loss(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
+    hipLaunchKernelGGL(fused_loss_kernel, dim3(1), dim3(64), 0, s, w.ltot, d->B, d->H, d->W, d->fused_image_weight, d->fused_loss);
+    return launch_ok("fused_loss");
+}
+
 int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
     BwdArgs a;
     a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.Ht = d->Ht; a.Wt = d->Wt; a.knum = d->knum;

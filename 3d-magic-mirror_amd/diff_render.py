@@ -36,71 +36,99 @@ class _PooledWorkspace(object):
             pass
 
 
+def _render_inputs(dr, no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases):
+    """fp32 dense device tensors + the shape checks of the render boundary (shared by render and render_recon)."""
+    N.require_device(vertices, textures, lights, bg, azimuths, elevations, distances, biases)
+    dev = azimuths.device
+    f32 = lambda t: N.as_f32(t, dev)
+    vertices, textures, lights, bg = f32(vertices), f32(textures), f32(lights), f32(bg)
+    azimuths, elevations, distances, biases = f32(azimuths).reshape(-1), f32(elevations).reshape(-1), f32(distances).reshape(-1), f32(biases)
+    B = azimuths.shape[0]
+    H, W = dr.render_height, dr.image_size
+    if vertices.shape != (B, dr.num_vertices, 3):
+        raise RuntimeError("vertices must be (B,%d,3), got %s" % (dr.num_vertices, tuple(vertices.shape)))
+    if textures.dim() != 4 or textures.shape[0] != B or textures.shape[1] != 3:
+        raise RuntimeError("textures must be (B,3,Ht,Wt), got %s" % (tuple(textures.shape),))
+    if lights.shape != (B, 9) or biases.shape != (B, 2) or elevations.shape[0] != B or distances.shape[0] != B:
+        raise RuntimeError("lights (B,9), biases (B,2), elevations/distances (B) expected")
+    if no_mask:
+        if bg is None:
+            raise TypeError("render(no_mask=True) needs attributes['bg'] (B,3,H,W)")   # reference: None.permute fails
+        if bg.shape != (B, 3, H, W):
+            raise RuntimeError("bg must be (B,3,%d,%d), got %s" % (H, W, tuple(bg.shape)))
+    return dev, B, H, W, vertices, textures, lights, bg, azimuths, elevations, distances, biases
+
+
 class _RenderFn(torch.autograd.Function):
-    """rgba (B,H,W,4), face_normals (B,F,3), imnormal (B,H,W,3), face_idx (B,H,W) = render(attributes)."""
+    """rgba (B,H,W,4), face_normals (B,F,3), imnormal (B,H,W,3), face_idx (B,H,W) = render(attributes).
+    With ``gt`` (B,4,H,W): the recon_data loss of the batch is folded into the same kernels (MMRenderDesc.fused_*) and returned as a
+    fifth output; the image is then an output without gradient (its only consumer, the loss, is already inside)."""
 
     @staticmethod
-    def forward(ctx, dr, no_mask, want_imnormal, vertices, textures, lights, bg, azimuths, elevations, distances, biases):
-        N.require_device(vertices, textures, lights, bg, azimuths, elevations, distances, biases)
-        dev = azimuths.device
-        f32 = lambda t: N.as_f32(t, dev)
-        vertices, textures, lights, bg = f32(vertices), f32(textures), f32(lights), f32(bg)
-        azimuths, elevations, distances, biases = f32(azimuths).reshape(-1), f32(elevations).reshape(-1), f32(distances).reshape(-1), f32(biases)
-        B = azimuths.shape[0]
-        H, W = dr.render_height, dr.image_size
+    def forward(ctx, dr, no_mask, want_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases):
+        dev, B, H, W, vertices, textures, lights, bg, azimuths, elevations, distances, biases = _render_inputs(
+            dr, no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases)
         st = dr._static(dev)
-        if vertices.shape != (B, dr.num_vertices, 3):
-            raise RuntimeError("vertices must be (B,%d,3), got %s" % (dr.num_vertices, tuple(vertices.shape)))
-        if textures.dim() != 4 or textures.shape[0] != B or textures.shape[1] != 3:
-            raise RuntimeError("textures must be (B,3,Ht,Wt), got %s" % (tuple(textures.shape),))
-        if lights.shape != (B, 9) or biases.shape != (B, 2) or elevations.shape[0] != B or distances.shape[0] != B:
-            raise RuntimeError("lights (B,9), biases (B,2), elevations/distances (B) expected")
-        if no_mask:
-            if bg is None:
-                raise TypeError("render(no_mask=True) needs attributes['bg'] (B,3,H,W)")   # reference: None.permute fails
-            if bg.shape != (B, 3, H, W):
-                raise RuntimeError("bg must be (B,3,%d,%d), got %s" % (H, W, tuple(bg.shape)))
         rgba = torch.empty((B, H, W, 4), device=dev, dtype=torch.float32)
         face_idx = torch.empty((B, H, W), device=dev, dtype=torch.int32)
         fn = torch.empty((B, dr.num_faces, 3), device=dev, dtype=torch.float32)
         imn = torch.empty((B, H, W, 3), device=dev, dtype=torch.float32) if want_imnormal else None
         d = dr._desc(st, B, no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases, rgba, face_idx, fn, imn)
+        loss = None
+        if gt is not None:
+            N.require_device(gt)
+            gt = N.as_f32(gt, dev)
+            if gt.shape != (B, 4, H, W):
+                raise RuntimeError("gt_data must be (B,4,%d,%d), got %s" % (H, W, tuple(gt.shape)))
+            loss = torch.empty((), device=dev, dtype=torch.float32)
+            d.fused_gt, d.fused_image_weight, d.fused_loss = N.ptr(gt), float(dr.image_weight), N.ptr(loss)
         nbytes = N.lib().mm_query_workspace(ctypes.byref(d))
         holder = _PooledWorkspace(dr._ws_pool, (str(dev), nbytes), nbytes, dev)
         ws = holder.buf
         d.workspace, d.workspace_bytes = N.ptr(ws), ws.numel()
         N.check(N.lib().mm_render_forward(ctypes.byref(d), N.current_stream(dev)), "mm_render_forward")
-        ctx.dr, ctx.no_mask = dr, bool(no_mask)
+        if gt is not None:
+            N.check(N.lib().mm_render_fused_loss(ctypes.byref(d), N.current_stream(dev)), "mm_render_fused_loss")
+        ctx.dr, ctx.no_mask, ctx.fused = dr, bool(no_mask), gt is not None
         ctx.ws_holder = holder                                   # returned to the pool when this node dies
-        ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn)
+        ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt,
+                              rgba if gt is not None else None)   # (the fused backward re-reads the prediction)
         ctx.mark_non_differentiable(face_idx)
         if imn is None:
             imn = torch.empty(0, device=dev)
         ctx.mark_non_differentiable(imn)
-        return rgba, fn, imn, face_idx
+        if gt is None:
+            return rgba, fn, imn, face_idx
+        ctx.mark_non_differentiable(rgba)
+        return rgba, fn, imn, face_idx, loss
 
     @staticmethod
-    def backward(ctx, g_rgba, g_fn, _g_imn, _g_idx):
-        vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn = ctx.saved_tensors
+    def backward(ctx, g_rgba, g_fn, _g_imn, _g_idx, g_loss=None):
+        vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt, rgba_fwd = ctx.saved_tensors
         ws = ctx.ws_holder.buf
         dr, dev = ctx.dr, azimuths.device
         B = azimuths.shape[0]
         H, W = dr.render_height, dr.image_size
         st = dr._static(dev)
-        if g_rgba is None:
-            g_rgba = torch.zeros((B, H, W, 4), device=dev, dtype=torch.float32)
-        g_rgba = g_rgba.to(torch.float32).contiguous()
         g_fn = None if g_fn is None else g_fn.to(torch.float32).contiguous()
         rgba_dummy = torch.empty(0, device=dev)
         d = dr._desc(st, B, ctx.no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases, rgba_dummy, face_idx, fn, None)
-        d.rgba = N.ptr(g_rgba)          # not read by the backward; any valid pointer satisfies the NULL check
+        if ctx.fused:
+            g_loss = torch.ones((), device=dev) if g_loss is None else g_loss.to(torch.float32).reshape(()).contiguous()
+            d.fused_gt, d.fused_image_weight, d.fused_grad_loss = N.ptr(gt), float(dr.image_weight), N.ptr(g_loss)
+            d.rgba = N.ptr(rgba_fwd)    # the forward's image: the fused backward forms dL/drgba from it and gt
+        else:
+            if g_rgba is None:
+                g_rgba = torch.zeros((B, H, W, 4), device=dev, dtype=torch.float32)
+            g_rgba = g_rgba.to(torch.float32).contiguous()
+            d.rgba = N.ptr(g_rgba)      # not read by the backward; any valid pointer satisfies the NULL check
         d.workspace, d.workspace_bytes = N.ptr(ws), ws.numel()
-        gv, gt, gl = torch.empty_like(vertices), torch.empty_like(textures), torch.empty_like(lights)
+        gv, gt_, gl = torch.empty_like(vertices), torch.empty_like(textures), torch.empty_like(lights)
         gbg = torch.empty_like(bg) if ctx.no_mask else None
         ga, ge, gd, gb = torch.empty_like(azimuths), torch.empty_like(elevations), torch.empty_like(distances), torch.empty_like(biases)
-        g = N.MMRenderGrads(N.ptr(g_rgba), N.ptr(g_fn), N.ptr(gv), N.ptr(gt), N.ptr(gl), N.ptr(gbg), N.ptr(ga), N.ptr(ge), N.ptr(gd), N.ptr(gb))
+        g = N.MMRenderGrads(None if ctx.fused else N.ptr(g_rgba), N.ptr(g_fn), N.ptr(gv), N.ptr(gt_), N.ptr(gl), N.ptr(gbg), N.ptr(ga), N.ptr(ge), N.ptr(gd), N.ptr(gb))
         N.check(N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), N.current_stream(dev)), "mm_render_backward")
-        return None, None, None, gv, gt, gl, gbg, ga, ge, gd, gb
+        return None, None, None, None, gv, gt_, gl, gbg, ga, ge, gd, gb
 
 
 class _ReconFn(torch.autograd.Function):
@@ -248,13 +276,26 @@ class DiffRender(object):
         vertices = attributes['vertices']
         textures = attributes['textures']
         lights = attributes['lights']
-        rgba, fn, imn, face_idx = _RenderFn.apply(self, bool(no_mask), self.emit_imnormal, vertices, textures, lights,
+        rgba, fn, imn, face_idx = _RenderFn.apply(self, bool(no_mask), self.emit_imnormal, None, vertices, textures, lights,
                                                   bg if no_mask else None, azimuths, elevations, distances, biases)
         rgbs = rgba.permute(0, 3, 1, 2)                 # (B,4,H,W) view of NHWC memory, like networks.py:317
         attributes['face_normals'] = fn
         attributes['imnormal'] = imn if self.emit_imnormal else None
         self.last_face_idx = face_idx                   # kaolin returns it from dibr_rasterization; the reference drops it
         return rgbs, attributes
+
+    def render_recon(self, gt_data, no_mask=False, **attributes):
+        """render(**attributes) and recon_data(rendered, gt_data, no_mask) (contour = 0) in ONE pass over the pixels: the loss terms
+        are reduced while the image is shaded and its gradient is formed inside the backward kernels (no loss launches, no dL/drgba
+        round trip) -- the path bench.py's `value` times, reachable from the class API.  Returns (loss, rgbs, attributes); ``rgbs``
+        carries no gradient here (use render + recon_data if the image feeds anything else that is differentiated)."""
+        a = attributes
+        rgba, fn, imn, face_idx, loss = _RenderFn.apply(self, bool(no_mask), self.emit_imnormal, gt_data, a['vertices'], a['textures'], a['lights'],
+                                                        a['bg'] if no_mask else None, a['azimuths'], a['elevations'], a['distances'], a['biases'])
+        attributes['face_normals'] = fn
+        attributes['imnormal'] = imn if self.emit_imnormal else None
+        self.last_face_idx = face_idx
+        return loss, rgba.permute(0, 3, 1, 2), attributes
 
     # ---- networks.py:364-390 -------------------------------------------------------------------------------------
     def recon_data(self, pred_data, gt_data, no_mask=False, contour=0):

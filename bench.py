@@ -14,6 +14,7 @@ What the ONE JSON line (rank 0) reports, all on the same workload:
                     (the reference's trainer issues four renders per iteration, trainer.py:276,345,347,367) and their kernels overlap.
                     This is the whole-job throughput of the C-ABI path when the caller keeps several batches in flight.
   value_one_stream  the same K steps strictly one after the other on ONE stream: what a caller gets who renders one batch at a time.
+  value_api_fused   the same step through DiffRender.render_recon (autograd API, loss folded into the render kernels like in `value`)
   value_api         DiffRender.render -> DiffRender.recon_data -> loss.backward() through the torch.autograd wrappers (the calls
                     trainer.py makes), one stream, imnormal materialised like the reference does.
 Every stream rotates through --rotate distinct synthetic batches (default 8 per stream: > 256 MiB of inputs in total, more than
@@ -249,6 +250,14 @@ def main():
         rgbs, _ = dr_api.render(no_mask=True, **a)
         dr_api.recon_data(rgbs, batches[0][k][1], no_mask=True).backward()
 
+    def one_api_fused():                                         # the same step through DiffRender.render_recon (loss folded into the render kernels)
+        k = ctr2[0] % nrot; ctr2[0] += 1
+        lv = leaves_rot[k]
+        for v in lv.values():
+            v.grad = None
+        a = dict(batches[0][k][0]); a.update(lv)
+        dr_api.render_recon(batches[0][k][1], no_mask=True, **a)[0].backward()
+
     if args.mode == "hipgraph":
         step.capture()
         one = step.replay
@@ -273,7 +282,7 @@ def main():
         reducer.wait(); torch.cuda.synchronize(dev)
     loss_value = float(step.loss) if args.mode != "torch" else None
 
-    one_stream = api_value = allreduce_ms = None
+    one_stream = api_value = api_fused_value = allreduce_ms = None
     if args.mode == "eager":
         for _ in range(min(args.warmup, 20)):
             one_single()
@@ -284,6 +293,10 @@ def main():
             one_api()
         e2 = timed(one_api, args.api_steps)
         api_value = round(world * B * args.api_steps / e2, 1)
+        for _ in range(10):
+            one_api_fused()
+        e2f = timed(one_api_fused, args.api_steps)
+        api_fused_value = round(world * B * args.api_steps / e2f, 1)
     if reducer is not None:
         # the collective alone (nothing to overlap with): K reductions back to back
         reducer.wait(); torch.cuda.synchronize(dev)
@@ -397,7 +410,7 @@ def main():
                        "grad_allreduce": None if reducer is None else
                                          {"mb_per_step_per_rank": round(reducer.bytes_per_step() / 1e6, 1), "per_step": True, "overlapped": True,
                                           "launched": reducer.launched, "alone_ms": allreduce_ms}},
-            "value_one_stream": one_stream, "value_api": api_value,
+            "value_one_stream": one_stream, "value_api": api_value, "value_api_fused": api_fused_value,
             "value_config3": None if not config3 else config3.get("images_per_s"), "config3": config3,
             "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},
             "loss": loss_value,

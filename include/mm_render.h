@@ -128,6 +128,10 @@ typedef struct MMRenderGrads {
 size_t mm_query_workspace(const MMRenderDesc* desc);
 int mm_render_forward(const MMRenderDesc* desc, mm_stream_t stream);
 int mm_render_backward(const MMRenderDesc* desc, const MMRenderGrads* grads, mm_stream_t stream);
+/* Fused mode only (desc->fused_gt and desc->fused_loss set), after mm_render_forward: writes the recon_data value of the batch
+ * (networks.py:364-390, contour = 0) to desc->fused_loss from the sums the forward left in the workspace -- for callers that need
+ * the loss before they run the backward (the autograd API DiffRender.render_recon).  mm_render_backward writes the same value. */
+int mm_render_fused_loss(const MMRenderDesc* desc, mm_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------------------------------
  * Reconstruction loss: replaces DiffRender.recon_data (networks.py:364-390) incl. kaolin mask_iou (:377) and the

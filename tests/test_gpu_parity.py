@@ -228,6 +228,25 @@ def test_backward_is_bitwise_reproducible(pkg):
         assert float(grads[0][k].abs().max()) > 0
 
 
+def test_render_recon_is_render_plus_recon_data(pkg):
+    """DiffRender.render_recon = render + recon_data with the loss folded into the render kernels: same value, same gradients."""
+    got = []
+    for fused in (False, True):
+        dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 6, 96, seed=31)
+        if fused:
+            loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=True, **datt)
+            assert not rgbs.requires_grad
+        else:
+            rgbs, out = dr.render(no_mask=True, **datt)
+            loss = dr.recon_data(rgbs, gt.to(dev), no_mask=True)
+        (2.5 * loss).backward()
+        got.append((float(loss), rgbs.detach().clone(), {k: datt[k].grad.clone() for k in LEAVES}))
+    assert abs(got[0][0] - got[1][0]) < 2e-6 and torch.equal(got[0][1], got[1][1])
+    for k in LEAVES:
+        _close(got[1][2][k].cpu().numpy(), got[0][2][k].cpu().numpy(), 2e-5)
+        assert float(got[1][2][k].abs().max()) > 0
+
+
 def test_recon_data_matches_reference_golden(pkg):
     z = np.load(os.path.join(GOLDEN, "losses.npz"))
     dev = torch.device("cuda:0")

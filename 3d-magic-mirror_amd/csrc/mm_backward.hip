@@ -645,9 +645,13 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     SweepStage* st = &s_stage[wave];
     const long long wid = (long long)block * 4 + wave;            // wave index over (item octet, image)
     const int b = (int)(wid % a.B);
-    const int item = (int)(wid / a.B) * MM_FPW + grp;
     const int2 ni = a.nitems[b];                                  // items of the image, pixels per chunk
-    if ((int)(wid / a.B) * MM_FPW >= ni.x) return;                // wave-uniform: the image has fewer items (the grid is sized for the cap)
+    // The image's items are dealt to its waves ROUND-ROBIN (wave w takes items w, w + nw, w + 2 nw, ...): the chunks of a close-up face are
+    // consecutive items, most of their pixels owned, and a wave holding eight of them in a row (a thousand hits, sixteen dependent rounds
+    // of hit loads) was the tail of this kernel; spread out, every wave gets at most one or two of them.
+    const int w_img = (int)(wid / a.B), nw = (ni.x + MM_FPW - 1) / MM_FPW;
+    if (w_img >= nw) return;                                      // wave-uniform: the image has fewer items (the grid is sized for the cap)
+    const int item = grp * nw + w_img;
     const bool live = item < ni.x;
     const int2 e = a.items[(size_t)b * a.item_cap + (live ? item : 0)];      // face, chunk
     const size_t o = (size_t)b * a.F + e.x;

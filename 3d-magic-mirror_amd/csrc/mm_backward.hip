@@ -48,10 +48,91 @@ struct BwdArgs {
     const long long* ltot;                                       // (B,MM_LSUB,4) fused loss sums of the raster waves (fixed point)
     // gather
     unsigned* gmax;                                              // (B,2) per image: max |K2 number| and max |dL/dalpha| as float bits (pixel pass -> gather)
-    const int2* items; const int2* nitems; float* part; int item_cap;   // sweep items {face, chunk} of the plan kernel; their partial sums
+    const int2* items; const int2* nitems; float* part; int item_cap;   // sweep items {face, chunk} of the plan workgroups; their partial sums
+    int2* plan_chunkmap; int2* plan_items; int2* plan_nitems; int plan_wgs;           // ... as the plan workgroups (first B of pixel_bwd's grid) write them
     int ntx, nty;
     float* grad_textures;
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 0. plan of the face sweep (the first MM_PLAN_WGS * B workgroups of pixel_bwd's grid; nothing in the pixel pass depends on it and the
+//    gather launch behind it finds it done): every face's inflated pixel box cut into chunks of MM_CHUNK_PX pixels, numbered in face
+//    order by an exclusive scan of the chunk counts.  Thread t owns the contiguous faces [t*per, (t+1)*per): it adds up their counts, ONE
+//    block scan gives its first item, and it numbers its faces' chunks from there.  Should the items run out (more than sixteen screens'
+//    worth of box pixels in one image), the image's chunk size doubles until they fit (item_cap >= F, so it ends).  It used to run
+//    between the vertex stage and the walk, on the forward's critical path (63 us at 13 776 faces); here it costs the step nothing.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MM_PLAN_LDS_FACES 14336   // 28 KiB of LDS: five workgroups per CU stay possible
+#define MM_PLAN_WGS 4              // workgroups per image where faces are many (else one): each counts every face (cheap, from LDS) and
+                                   // writes the items of its share
+__device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
+    const int nwg = a.plan_wgs;                                   // 1 or MM_PLAN_WGS
+    __shared__ int s_wave[MM_PLAN_WGS][4];
+    // the faces' chunk counts at the base chunk size are staged in LDS (2 bytes a face, read once, coalesced, eight loads in flight per
+    // thread): with thousands of faces per thread-range the passes below were a chain of dependent trips to memory, one per face.
+    // ceil(ceil(n / c) / 2^k) = ceil(n / (c 2^k)): the doubled chunk sizes need nothing else.
+    __shared__ unsigned short s_nch[MM_PLAN_LDS_FACES];
+    const int tid = threadIdx.x;
+    const bool staged = a.F <= MM_PLAN_LDS_FACES;                 // (more faces than that: the counts are re-read from the face records)
+    auto box_px = [&](int f) {
+        const unsigned ext = __float_as_uint(a.geo[((size_t)b * a.F + f) * 3 + 2].w);
+        return (int)(ext & 0xFFFFu) * (int)(ext >> 16);          // 0: the box misses the image
+    };
+    if (staged) {
+        for (int f0 = tid; f0 < a.F; f0 += 8 * 256) {
+            int px[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) px[u] = f0 + u * 256 < a.F ? box_px(f0 + u * 256) : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (f0 + u * 256 < a.F) s_nch[f0 + u * 256] = (unsigned short)min((px[u] + MM_CHUNK_PX - 1) / MM_CHUNK_PX, 65535);
+        }
+        __syncthreads();
+    }
+    auto chunks = [&](int f, int shift) {                        // the face's items at chunk size MM_CHUNK_PX << shift
+        if (staged) return ((int)s_nch[f] + (1 << shift) - 1) >> shift;
+        const int chunk = MM_CHUNK_PX << shift;
+        return (box_px(f) + chunk - 1) / chunk;
+    };
+    // the faces are cut into MM_PLAN_WGS * 256 contiguous ranges; range (k, t) = faces of thread t of workgroup k.  Every workgroup
+    // counts all of them (so that it knows the total and what lies in front of its own quarter) and writes only its own.
+    const int per = (a.F + nwg * 256 - 1) / (nwg * 256);
+    int shift = 0, first = 0, total = 0;
+    for (;; ++shift) {
+        int mine[MM_PLAN_WGS], pre = 0;
+#pragma unroll
+        for (int k = 0; k < MM_PLAN_WGS; ++k) {
+            if (k >= nwg) { if ((tid & 63) == 63) s_wave[k][tid >> 6] = 0; continue; }      // (workgroup-uniform)
+            const int f0 = min(a.F, (k * 256 + tid) * per), f1 = min(a.F, f0 + per);
+            mine[k] = 0;
+            for (int f = f0; f < f1; ++f) mine[k] += chunks(f, shift);
+            int inc = mine[k];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += n; }
+            if (k == q) pre = inc - mine[k];
+            if (k == 0) __syncthreads();                         // (s_wave of the previous round has been read)
+            if ((tid & 63) == 63) s_wave[k][tid >> 6] = inc;
+        }
+        __syncthreads();
+        first = pre; total = 0;
+#pragma unroll
+        for (int k = 0; k < MM_PLAN_WGS; ++k) {
+            const int tk = ((s_wave[k][0] + s_wave[k][1]) + s_wave[k][2]) + s_wave[k][3];
+            if (k < q) first += tk;
+            if (k == q) for (int w = 0; w < (tid >> 6); ++w) first += s_wave[k][w];
+            total += tk;
+        }
+        if (total <= a.item_cap || shift >= 20) break;           // workgroup-uniform (and the same in the image's other workgroups)
+    }
+    const int chunk = MM_CHUNK_PX << shift;
+    const int f0 = min(a.F, (q * 256 + tid) * per), f1 = min(a.F, f0 + per);
+    for (int f = f0; f < f1; ++f) {
+        const int nch = chunks(f, shift);
+        a.plan_chunkmap[(size_t)b * a.F + f] = make_int2(first, nch);
+        for (int c = 0; c < nch; ++c) a.plan_items[(size_t)b * a.item_cap + first + c] = make_int2(f, c);
+        first += nch;
+    }
+    if (q == 0 && tid == 0) a.plan_nitems[b] = make_int2(total, chunk);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. pixel-major pass
@@ -64,8 +145,9 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     MM_TIMELINE_BEGIN();
     __shared__ float s_dl[MM_BLOCK_WAVES][9];
     __shared__ float s_gm[MM_BLOCK_WAVES][2];
+    if ((int)blockIdx.x < a.plan_wgs * a.B) { plan_sweep_items(a, blockIdx.x / a.plan_wgs, blockIdx.x % a.plan_wgs); return; }   // (workgroup-uniform)
     int b, blk;
-    map_block(blockIdx.x, a.B, a.blocks_per_image, b, blk);
+    map_block(blockIdx.x - a.plan_wgs * a.B, a.B, a.blocks_per_image, b, blk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
     const int px = bx * MM_BLOCK_PX + (wave & 1) * MM_TILE + (lane & 7), py = by * MM_BLOCK_PX + (wave >> 1) * MM_TILE + (lane >> 3);
@@ -729,12 +811,13 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
     a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
     a.items = w.items; a.nitems = w.nitems; a.part = w.part; a.item_cap = w.item_cap;
+    a.plan_chunkmap = w.chunkmap; a.plan_items = w.items; a.plan_nitems = w.nitems; a.plan_wgs = d->F > 4096 ? MM_PLAN_WGS : 1;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures;
     // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)
     {
         ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
-        dim3 grid(a.blocks_per_image * d->B);
+        dim3 grid(a.blocks_per_image * d->B + a.plan_wgs * d->B);    // + the plan workgroups, in front
         if (d->no_mask) hipLaunchKernelGGL(pixel_bwd_kernel<true>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(pixel_bwd_kernel<false>, grid, dim3(256), 0, s, a);
     }

@@ -72,69 +72,11 @@ __global__ __launch_bounds__(kBlock ? 256 : 64, kBlock ? 5 : 1) void raster_fwd_
 // sort in LDS (keys clipped to 1023; slots per image <= 1024), linear in the slots.  Only the launch ORDER of raster_fwd
 // depends on it -- slots with equal counts may come out in any order, no result does.  Bit 15 of an entry marks a tile that no
 // face can touch (count 0), which raster_fwd then never walks.
-#define MM_PLAN_LDS_FACES 24576
 __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short* order, int* nheavy) {
     __shared__ int s_key[1024];
     __shared__ int s_start[1024];          // histogram, then the first output position of every key
     __shared__ int s_wave[4];
-    // two workgroups per image, side by side: the even one sorts the tiles, the odd one lists the backward's sweep items
-    const int b = blockIdx.x >> 1, tid = threadIdx.x, nslot = 4 * a.blocks_per_image;
-    const bool do_items = (blockIdx.x & 1) != 0;
-    // (b) sweep items of the backward: every face's inflated pixel box cut into chunks of MM_CHUNK_PX pixels, numbered in face
-    //     order by an exclusive scan of the chunk counts.  Thread t owns the contiguous faces [t*per, (t+1)*per): it adds up
-    //     their counts (independent loads), ONE block scan gives its first item, and it numbers its faces' chunks from there.
-    //     Should the items run out (more than sixteen screens' worth of box pixels in one image), the image's chunk size doubles
-    //     until they fit (item_cap >= F, so it ends).
-    if (do_items) {
-        if (!a.chunkmap) return;
-        // the faces' chunk counts at the base chunk size are staged in LDS (2 bytes a face, read once, coalesced, eight loads in flight per
-        // thread): with thousands of faces per thread-range the two passes below were a chain of dependent trips to memory, one per face
-        // (66 us at 13 776 faces).  ceil(ceil(n / c) / 2^k) = ceil(n / (c 2^k)): the doubled chunk sizes need nothing else.
-        __shared__ unsigned short s_nch[MM_PLAN_LDS_FACES];
-        const bool staged = a.F <= MM_PLAN_LDS_FACES;             // (more faces than that: the counts are re-read from the face records)
-        auto box_px = [&](int f) {
-            const unsigned ext = __float_as_uint(a.geo[((size_t)b * a.F + f) * 3 + 2].w);
-            return (int)(ext & 0xFFFFu) * (int)(ext >> 16);      // 0: the box misses the image
-        };
-        if (staged) {
-            for (int f0 = tid; f0 < a.F; f0 += 8 * 256) {
-                int px[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) px[u] = f0 + u * 256 < a.F ? box_px(f0 + u * 256) : 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) if (f0 + u * 256 < a.F) s_nch[f0 + u * 256] = (unsigned short)min((px[u] + MM_CHUNK_PX - 1) / MM_CHUNK_PX, 65535);
-            }
-            __syncthreads();
-        }
-        const int per = (a.F + 255) / 256, f0 = min(a.F, tid * per), f1 = min(a.F, f0 + per);
-        auto chunks = [&](int f, int shift) {                    // the face's items at chunk size MM_CHUNK_PX << shift
-            if (staged) return ((int)s_nch[f] + (1 << shift) - 1) >> shift;
-            const int chunk = MM_CHUNK_PX << shift;
-            return (box_px(f) + chunk - 1) / chunk;
-        };
-        int shift = 0, first = 0, total = 0;
-        for (;; ++shift) {
-            int mine = 0;
-            for (int f = f0; f < f1; ++f) mine += chunks(f, shift);
-            int wtot;
-            first = wave_prefix_excl(mine, tid & 63, wtot);
-            __syncthreads();                                     // (s_wave of the previous round has been read)
-            if ((tid & 63) == 63) s_wave[tid >> 6] = wtot;
-            __syncthreads();
-            for (int w = 0; w < (tid >> 6); ++w) first += s_wave[w];
-            total = ((s_wave[0] + s_wave[1]) + s_wave[2]) + s_wave[3];
-            if (total <= a.item_cap || shift >= 20) break;       // workgroup-uniform
-        }
-        const int chunk = MM_CHUNK_PX << shift;
-        for (int f = f0; f < f1; ++f) {
-            const int nch = chunks(f, shift);
-            a.chunkmap[(size_t)b * a.F + f] = make_int2(first, nch);
-            for (int c = 0; c < nch; ++c) a.items[(size_t)b * a.item_cap + first + c] = make_int2(f, c);
-            first += nch;
-        }
-        if (tid == 0) a.nitems[b] = make_int2(total, chunk);
-        return;
-    }
+    const int b = blockIdx.x, tid = threadIdx.x, nslot = 4 * a.blocks_per_image;
     if (!order) return;
     for (int i = tid; i < 1024; i += 256) s_start[i] = 0;
     __syncthreads();
@@ -195,17 +137,17 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
 
 const unsigned short* launch_order(const RasterArgs& a_in, unsigned short* order, int* nheavy, int B, void** prof_events, hipStream_t s) {
     const bool sort = 4 * a_in.blocks_per_image <= 1024 && a_in.words <= 64;        // the tile sort is skipped where it would not pay
-    if (!sort && !a_in.chunkmap) return nullptr;
+    if (!sort) return nullptr;
     RasterArgs a = a_in;
     a.order = nullptr;
     ProfScope po(prof_events, MM_PROF_ORDER, s);
-    hipLaunchKernelGGL(order_kernel, dim3(2 * B), dim3(256), 0, s, a, sort ? order : nullptr, nheavy);
-    return sort ? order : nullptr;
+    hipLaunchKernelGGL(order_kernel, dim3(B), dim3(256), 0, s, a, order, nheavy);
+    return order;
 }
 
 int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     RasterArgs a = make_raster_args(d, w);
-    a.order = launch_order(a, w.order, w.nheavy, d->B, d->prof_events, s);     // heavy-first launch order + sweep items of the backward
+    a.order = launch_order(a, w.order, w.nheavy, d->B, d->prof_events, s);     // heavy-first launch order
     a.nheavy = w.nheavy;
     const bool block = walk_block_mode(a);
     const dim3 grid(walk_grid(a, block));

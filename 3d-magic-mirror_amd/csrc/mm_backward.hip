@@ -62,7 +62,9 @@ struct BwdArgs {
 //    worth of box pixels in one image), the image's chunk size doubles until they fit (item_cap >= F, so it ends).  It used to run
 //    between the vertex stage and the walk, on the forward's critical path (63 us at 13 776 faces); here it costs the step nothing.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef MM_PLAN_LDS_FACES
 #define MM_PLAN_LDS_FACES 14336   // 28 KiB of LDS: five workgroups per CU stay possible
+#endif
 #define MM_PLAN_WGS 4              // workgroups per image where faces are many (else one): each counts every face (cheap, from LDS) and
                                    // writes the items of its share
 __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {

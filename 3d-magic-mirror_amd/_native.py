@@ -223,6 +223,42 @@ def check(status, what):
                                                             " [" + detail + "]" if detail else ""))
 
 
+_EXT = False
+
+
+def torch_ext():
+    """The optional C++ host path (lib/mm_torch_ext.so, built by build_native.build_torch_ext): the module, or None if it is not there or
+    MM_NO_TORCH_EXT is set (then diff_render.py issues the same ABI calls from Python).  Never built lazily: 30 s of g++ do not belong in a
+    first render call; __graft_entry__.build() builds it."""
+    global _EXT
+    if _EXT is False:
+        _EXT = None
+        from . import build_native as bn
+        if not os.environ.get("MM_NO_TORCH_EXT") and os.path.exists(bn.EXT) and not bn.ext_needs_build():
+            import importlib.machinery
+            import importlib.util
+            try:
+                loader = importlib.machinery.ExtensionFileLoader("mm_torch_ext", bn.EXT)
+                mod = importlib.util.module_from_spec(importlib.util.spec_from_loader("mm_torch_ext", loader))
+                loader.exec_module(mod)
+                if mod.desc_bytes() == ctypes.sizeof(MMRenderDesc):
+                    _EXT = mod
+            except Exception:                                      # a stale binary of another torch build: use the Python path
+                _EXT = None
+    return _EXT
+
+
+_ADDR = {}
+
+
+def fn_addr(name):
+    """address of an exported function of the library, for the C++ host path"""
+    a = _ADDR.get(name)
+    if a is None:
+        a = _ADDR[name] = ctypes.cast(getattr(lib(), name), ctypes.c_void_p).value
+    return a
+
+
 def as_f32(t, dev):
     """``t`` detached as a dense fp32 tensor on ``dev``; the common case (already so) costs one attribute test each."""
     if t is None:

@@ -77,5 +77,52 @@ def build(force=False, verbose=False, out=None, extra_flags=None):
     return target
 
 
+EXT = os.path.join(HERE, "lib", "mm_torch_ext.so")
+EXT_SRC = os.path.join(CSRC, "mm_torch_ext.cpp")
+
+
+def ext_needs_build():
+    if not os.path.exists(EXT):
+        return True
+    t = os.path.getmtime(EXT)
+    return any(os.path.getmtime(d) > t for d in (EXT_SRC, os.path.join(HERE, "..", "include", "mm_render.h")))
+
+
+def build_torch_ext(force=False, verbose=False):
+    """The optional host-side fast path of the autograd API (csrc/mm_torch_ext.cpp): host compiler only, ~30 s, same lock / atomic publish
+    as the library.  Plumbing above the C ABI -- diff_render.py works without it (Python path, same calls)."""
+    import fcntl
+    import sysconfig
+    import tempfile
+    import torch
+    from torch.utils.cpp_extension import include_paths
+    if not force and not ext_needs_build():
+        return EXT
+    os.makedirs(os.path.dirname(EXT), exist_ok=True)
+    with open(os.path.join(os.path.dirname(EXT), ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not ext_needs_build():
+                return EXT
+            tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+            fd, tmp = tempfile.mkstemp(prefix="ext.", suffix=".so", dir=os.path.dirname(EXT))
+            os.close(fd)
+            cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-DTORCH_EXTENSION_NAME=mm_torch_ext",
+                   "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), EXT_SRC, "-o", tmp] + \
+                  ["-I" + i for i in include_paths() + [sysconfig.get_paths()["include"]]] + \
+                  ["-L" + tl, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python", "-Wl,-rpath," + tl]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, EXT)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return EXT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

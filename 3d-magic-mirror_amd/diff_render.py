@@ -239,6 +239,44 @@ class DiffRender(object):
             self._static_cache[key] = st
         return st
 
+    def _render_node(self, no_mask, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases):
+        """One autograd node for the render (+ the fused loss if gt is given).  With lib/mm_torch_ext.so built, the node is C++
+        (csrc/mm_torch_ext.cpp: no Python in the backward); otherwise the torch.autograd.Function above issues the same ABI calls."""
+        ext = N.torch_ext()
+        if ext is None:
+            return _RenderFn.apply(self, no_mask, self.emit_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases)
+        N.require_device(azimuths)
+        if no_mask and bg is None:
+            raise TypeError("render(no_mask=True) needs attributes['bg'] (B,3,H,W)")   # reference: None.permute fails
+        if textures.dim() != 4:
+            raise RuntimeError("textures must be (B,3,Ht,Wt), got %s" % (tuple(textures.shape),))
+        dev = azimuths.device
+        proto, nbytes = self._proto(self._static(dev), azimuths.numel(), no_mask, textures.shape[2], textures.shape[3])
+        return ext.render(N.fn_addr("mm_render_forward"), N.fn_addr("mm_render_fused_loss"), N.fn_addr("mm_render_backward"), proto, nbytes,
+                          vertices, textures, lights, bg, azimuths, elevations, distances, biases, gt, bool(self.emit_imnormal),
+                          float(self.image_weight), torch._C._cuda_getCurrentRawStream(dev.index))
+
+    def _proto(self, st, B, no_mask, Ht, Wt):
+        """(bytes of the MMRenderDesc prototype of this shape, its workspace size) for the C++ host path; cached like _desc's prototypes."""
+        key = ("bytes", id(st), B, int(bool(no_mask)), Ht, Wt, self.knum, self.sigmainv, self.boxlen, self.multiplier, self.eps, self.options)
+        hit = self._desc_cache.get(key)
+        if hit is None:
+            d = N.MMRenderDesc()
+            d.B, d.H, d.W, d.V, d.F = B, self.render_height, self.image_size, self.num_vertices, self.num_faces
+            d.Ht, d.Wt = Ht, Wt
+            d.no_mask, d.knum = int(bool(no_mask)), self.knum
+            for i in range(3):
+                d.proj[i] = float(self.cam_proj[i, 0])
+            d.sigmainv, d.boxlen, d.multiplier, d.eps = self.sigmainv, self.boxlen, self.multiplier, self.eps
+            d.faces, d.face_uvs = N.ptr(st["faces"]), N.ptr(st["face_uvs"])
+            d.vc_offsets, d.vc_items = N.ptr(st["vc_offsets"]), N.ptr(st["vc_items"])
+            d.options = self.options
+            hit = (bytes(d), N.lib().mm_query_workspace(ctypes.byref(d)))
+            if len(self._desc_cache) > 32:
+                self._desc_cache.clear()
+            self._desc_cache[key] = hit
+        return hit
+
     def _desc(self, st, B, no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases, rgba, face_idx, fn, imn):
         """MMRenderDesc for one call.  The constant part (sizes, dibr constants, template pointers) is filled once per shape and
         copied; only the per-call pointers are set here (host time matters: this path is enqueue-bound)."""
@@ -276,8 +314,8 @@ class DiffRender(object):
         vertices = attributes['vertices']
         textures = attributes['textures']
         lights = attributes['lights']
-        rgba, fn, imn, face_idx = _RenderFn.apply(self, bool(no_mask), self.emit_imnormal, None, vertices, textures, lights,
-                                                  bg if no_mask else None, azimuths, elevations, distances, biases)
+        rgba, fn, imn, face_idx = self._render_node(bool(no_mask), None, vertices, textures, lights, bg if no_mask else None,
+                                                    azimuths, elevations, distances, biases)
         rgbs = rgba.permute(0, 3, 1, 2)                 # (B,4,H,W) view of NHWC memory, like networks.py:317
         attributes['face_normals'] = fn
         attributes['imnormal'] = imn if self.emit_imnormal else None
@@ -290,8 +328,8 @@ class DiffRender(object):
         round trip) -- the path bench.py's `value` times, reachable from the class API.  Returns (loss, rgbs, attributes); ``rgbs``
         carries no gradient here (use render + recon_data if the image feeds anything else that is differentiated)."""
         a = attributes
-        rgba, fn, imn, face_idx, loss = _RenderFn.apply(self, bool(no_mask), self.emit_imnormal, gt_data, a['vertices'], a['textures'], a['lights'],
-                                                        a['bg'] if no_mask else None, a['azimuths'], a['elevations'], a['distances'], a['biases'])
+        rgba, fn, imn, face_idx, loss = self._render_node(bool(no_mask), gt_data, a['vertices'], a['textures'], a['lights'],
+                                                          a['bg'] if no_mask else None, a['azimuths'], a['elevations'], a['distances'], a['biases'])
         attributes['face_normals'] = fn
         attributes['imnormal'] = imn if self.emit_imnormal else None
         self.last_face_idx = face_idx
@@ -299,8 +337,12 @@ class DiffRender(object):
 
     # ---- networks.py:364-390 -------------------------------------------------------------------------------------
     def recon_data(self, pred_data, gt_data, no_mask=False, contour=0):
-        loss = _ReconFn.apply(pred_data, gt_data, self.image_weight, contour)
-        return loss
+        ext = N.torch_ext()
+        if ext is None:
+            return _ReconFn.apply(pred_data, gt_data, self.image_weight, contour)
+        N.require_device(pred_data, gt_data)
+        return ext.recon_data(N.fn_addr("mm_recon_query_workspace"), N.fn_addr("mm_recon_data_forward"), N.fn_addr("mm_recon_data_backward"),
+                              pred_data, gt_data, float(self.image_weight), float(contour), torch._C._cuda_getCurrentRawStream(pred_data.device.index))
 
     # ---- networks.py:326-362: seven means in one HIP launch per direction (att_loss.py / csrc/mm_attloss.hip); the chamfer
     # variant of the shape term is a HIP nearest-neighbour search + a differentiable gather ----------

@@ -247,6 +247,34 @@ def test_render_recon_is_render_plus_recon_data(pkg):
         assert float(got[1][2][k].abs().max()) > 0
 
 
+def test_cpp_and_python_host_paths_agree(pkg):
+    """The optional C++ autograd nodes (lib/mm_torch_ext.so) and the Python torch.autograd.Functions issue the same ABI calls: same bits,
+    for render + recon_data and for render_recon."""
+    N = pkg._native
+    if N.torch_ext() is None:
+        pytest.skip("mm_torch_ext is not built")
+    ext, got = N._EXT, []
+    try:
+        for use_ext in (True, False):
+            N._EXT = ext if use_ext else None
+            for fused in (False, True):
+                dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 5, 80, seed=41)
+                if fused:
+                    loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=True, **datt)
+                else:
+                    rgbs, out = dr.render(no_mask=True, **datt)
+                    loss = dr.recon_data(rgbs, gt.to(dev), no_mask=True) + 1e-3 * out["face_normals"].sum()
+                loss.backward()
+                got.append((loss.detach().clone(), rgbs.detach().clone(), out["imnormal"].clone(), dr.last_face_idx.clone(),
+                            {k: datt[k].grad.clone() for k in LEAVES}))
+    finally:
+        N._EXT = ext
+    for a, b in ((got[0], got[2]), (got[1], got[3])):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        for k in LEAVES:
+            assert torch.equal(a[4][k], b[4][k]), k
+
+
 def test_recon_data_matches_reference_golden(pkg):
     z = np.load(os.path.join(GOLDEN, "losses.npz"))
     dev = torch.device("cuda:0")

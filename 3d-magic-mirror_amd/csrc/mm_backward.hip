@@ -577,7 +577,7 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s
     for (int r = tid; r < nsp; r += 256) if (sp[r].tile == T) mx = fmaxf(mx, tex_record_max(sp[r].r));
     mx = wave_max(mx);
     if ((tid & 63) == 0) s_max[tid >> 6] = mx;
-    for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) (&s_acc[0][0])[i] = 0;
+    for (int i = tid; i < 3 * MM_TS * MM_TS / 4; i += 256) ((int4*)&s_acc[0][0])[i] = make_int4(0, 0, 0, 0);   // (16-byte LDS stores)
     __syncthreads();
     mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
     MM_PP_MARK(1);
@@ -595,12 +595,25 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s
     }
     MM_PP_MARK(2);
     MM_PP_COUNT(nrec, 0);
-    // write the tile once (also where nothing landed: no separate zero-fill of grad_textures)
-    for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) {
-        const int c = i / (MM_TS * MM_TS), r = i - c * (MM_TS * MM_TS);
-        const int ly = r / MM_TS, lx = r - ly * MM_TS;
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x < a.Wt && y < a.Ht) a.grad_textures[(((size_t)b * 3 + c) * a.Ht + y) * a.Wt + x] = (float)s_acc[c][r] * inv;
+    // write the tile once (also where nothing landed: no separate zero-fill of grad_textures): four texels of a row per thread and store
+    if ((a.Wt & 3) == 0 && (((size_t)a.grad_textures) & 15) == 0) {
+        for (int i = tid; i < 3 * MM_TS * MM_TS / 4; i += 256) {
+            const int c = i / (MM_TS * MM_TS / 4), r = i - c * (MM_TS * MM_TS / 4);
+            const int ly = r / (MM_TS / 4), lx = (r - ly * (MM_TS / 4)) * 4;
+            const int x = tx0 + lx, y = ty0 + ly;
+            if (x < a.Wt && y < a.Ht) {
+                const int4 v = *(const int4*)&s_acc[c][ly * MM_TS + lx];
+                *(float4*)(a.grad_textures + (((size_t)b * 3 + c) * a.Ht + y) * a.Wt + x) =
+                    make_float4((float)v.x * inv, (float)v.y * inv, (float)v.z * inv, (float)v.w * inv);
+            }
+        }
+    } else {
+        for (int i = tid; i < 3 * MM_TS * MM_TS; i += 256) {
+            const int c = i / (MM_TS * MM_TS), r = i - c * (MM_TS * MM_TS);
+            const int ly = r / MM_TS, lx = r - ly * MM_TS;
+            const int x = tx0 + lx, y = ty0 + ly;
+            if (x < a.Wt && y < a.Ht) a.grad_textures[(((size_t)b * 3 + c) * a.Ht + y) * a.Wt + x] = (float)s_acc[c][r] * inv;
+        }
     }
     MM_PP_MARK(3);
     MM_PP_FLUSH(gather_tex, (long long)block * 4 + (threadIdx.x >> 6));

@@ -131,7 +131,6 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.order = nullptr;
     a.nheavy = nullptr;
     a.feats = nullptr; a.D = 0; a.interp = nullptr; a.soft_out = nullptr; a.face_idx64 = nullptr; a.options = d->options;
-    a.chunkmap = w.chunkmap; a.items = w.items; a.nitems = w.nitems; a.item_cap = w.item_cap;
     return a;
 }
 

@@ -30,8 +30,6 @@ struct RasterArgs {
     const float* feats; int D;              // (B,F,3,D) per-corner features
     float* interp; float* soft_out; long long* face_idx64;
     int options;                            // MM_OPT_* bits
-    // plan kernel outputs for the backward (fused path only; nullptr: not wanted)
-    int2* chunkmap; int2* items; int2* nitems; int item_cap;
 };
 
 #define MM_PAIR_ROUND 512

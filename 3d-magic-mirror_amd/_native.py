@@ -122,7 +122,7 @@ OPT_WALK_BLOCK, OPT_WALK_WAVE = 1 << 1, 1 << 2
 OPT_CULL_STRICT, OPT_SOFT_SKIP_CULLED, OPT_BBOX_HALF_OPEN, OPT_BARY_ONE_MINUS, OPT_SH_ORDER_XYZ = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
-EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_render_fused_loss", "mm_recon_query_workspace",
+EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_render_fused_loss", "mm_debug_workspace_layout", "mm_recon_query_workspace",
            "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_nearest_neighbour", "mm_status_string", "mm_last_error_detail",
            "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward", "mm_texture_flow_forward",
            "mm_texture_flow_backward", "mm_attribute_loss_query_workspace", "mm_attribute_loss_forward",

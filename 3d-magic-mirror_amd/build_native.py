@@ -5,8 +5,9 @@ Flags that matter:
   -ffp-contract=off       every fp32 expression rounds as written (face_idx bit-parity with the CPU oracle); HIP's default
                           correctly rounded fp32 '/' and sqrtf are kept for the same reason
   -munsafe-fp-atomics     atomicAdd(float) lowers to the hardware global_atomic_add_f32 (no CAS loop)
-Per file: the backward (mm_backward.hip) is held to 1e-4, not to the bit, and the whole path is bound by VALU issue, so it is
-compiled with fma contraction and the 2.5-ulp division/sqrt sequences (about a third fewer vector instructions).
+Per file: the gathers of the backward (mm_backward.hip) are held to 1e-4, not to the bit, and bound by instruction issue, so they are
+compiled with fma contraction and the 2.5-ulp division/sqrt sequences (about a third fewer vector instructions).  The pixel pass of the
+backward (mm_pixel_bwd.hip) recomputes the forward's per-pixel quantities and is compiled like the forward (see csrc/mm_backward.h).
 """
 import os
 import subprocess
@@ -21,8 +22,8 @@ LIB = os.path.join(HERE, "lib", "libmm_render.so")
 EXACT = ["-ffp-contract=off"]
 RELAXED = ["-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
 SOURCES = {"mm_abi.hip": EXACT, "mm_reg.hip": EXACT, "mm_texflow.hip": EXACT, "mm_attloss.hip": EXACT, "mm_vertex.hip": EXACT, "mm_raster.hip": EXACT,
-           "mm_backward.hip": RELAXED, "mm_loss.hip": EXACT, "mm_nn.hip": EXACT, "mm_dibr.hip": EXACT, "mm_ops.hip": EXACT}
-HEADERS = ["mm_device.h", "mm_raster_common.h", "mm_raster_walk.h", os.path.join("..", "..", "include", "mm_render.h")]
+           "mm_backward.hip": RELAXED, "mm_pixel_bwd.hip": EXACT, "mm_loss.hip": EXACT, "mm_nn.hip": EXACT, "mm_dibr.hip": EXACT, "mm_ops.hip": EXACT}
+HEADERS = ["mm_device.h", "mm_raster_common.h", "mm_raster_walk.h", "mm_backward.h", os.path.join("..", "..", "include", "mm_render.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

@@ -64,6 +64,15 @@ int mm_render_fused_loss(const MMRenderDesc* d, mm_stream_t stream) {
     return mm::launch_fused_loss(d, w, (hipStream_t)stream);
 }
 
+int mm_debug_workspace_layout(const MMRenderDesc* d, size_t* out5) {
+    if (!d || !out5) return MM_ERR_NULL_POINTER;
+    const mm::Workspace w = mm::carve_workspace(nullptr, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt);
+    out5[0] = (size_t)((char*)w.chunkmap - (char*)nullptr); out5[1] = (size_t)((char*)w.items - (char*)nullptr);
+    out5[2] = (size_t)((char*)w.nitems - (char*)nullptr); out5[3] = (size_t)((char*)w.part - (char*)nullptr); out5[4] = (size_t)w.item_cap;
+    out5[5] = (size_t)((char*)w.gp - (char*)nullptr); out5[6] = (size_t)((char*)w.gp2 - (char*)nullptr); out5[7] = (size_t)((char*)w.soft - (char*)nullptr);
+    return MM_OK;
+}
+
 int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {
     int st = check_render(d, true);
     if (st != MM_OK) return st;

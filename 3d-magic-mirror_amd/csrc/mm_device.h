@@ -203,6 +203,41 @@ __device__ inline Float3 to_camera(const float* __restrict__ v, const float* T) 
 __device__ inline float pixel_x(int px, int W, float mult) { return (mult / (float)W) * (float)(2 * px + 1 - W); }
 __device__ inline float pixel_y(int py, int H, float mult) { return (mult / (float)H) * (float)(H - 2 * py - 1); }
 
+// ---- one factor of the silhouette product:  q = 1 - exp(-sigma' d^2),  d = distance from the pixel centre to the
+// nearest edge of the face, sigma' = sigmainv / multiplier^2.  Held to 1e-4, not to the bit: hardware reciprocal / exp2 (about 1 ulp each).
+// But it must be BIT-IDENTICAL in the forward and in the backward, whatever flags their translation units are compiled with: the forward
+// stores the product of the factors of a pixel, and the backward gets "the product over the OTHER faces" by dividing by the factor it
+// recomputes.  For a pixel centre almost exactly on an edge, q is a few ulps of 1 - p, and a last-bit difference between the two
+// evaluations is a 10-20 % error in that pixel's gradient (found by profiles/tools/fuzz_parity.py: 1e-3 absolute on one vertex).
+// Hence: no contraction inside (pragma), no division (the flags change how `/` rounds), pixel centre and sigma' passed in as the
+// forward computes them (IEEE: multiplier / W and sigmainv / multiplier^2 are formed on the host for the backward).
+__device__ inline float seg_dist2_fast(float px, float py, float ux, float uy, float vx, float vy) {
+#pragma clang fp contract(off)
+    const float ex = vx - ux, ey = vy - uy, rx = px - ux, ry = py - uy;
+    const float len2 = ex * ex + ey * ey;
+    const float dot = rx * ex + ry * ey;
+    float t = (len2 > 0.f) ? dot * __builtin_amdgcn_rcpf(len2) : 0.f;
+    t = fminf(fmaxf(t, 0.f), 1.f);                                // clamped projection: the three regions of seg_dist2 in one form
+    const float qx = rx - t * ex, qy = ry - t * ey;
+    return qx * qx + qy * qy;
+}
+__device__ inline float soft_factor(float x0, float y0, const float4& p0, const float4& p1, float sig2) {
+#pragma clang fp contract(off)
+    const float d = fminf(fminf(seg_dist2_fast(x0, y0, p0.x, p0.y, p0.z, p0.w), seg_dist2_fast(x0, y0, p0.z, p0.w, p1.x, p1.y)),
+                          seg_dist2_fast(x0, y0, p1.x, p1.y, p0.x, p0.y));
+    return 1.f - __builtin_amdgcn_exp2f(-(d * sig2) * 1.4426950408889634f);
+}
+// pixel centre from the host-formed factor k = multiplier / W (or / H): the same float as pixel_x / pixel_y in a translation unit with
+// IEEE division, in any translation unit
+__device__ inline float pixel_x_k(int px, int W, float kx) {
+#pragma clang fp contract(off)
+    return kx * (float)(2 * px + 1 - W);
+}
+__device__ inline float pixel_y_k(int py, int H, float ky) {
+#pragma clang fp contract(off)
+    return ky * (float)(H - 2 * py - 1);
+}
+
 // conservative pixel range [lo, hi] whose centres can satisfy  lo_v <= centre <= hi_v  (a 0.02 px slack covers the
 // rounding of this closed form by orders of magnitude; callers re-test every pixel exactly).  flip: centres fall with the index (y).
 __device__ inline void pixel_range(float lo_v, float hi_v, float mult, int n, bool flip, int& lo, int& hi) {

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
                 t1 = seg_nearest_t(x0, y0, p1.x, p1.y, p0.x, p0.y, qx1, qy1, d21);          // edge 2: c -> a
                 if (d21 < d2) { d2 = d21; qx = qx1; qy = qy1; t = t1; e = 2; }
                 const float p = expf(-((d2 / s2) * a.sigmainv));
-                const float q = 1.f - p;
+                const float q = soft_factor(x0, y0, p0, p1, a.sigmainv / s2);    // the factor exactly as the walk folded it into the product
                 const float qnz = fabsf(sq);
                 const bool onezero = sq < 0.f;
                 const float excl = (q != 0.f) ? (onezero ? 0.f : qnz / q) : (onezero ? qnz : 0.f);

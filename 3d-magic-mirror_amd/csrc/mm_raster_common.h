@@ -166,27 +166,13 @@ __device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* s
         atomicMax(&acc->key[l], depth_key(z0, __float_as_int(p2.z)));
 }
 
-// The silhouette is held to 1e-4, not to the bit (only face_idx is), and its pair evaluations are most of the forward's
-// instructions: they use the hardware reciprocal / exp2 / log2 (about 1 ulp each) instead of the IEEE sequences.
-__device__ inline float seg_dist2_fast(float px, float py, float ux, float uy, float vx, float vy) {
-    const float ex = vx - ux, ey = vy - uy, rx = px - ux, ry = py - uy;
-    const float len2 = ex * ex + ey * ey;
-    const float dot = rx * ex + ry * ey;
-    float t = (len2 > 0.f) ? dot * __builtin_amdgcn_rcpf(len2) : 0.f;
-    t = fminf(fmaxf(t, 0.f), 1.f);                                // clamped projection: the three regions of seg_dist2 in one form
-    const float qx = rx - t * ex, qy = ry - t * ey;
-    return qx * qx + qy * qy;
-}
-
 // K3, one (pixel l, candidate j) pair: factor q = 1 - exp(-sigma d^2) folded into the pixel's integer log2 sum.
 // sig2 = sigmainv / multiplier^2 (d is in multiplier units).
 template <class Stage>
 __device__ inline void soft_pair(const RasterArgs& a, const TileCtx& t, Stage* st, Stage* acc, float sig2, int l, int j, bool live) {
     const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
     const float4 p0 = st->p0[j], p1 = st->p1[j];
-    const float d = fminf(fminf(seg_dist2_fast(x0, y0, p0.x, p0.y, p0.z, p0.w), seg_dist2_fast(x0, y0, p0.z, p0.w, p1.x, p1.y)),
-                          seg_dist2_fast(x0, y0, p1.x, p1.y, p0.x, p0.y));
-    const float q = 1.f - __builtin_amdgcn_exp2f(-(d * sig2) * 1.4426950408889634f);
+    const float q = soft_factor(x0, y0, p0, p1, sig2);
     if (live) {
         if (q == 0.f) atomicAdd(&acc->zeros[l], 1);
         else {                                                   // log2(q) in 2^-32 fixed point: floor part and 32 fraction bits

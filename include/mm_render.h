@@ -133,6 +133,10 @@ int mm_render_backward(const MMRenderDesc* desc, const MMRenderGrads* grads, mm_
  * (networks.py:364-390, contour = 0) to desc->fused_loss from the sums the forward left in the workspace -- for callers that need
  * the loss before they run the backward (the autograd API DiffRender.render_recon).  mm_render_backward writes the same value. */
 int mm_render_fused_loss(const MMRenderDesc* desc, mm_stream_t stream);
+/* Tools only (profiles/tools): byte offsets inside the render workspace of out[0] = chunkmap (B,F) int2, out[1] = sweep items (B,item_cap)
+ * int2, out[2] = nitems (B) int2, out[3] = per-item partial sums (B,item_cap,12) float; out[4] = item_cap; out[5] = gp (B,H,W,2) float4,
+ * out[6] = gp2 (B,H,W) float, out[7] = soft (B,H,W) float2.  Returns 0, or MM_ERR_*. */
+int mm_debug_workspace_layout(const MMRenderDesc* desc, size_t* out8);
 
 /* --------------------------------------------------------------------------------------------------------------------
  * Reconstruction loss: replaces DiffRender.recon_data (networks.py:364-390) incl. kaolin mask_iou (:377) and the

@@ -1,0 +1,74 @@
+"""Randomised HIP-vs-oracle parity over templates, batch sizes, screen sizes, camera distances and dibr constants (face_idx bit-exact, RGBA
+and all gradients 1e-4): a hunt for corner cases the fixed parity cases miss (many windows / chunks of candidates in one tile, cooperative
+tiles with more than one window, ragged screens, far and near cameras).   python profiles/tools/fuzz_parity.py [cases] [seed]"""
+import sys, importlib, os, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle
+pkg = importlib.import_module("3d-magic-mirror_amd")
+LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "distances", "biases")
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+bad = 0
+only = os.environ.get("MM_FUZZ_ONLY")
+for case in range(ncase):
+    name = rng.choice(["sphere", "smpl_uv_642", "ellipsoid", "sphere2", "smpl_uv"], p=[0.25, 0.3, 0.15, 0.15, 0.15])
+    big = name in ("sphere2", "smpl_uv")
+    S = int(rng.choice([24, 32, 40, 50, 64, 72, 96, 128] if not big else [24, 32, 48, 64, 80]))
+    ratio = int(rng.choice([1, 1, 2]))
+    B = int(rng.integers(1, 5 if big else 9))
+    no_mask = bool(rng.integers(0, 2))
+    knum = int(rng.choice([30, 30, 30, 5, 70]))
+    boxlen = float(rng.choice([0.02, 0.02, 0.05, 0.15]))
+    sigmainv = float(rng.choice([7000.0, 7000.0, 900.0, 200.0]))
+    mode = rng.choice(["default", "far", "near", "mixed"], p=[0.4, 0.25, 0.15, 0.2])
+    dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio)
+    dr.knum, dr.boxlen, dr.sigmainv = knum, boxlen, sigmainv
+    dr.options = int(os.environ.get("MM_OPTIONS", "0"))
+    H, W = dr.render_height, dr.image_size
+    att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=int(rng.integers(0, 1 << 30)))
+    if mode == "far":
+        att["distances"] = torch.full_like(att["distances"], float(rng.uniform(8.0, 30.0)))
+    elif mode == "near":
+        att["distances"] = torch.full_like(att["distances"], float(rng.uniform(1.5, 1.9)))
+    elif mode == "mixed":
+        att["distances"] = torch.from_numpy(rng.uniform(1.6, 25.0, size=B).astype(np.float32))
+    datt = {k: (v.to(dev).requires_grad_(k in LEAVES) if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp["faces"] = dr.faces.numpy().astype(np.int32); inp["face_uvs"] = dr.face_uvs.numpy()[0]
+    proj = dr.cam_proj.numpy().reshape(3)
+    tag = "%s B=%d %dx%d no_mask=%d knum=%d boxlen=%g sigmainv=%g %s" % (name, B, H, W, no_mask, knum, boxlen, sigmainv, mode)
+    if only is not None and case != int(only):
+        continue
+    try:
+        rgbs, out = dr.render(no_mask=no_mask, **datt)
+        dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask).backward()
+        torch.cuda.synchronize()
+        kw = dict(knum=knum, boxlen=boxlen, sigmainv=sigmainv)
+        rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj, **kw)
+        loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+        g_o = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None, **kw)
+        nf = int((dr.last_face_idx.cpu().numpy() != fidx_o).sum())
+        errs = {"rgba": float(np.abs(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy() - rgba_o).max())}
+        for k in LEAVES:
+            if datt.get(k) is None or (k == "bg" and not no_mask):
+                continue
+            ref = g_o[k]
+            errs[k] = float(np.abs(datt[k].grad.cpu().numpy() - ref).max() / max(1.0, float(np.abs(ref).max())))
+        worst = max(errs.values())
+        ok = nf == 0 and worst <= 1e-4
+        print("%s  case %2d  %-90s face_idx diff %d, worst err %.2e (%s)" % ("ok  " if ok else "FAIL", case, tag, nf, worst, max(errs, key=errs.get)), flush=True)
+        bad += not ok
+        if not ok and os.environ.get("MM_FUZZ_DETAIL"):
+            print("      all errors:", {k: "%.2e" % v for k, v in errs.items()})
+            g64 = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)).astype(np.float64), None, dtype=np.float64, **kw)
+            for k in ("vertices", "distances", "azimuths"):
+                got = datt[k].grad.cpu().numpy().astype(np.float64); r32 = g_o[k].astype(np.float64); r64 = g64[k]
+                i = np.unravel_index(np.abs(got - r32).argmax(), got.shape)
+                print("      %s worst at %s: hip %.6e oracle32 %.6e oracle64 %.6e | max|ref| %.3e | hip-vs-64 %.2e, o32-vs-64 %.2e (relative to max)" % (
+                    k, i, got[i], r32[i], r64[i], np.abs(r32).max(), np.abs(got - r64).max() / max(1, np.abs(r64).max()), np.abs(r32 - r64).max() / max(1, np.abs(r64).max())))
+    except Exception as e:                                          # noqa: BLE001
+        print("EXC   case %2d  %s: %r" % (case, tag, e), flush=True)
+        bad += 1
+print("failures:", bad)

@@ -201,6 +201,42 @@ def test_appendix_c_switches_match_the_oracle(pkg, oracle, bit):
     assert (not torch.equal(base_idx, dr2.last_face_idx)) or float((base2 - r2).abs().max()) > 1e-6, bit   # the switch changed something
 
 
+@pytest.mark.parametrize("name,B,S,ratio,no_mask,sigmainv,boxlen,seed,dist", [
+    ("sphere", 2, 96, 2, True, 900.0, 0.02, 794003348, None),           # a covered pixel whose texture row coordinate is 58.99994
+    ("smpl_uv_642", 6, 96, 1, True, 900.0, 0.02, 339905349, 1.808205592613872),
+    ("sphere", 3, 128, 2, False, 200.0, 0.02, 723017325, None),
+    ("ellipsoid", 3, 128, 2, False, 200.0, 0.15, 769837633, None),
+])
+def test_fuzz_regressions_pixel_pass_recomputes_the_forward_bit_for_bit(pkg, oracle, name, B, S, ratio, no_mask, sigmainv, boxlen, seed, dist):
+    """Found by profiles/tools/fuzz_parity.py (4 of 860 random cases): the backward's pixel pass recomputes uv -> texel cell and the
+    pre-clamp colour; compiled with other floating-point flags than the forward it landed, for a pixel within an ulp of a texel-cell border
+    (or of 0 / 1), in the neighbouring bilinear cell (on the other side of torch.clamp): a different one-sided derivative, up to 1e-3 on one
+    vertex gradient.  The pixel pass is now compiled like the forward (csrc/mm_backward.h) and recomputes it bit for bit."""
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, name + ".npz"), S, ratio=ratio)
+    dr.sigmainv, dr.boxlen = sigmainv, boxlen
+    dev = torch.device("cuda:0")
+    H, W = dr.render_height, dr.image_size
+    att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=seed)
+    if dist is not None:
+        att["distances"] = torch.full_like(att["distances"], dist)
+    datt = {k: (v.to(dev).requires_grad_(k in LEAVES) if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp["faces"] = dr.faces.numpy().astype(np.int32); inp["face_uvs"] = dr.face_uvs.numpy()[0]
+    proj = dr.cam_proj.numpy().reshape(3)
+    rgbs, out = dr.render(no_mask=no_mask, **datt)
+    dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask).backward()
+    kw = dict(sigmainv=sigmainv, boxlen=boxlen)
+    rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj, **kw)
+    loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+    g_o = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None, **kw)
+    assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
+    assert np.array_equal(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy()[..., :3], rgba_o[..., :3])       # the colour channels are bit-exact
+    for k in LEAVES:
+        if k == "bg" and not no_mask:
+            continue
+        _close(datt[k].grad.cpu().numpy(), g_o[k], 2e-5)
+
+
 def test_backward_twice_after_one_forward(pkg):
     """retain_graph: the backward leaves its scratch counters the way it found them (the library clears them in-kernel)."""
     dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 4, 96, seed=21)

@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle
 pkg = importlib.import_module("3d-magic-mirror_amd")
+sys.path.insert(0, os.path.join(ROOT, "3d-magic-mirror_amd", "shim"))
+import kaolin as kal
 LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "distances", "biases")
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -41,9 +43,34 @@ for case in range(ncase):
     tag = "%s B=%d %dx%d no_mask=%d knum=%d boxlen=%g sigmainv=%g %s" % (name, B, H, W, no_mask, knum, boxlen, sigmainv, mode)
     if only is not None and case != int(only):
         continue
+    api = str(rng.choice(["render+recon_data", "render_recon", "shim operators"], p=[0.4, 0.3, 0.3]))
+    tag += " | " + api
     try:
-        rgbs, out = dr.render(no_mask=no_mask, **datt)
-        dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask).backward()
+        if api == "render+recon_data":
+            rgbs, out = dr.render(no_mask=no_mask, **datt)
+            dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask).backward()
+        elif api == "render_recon":
+            loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=no_mask, **datt)
+            loss.backward()
+        else:                                                    # the reference's own composition of the kaolin-shaped operators
+            Tt = torch.from_numpy(oracle.camera(inp["distances"], inp["elevations"], inp["azimuths"], inp["biases"])).to(dev).requires_grad_(True)
+            F = dr.num_faces
+            fvc_t, fvi_t, fn_t = kal.render.mesh.prepare_vertices(vertices=datt["vertices"], faces=dr.faces, camera_proj=dr.cam_proj, camera_transform=Tt)
+            nrm = kal.ops.mesh.face_normals(fvc_t, unit=True).unsqueeze(-2).repeat(1, 1, 3, 1)
+            feats = [torch.ones((B, F, 3, 1), device=dev), dr.face_uvs.to(dev).repeat(B, 1, 1, 1), nrm]
+            (texmask, texcoord, imnormal), soft_t, fidx_t = kal.render.mesh.dibr_rasterization(
+                H, W, fvc_t[:, :, :, -1], fvi_t, feats, fn_t[:, :, -1], knum=knum, boxlen=boxlen, sigmainv=sigmainv)
+            texcolor = kal.render.mesh.texture_mapping(texcoord, datt["textures"], mode='bilinear')
+            coef = kal.render.mesh.spherical_harmonic_lighting(imnormal, datt["lights"])
+            image = (texcolor * texmask + datt["bg"].permute(0, 2, 3, 1) * (1 - texmask)) * coef.unsqueeze(-1) if no_mask else \
+                texcolor * texmask * coef.unsqueeze(-1) + torch.ones_like(texcolor) * (1 - texmask)
+            rgbs = torch.cat([torch.clamp(image, 0, 1), soft_t[..., None]], -1).permute(0, 3, 1, 2)
+            dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask).backward()
+            dr.last_face_idx = fidx_t.int()
+            # the camera chain is the oracle's here (T is a leaf): push dL/dT through it so that all eight gradients can be compared
+            dd, de, da, db = oracle.camera_backward(inp["distances"], inp["elevations"], inp["azimuths"], inp["biases"], Tt.grad.cpu().numpy())
+            for k, v in (("distances", dd), ("elevations", de), ("azimuths", da), ("biases", db)):
+                datt[k].grad = torch.from_numpy(np.ascontiguousarray(v)).to(dev).reshape(datt[k].shape)
         torch.cuda.synchronize()
         kw = dict(knum=knum, boxlen=boxlen, sigmainv=sigmainv)
         rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj, **kw)

@@ -17,9 +17,9 @@ only = os.environ.get("MM_FUZZ_ONLY")
 for case in range(ncase):
     name = rng.choice(["sphere", "smpl_uv_642", "ellipsoid", "sphere2", "smpl_uv"], p=[0.25, 0.3, 0.15, 0.15, 0.15])
     big = name in ("sphere2", "smpl_uv")
-    S = int(rng.choice([24, 32, 40, 50, 64, 72, 96, 128] if not big else [24, 32, 48, 64, 80]))
+    S = int(rng.choice([8, 16, 20, 24, 32, 40, 50, 64, 72, 96, 128] if not big else [16, 24, 32, 48, 64, 80]))
     ratio = int(rng.choice([1, 1, 2]))
-    B = int(rng.integers(1, 5 if big else 9))
+    B = int(rng.integers(1, 5 if big else 9)) if rng.random() < 0.85 or big else int(rng.integers(9, 80))
     no_mask = bool(rng.integers(0, 2))
     knum = int(rng.choice([30, 30, 30, 5, 70]))
     boxlen = float(rng.choice([0.02, 0.02, 0.05, 0.15]))
@@ -27,7 +27,8 @@ for case in range(ncase):
     mode = rng.choice(["default", "far", "near", "mixed"], p=[0.4, 0.25, 0.15, 0.2])
     dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio)
     dr.knum, dr.boxlen, dr.sigmainv = knum, boxlen, sigmainv
-    dr.options = int(os.environ.get("MM_OPTIONS", "0"))
+    optbit = int(rng.choice([0, 0, 0, 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8, (1 << 4) | (1 << 5)]))   # Appendix-C switches, mirrored by the oracle
+    dr.options = int(os.environ.get("MM_OPTIONS", "0")) | optbit
     H, W = dr.render_height, dr.image_size
     att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=int(rng.integers(0, 1 << 30)))
     if mode == "far":
@@ -40,10 +41,12 @@ for case in range(ncase):
     inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att.items()}
     inp["faces"] = dr.faces.numpy().astype(np.int32); inp["face_uvs"] = dr.face_uvs.numpy()[0]
     proj = dr.cam_proj.numpy().reshape(3)
-    tag = "%s B=%d %dx%d no_mask=%d knum=%d boxlen=%g sigmainv=%g %s" % (name, B, H, W, no_mask, knum, boxlen, sigmainv, mode)
+    tag = "%s B=%d %dx%d no_mask=%d knum=%d boxlen=%g sigmainv=%g %s opt=%d" % (name, B, H, W, no_mask, knum, boxlen, sigmainv, mode, optbit)
     if only is not None and case != int(only):
         continue
     api = str(rng.choice(["render+recon_data", "render_recon", "shim operators"], p=[0.4, 0.3, 0.3]))
+    if optbit and api == "shim operators":
+        api = "render_recon"                                     # (the kaolin-shaped operators take no option bits through their signatures)
     tag += " | " + api
     try:
         if api == "render+recon_data":
@@ -73,9 +76,10 @@ for case in range(ncase):
                 datt[k].grad = torch.from_numpy(np.ascontiguousarray(v)).to(dev).reshape(datt[k].shape)
         torch.cuda.synchronize()
         kw = dict(knum=knum, boxlen=boxlen, sigmainv=sigmainv)
-        rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj, **kw)
-        loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
-        g_o = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None, **kw)
+        with oracle.options(optbit):
+            rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj, **kw)
+            loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+            g_o = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None, **kw)
         nf = int((dr.last_face_idx.cpu().numpy() != fidx_o).sum())
         errs = {"rgba": float(np.abs(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy() - rgba_o).max())}
         for k in LEAVES:

@@ -1,20 +1,23 @@
-// mm_backward.hip -- pixel-stage backward of the render path for gfx950, without a single floating-point atomic on HBM.
+// mm_backward.hip -- the GATHER half of the render path's backward for gfx950: no floating-point atomic anywhere, on HBM or in LDS.
 //
-// kaolin's backward kernels (rasterize_backward_cuda, dibr_soft_mask_backward_cuda) and torch's grid_sampler backward
-// SCATTER per-pixel contributions with atomicAdd.  On MI355X an agent-scope float atomic is executed at the memory side
-// of the fabric (the eight XCD L2s are not coherent with each other), ~17 G atomics/s measured, and this path would issue
-// ~5 M of them per batch.  The backward is therefore organised as two GATHER passes (SURVEY.md Appendix A for the math):
+// kaolin's backward kernels (rasterize_backward_cuda, dibr_soft_mask_backward_cuda) and torch's grid_sampler backward SCATTER per-pixel
+// contributions with atomicAdd.  On MI355X an agent-scope float atomic is executed at the memory side of the fabric (the eight XCD L2s are
+// not coherent with each other), ~17 G atomics/s measured, and this path would issue ~5 M of them per batch; an LDS float atomic costs
+// ~81 ns of the CU's LDS unit per wave-instruction whatever the addresses (profiles/r02_lds_atomic_calibration.txt).  The backward is
+// therefore two passes (SURVEY.md Appendix A for the math):
 //
-//   1. pixel_bwd   pixel-major, one lane per pixel: re-shades the pixel, writes dL/dbg, reduces dL/dlights per
-//                  workgroup (plain stores of partials), and leaves for every covered pixel the nine numbers the gather
-//                  needs: d/d(texture sample rgb), d/d(mask), d/d(u,v), d/d(normal).
-//   2a. texture_gather  one workgroup per (image, 32x32-texel texture tile), the tile's accumulators in LDS: it streams the
-//                  RECORD list the pixel pass appended for the tile (one record per covered pixel and tile under its bilinear
-//                  footprint; slots handed out by one returning atomic per wave and tile), adds each footprint to the LDS
-//                  tile (LDS float adds) and writes the tile once with plain stores: no zero-fill pass over grad_textures.
-//   2b. face_gather  8 lanes per (image, face) sweep the face's inflated screen box: pixels it owns give the K2
-//                  barycentric gradient, uncovered pixels that hold the face among their first knum soft-mask faces give
-//                  K4.  dL/d(face xy) and dL/d(face normal) are written once per face with plain stores.
+//   1. pixel_bwd (mm_pixel_bwd.hip, compiled like the forward: see mm_backward.h)   pixel-major, one lane per pixel: re-shades the pixel,
+//      writes dL/dbg, reduces dL/dlights per workgroup, leaves for every covered pixel the nine K2 numbers of its face (gp, gp2), for every
+//      uncovered one dL/dalpha, per image the maxima that fix the gather's fixed-point scales, and APPENDS the pixel's texture contribution
+//      to the record list of every 32x32-texel tile under its bilinear footprint.  Its first workgroups plan the face sweep (sweep items).
+//   2. gather_bwd (this file), one launch, two kinds of workgroup:
+//      a. texture tiles   one workgroup per (image, tile): streams the tile's record list into INT32 fixed-point LDS accumulators (per-tile
+//         power-of-two scale) and writes the tile once with plain stores: no zero-fill pass over grad_textures.
+//      b. face sweep      8 lanes per sweep item (a 128-pixel chunk of a face's inflated screen box; an image's items are dealt to its waves
+//         round-robin): pixels the face owns give K2 (add the pixel pass's numbers), uncovered pixels that hold the face among their first
+//         knum silhouette faces give K4; hits are ballot-compacted over the wave and finished by all 64 lanes into INT64 fixed-point per-item
+//         LDS sums; one plain store per item, added up per face in index order by the vertex backward.
+//   Integer adds commute exactly: the whole backward is bitwise reproducible.
 #include <cstdlib>
 #include "mm_backward.h"
 

@@ -1,15 +1,16 @@
-// mm_raster.hip -- pixel stage of the render path for gfx950 (forward and backward).
+// mm_raster.hip -- pixel stage of the render path's FORWARD for gfx950: the fused walk + shade kernel and the tile sort (the backward is
+// mm_pixel_bwd.hip + mm_backward.hip).
 //
 // Replaces, fused into one launch per direction, what the reference reaches through kaolin for every pixel
 // (call sites /root/reference/networks.py:297-317; semantics SURVEY.md 8(a) rows a8-a11, gradients Appendix A):
 //   packed_rasterize_forward  (K1)  nearest front-facing face per pixel, barycentric interpolation
 //   dibr_soft_mask_forward    (K3)  1 - prod(1 - exp(-sigma d^2)) over the first <= knum nearby faces
-//   texture_mapping / grid_sample, spherical_harmonic_lighting, composite, clamp, cat
-// and their backward kernels (K2, K4, grid_sampler backward, SH backward).
+//   texture_mapping / grid_sample, spherical_harmonic_lighting, composite, clamp, cat   [+ the forward of recon_data when fused]
 //
 // Design (not kaolin's pixel-major brute force over all faces):
-//   * a wave owns an 8x8 pixel tile, one lane per pixel (one wave per workgroup).
-//   * the bin kernel left, per screen bin, a bit-per-face mask of the faces whose pixel box, inflated by the silhouette
+//   * a wave owns an 8x8 pixel tile, one lane per pixel; tiles are taken in the order the sort kernel left (most candidates first: a launch
+//     lasts as long as its slowest tile), heavy tiles by the four waves of a workgroup together, empty tiles four per wave.
+//   * the vertex stage left, per screen bin, a bit-per-face mask of the faces whose pixel box, inflated by the silhouette
 //     margin, touches it.  The wave loads its bin's mask words coalesced, turns the set bits into an ORDERED candidate
 //     list with popcount + wave prefix sum (face order = bit order, which the soft mask's "first knum faces" rule needs)
 //     and stages 64 candidates at a time in LDS (struct-of-arrays float4 rows) -- ONE walk serves colour and silhouette.
@@ -20,6 +21,7 @@
 //     exact, commutative LDS atomics: 64-bit max of (orderable z, ~face id) for colour -- argmax over (z, -index) is
 //     exactly kaolin's "strict z > best in index order" -- and an integer sum of log2(1-p) for the silhouette.  A wave's
 //     critical path is pairs/64 evaluations, not its busiest pixel, and results do not depend on evaluation order.
+//   * the epilogue (winner -> uv -> texels -> shade -> store) is written as TWO dependent trips to memory (mm_raster_common.h: shade_store).
 #include "mm_raster_walk.h"
 
 MM_TIMELINE_STORAGE(raster_fwd)

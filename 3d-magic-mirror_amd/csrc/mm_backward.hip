@@ -292,8 +292,9 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
     }
     for (int k = sl; k < 9; k += MM_FL) st->slot[grp].acc[k] = 0ll;
     int nmax = hi - lo;
-#pragma unroll
-    for (int o = MM_FL; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    nmax = max(nmax, (int)lane_xchg<8>((unsigned)nmax, lane)); nmax = max(nmax, (int)lane_xchg<16>((unsigned)nmax, lane));
+    nmax = max(nmax, (int)lane_xchg<32>((unsigned)nmax, lane));
+    static_assert(MM_FL == 8, "the exchange strides above start at the lanes-per-item count");
     wave_sync_lds();
     MM_PP_MARK(0);
 

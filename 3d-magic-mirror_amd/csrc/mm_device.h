@@ -430,13 +430,33 @@ __device__ inline int ballot_rank(uint64_t bal) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
 }
 
+// lane <-> lane ^ S exchange of a 32-bit value WITHOUT the LDS crossbar: DPP lane selects for S = 1, 2, 4, 8 (quad permutes, half-row
+// mirror, row rotate) and gfx950's v_permlane16_swap / v_permlane32_swap for S = 16, 32.  A ds_bpermute costs an address VGPR, an LDS
+// instruction and ~100 cycles of latency on the wave's critical path; a 64x64 bit transpose made twelve of them, dependent in pairs.
+// (checked against the definition on the box: profiles/tools/xchg_test.hip)
+typedef unsigned mm_v2u __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ inline unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+template <int S>
+__device__ inline unsigned lane_xchg(unsigned v, int lane) {
+    if constexpr (S == 1) return dpp_u32<0xB1>(v);                       // quad_perm [1,0,3,2]
+    else if constexpr (S == 2) return dpp_u32<0x4E>(v);                  // quad_perm [2,3,0,1]
+    else if constexpr (S == 4) return dpp_u32<0x1B>(dpp_u32<0x141>(v));  // row_half_mirror (^7) then quad_perm [3,2,1,0] (^3)
+    else if constexpr (S == 8) return dpp_u32<0x128>(v);                 // row_ror:8
+    else if constexpr (S == 16) { const mm_v2u r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane & 16) ? r.x : r.y; }
+    else { const mm_v2u r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? r.x : r.y; }
+}
+
+template <int S>
+__device__ inline float xchg_f32(float v, int lane) { return __uint_as_float(lane_xchg<S>(__float_as_uint(v), lane)); }
+
 // 64x64 bit-matrix transpose across the wave: lane i holds row i on entry and column i on exit (6 butterfly stages).
 template <int S>
 __device__ inline uint64_t transpose_stage(uint64_t x, int lane) {
     // m: bit positions whose index has bit S clear
     constexpr uint64_t m = S == 32 ? 0x00000000FFFFFFFFull : S == 16 ? 0x0000FFFF0000FFFFull : S == 8 ? 0x00FF00FF00FF00FFull
                          : S == 4 ? 0x0F0F0F0F0F0F0F0Full : S == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
-    const unsigned lo = __shfl_xor((unsigned)x, S, 64), hi = __shfl_xor((unsigned)(x >> 32), S, 64);
+    const unsigned lo = lane_xchg<S>((unsigned)x, lane), hi = lane_xchg<S>((unsigned)(x >> 32), lane);
     const uint64_t y = ((uint64_t)hi << 32) | lo;
     return (lane & S) ? (((y >> S) & m) | (x & ~m)) : ((x & m) | ((y & m) << S));
 }
@@ -449,6 +469,25 @@ __device__ inline uint64_t wave_transpose64(uint64_t x, int lane) {
     x = transpose_stage<2>(x, lane);
     x = transpose_stage<1>(x, lane);
     return x;
+}
+
+// Exclusive prefix sum over the wave (total = the wave's sum, in every lane): the classic DPP scan -- row_shr 1, 2, 4, 8 inside the
+// 16-lane rows (lanes shifted in from outside a row read 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.
+// Six VALU instructions with cross-lane operands instead of six dependent ds_bpermute round trips (~100 cycles each); the walk kernels
+// scan twice per batch of candidates.  Integer adds: the result is the same whatever the order.
+template <int CTRL, int ROWS, bool BOUND>
+__device__ inline int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xF, BOUND); }
+__device__ inline int wave_prefix_excl(int v, int lane, int& total) {
+    (void)lane;
+    int inc = v;
+    inc += dpp_i32<0x111, 0xF, true>(inc);                       // row_shr:1
+    inc += dpp_i32<0x112, 0xF, true>(inc);                       // row_shr:2
+    inc += dpp_i32<0x114, 0xF, true>(inc);                       // row_shr:4
+    inc += dpp_i32<0x118, 0xF, true>(inc);                       // row_shr:8
+    inc += dpp_i32<0x142, 0xA, false>(inc);                      // row_bcast:15 -> rows 1, 3
+    inc += dpp_i32<0x143, 0xC, false>(inc);                      // row_bcast:31 -> rows 2, 3
+    total = __builtin_amdgcn_readlane(inc, 63);
+    return inc - v;
 }
 
 // ---- screen binning of one wave's 64 faces = mask word c of every bin -------------------------------------------------

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void prepare_bwd_kernel(MMPrepareDesc d, MMPre
             }
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { dv[j] += __shfl_xor(dv[j], 4, 8); dv[j] += __shfl_xor(dv[j], 2, 8); dv[j] += __shfl_xor(dv[j], 1, 8); }
+        for (int j = 0; j < 3; ++j) { dv[j] += xchg_f32<4>(dv[j], tid); dv[j] += xchg_f32<2>(dv[j], tid); dv[j] += xchg_f32<1>(dv[j], tid); }
         if (cl == 0) {
             float* gv = g.grad_vertices + ((size_t)b * d.V + v) * 3;
 #pragma unroll

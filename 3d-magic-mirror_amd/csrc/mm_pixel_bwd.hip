@@ -59,9 +59,8 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
             const int f0 = min(a.F, (k * 256 + tid) * per), f1 = min(a.F, f0 + per);
             mine[k] = 0;
             for (int f = f0; f < f1; ++f) mine[k] += chunks(f, shift);
-            int inc = mine[k];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += n; }
+            int wsum;
+            const int inc = wave_prefix_excl(mine[k], tid & 63, wsum) + mine[k];
             if (k == q) pre = inc - mine[k];
             if (k == 0) __syncthreads();                         // (s_wave of the previous round has been read)
             if ((tid & 63) == 63) s_wave[k][tid >> 6] = inc;

@@ -63,17 +63,6 @@ __device__ inline void tile_pixels(const RasterArgs& a, TileCtx& t) {
     for (int i = 0; i < MM_TILE; ++i) { t.xs[i] = pixel_x(t.tx0 + i, a.W, a.mult); t.ys[i] = pixel_y(t.ty0 + i, a.H, a.mult); }
 }
 
-__device__ inline int wave_prefix_excl(int v, int lane, int& total) {
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int n = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += n;
-    }
-    total = __shfl(inc, 63, 64);
-    return inc - v;
-}
-
 __device__ inline void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

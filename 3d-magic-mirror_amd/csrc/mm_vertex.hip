@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         MM_PP_MARK(1);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            d[j] += __shfl_xor(d[j], 4, 8); d[j] += __shfl_xor(d[j], 2, 8); d[j] += __shfl_xor(d[j], 1, 8);
+            d[j] += xchg_f32<4>(d[j], tid); d[j] += xchg_f32<2>(d[j], tid); d[j] += xchg_f32<1>(d[j], tid);
         }
         if (cl == 0) {
             float* gv = a.grad_vertices + ((size_t)b * a.V + v) * 3;

@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
     const float xmax = fmaxf(fmaxf(p0.x, p0.z), p1.x), ymax = fmaxf(fmaxf(p0.y, p0.w), p1.y);
     const float s2 = a.mult * a.mult;
     int nmax = npx;
-#pragma unroll
-    for (int s = MM_DB_FL; s < 64; s <<= 1) nmax = max(nmax, __shfl_xor(nmax, s, 64));
+    static_assert(MM_DB_FL == 16, "the exchange strides below start at the lanes-per-face count");
+    nmax = max(nmax, (int)lane_xchg<16>((unsigned)nmax, threadIdx.x & 63)); nmax = max(nmax, (int)lane_xchg<32>((unsigned)nmax, threadIdx.x & 63));
     wave_lds_sync();
     for (int base = 0; base < nmax; base += MM_DB_FL) {
         const int idx = base + sl;

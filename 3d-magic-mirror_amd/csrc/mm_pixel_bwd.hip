@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
         unsigned long long pending = __ballot(rtile[c] >= 0);
         while (pending) {
             const int ld = __ffsll((unsigned long long)pending) - 1;
-            const int tile = __shfl(rtile[c], ld, 64);
+            const int tile = __builtin_amdgcn_readlane(rtile[c], ld);   // (`ld` is wave-uniform: a scalar lane select, no LDS-crossbar round trip per tile)
             const unsigned long long m = __ballot(rtile[c] == tile);
             if (rtile[c] == tile) { leader[c] = ld; rank[c] = ballot_rank(m); size = __popcll(m); }
             pending &= ~m;

@@ -32,8 +32,11 @@ namespace mm {
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef MM_RASTER_LB
+#define MM_RASTER_LB 5
+#endif
 template <bool kNoMask, bool kBlock>
-__global__ __launch_bounds__(kBlock ? 256 : 64, kBlock ? 5 : 1) void raster_fwd_kernel(RasterArgs a) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
+__global__ __launch_bounds__(kBlock ? 256 : 64, kBlock ? MM_RASTER_LB : 1) void raster_fwd_kernel(RasterArgs a) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
     MM_TIMELINE_BEGIN();
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
     MM_PP_BEGIN();

@@ -86,7 +86,7 @@ __device__ inline int idw_next(IdWindows& iw, const TileCtx& t, WaveStage* st) {
     const int end = iw.pre + iw.pc;
     const bool part = t.lane >= iw.first && end - iw.done <= MM_GROUP_WORDS * 64;   // whole words, contiguous from `first` (a word holds <= 64 ids)
     const int last = 63 - __clzll((unsigned long long)__ballot(part));
-    const int wend = __shfl(end, last, 64);
+    const int wend = __builtin_amdgcn_readlane(end, last);         // (`last` is wave-uniform: a scalar lane select, not an LDS-crossbar shuffle)
     if (part) {
         uint64_t w = iw.w;
         int pos = iw.pre - iw.done;

@@ -175,7 +175,19 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
             const float* part = a.part + ((size_t)b * a.item_cap + cm.x) * 12;
-            for (int c = 0; c < cm.y; ++c) {
+            // the first four items' sums in ONE trip (clamped addresses, selected afterwards: a loop over a per-lane count costs a dependent
+            // trip per item, and faces of two or three items are common); the rare rest one by one.  Added in index order either way.
+            float pk[4][5];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float* pc4 = a.part + ((size_t)b * a.item_cap + min(cm.x + min(c, max(cm.y - 1, 0)), a.item_cap - 1)) * 12;   // (a face without items still addresses a valid row)
+                pk[c][0] = pc4[k * 2]; pk[c][1] = pc4[k * 2 + 1]; pk[c][2] = pc4[6]; pk[c][3] = pc4[7]; pk[c][4] = pc4[8];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < cm.y) { gx += pk[c][0]; gy += pk[c][1]; g[0] += pk[c][2]; g[1] += pk[c][3]; g[2] += pk[c][4]; }
+            }
+            for (int c = 4; c < cm.y; ++c) {
                 gx += part[c * 12 + k * 2]; gy += part[c * 12 + k * 2 + 1];
                 g[0] += part[c * 12 + 6]; g[1] += part[c * 12 + 7]; g[2] += part[c * 12 + 8];
             }

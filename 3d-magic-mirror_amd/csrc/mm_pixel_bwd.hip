@@ -121,34 +121,41 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     }
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int hf = -1;
-    if (a.gt) {
-        // fused recon_data backward (Appendix A.4); the image's totals are exact integer sums left by its raster waves
+    // fused recon_data backward (Appendix A.4): dL/dpred_c = kl1 * sign(pred_c' - gt_c') * gm needs the PREDICTION -- which this pass
+    // recomputes anyway, bit for bit (it is compiled like the forward for that reason: mm_backward.h), so the forward image is not read
+    // back (16 bytes per pixel of a bandwidth-bound kernel); the sign is taken where the pixel's colour is re-formed (grad_colour below).
+    float gi3[3] = {0.f, 0.f, 0.f}, gmv = 0.f, kl1 = 0.f;
+    const bool fused = a.gt != nullptr;
+    if (fused) {
+        // the image's totals are exact integer sums left by its raster waves
         float l1s, up, un;
         loss_totals(a.ltot, b, l1s, up, un);
         const float U = un + 1e-10f;
         const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
         // everything that is the same for all pixels of the image is folded into three coefficients (wave-uniform arithmetic
         // once, instead of four divisions per lane): dL/dpred_c = kl1 * sign * gm,  dL/dalpha = ka * gm + kb * (1 - gm)
-        const float kl1 = gs * a.image_weight / ((float)a.B * 3.f * (float)a.H * (float)a.W);
+        kl1 = gs * a.image_weight / ((float)a.B * 3.f * (float)a.H * (float)a.W);
         const float ka = -gs / ((float)a.B * U), kb = gs * up / ((float)a.B * U * U);
         if (in_img) {
             hf = a.face_idx[pix];
-            const float4 pr = *(const float4*)(a.rgba + pix * 4);
             const float* g = a.gt + (size_t)b * 4 * hw;
             const float gm = g[3 * hw + pin];
-            float gq[3];
-            const float prc[3] = {pr.x, pr.y, pr.z};
+            gmv = gm;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float gi = g[c * hw + pin] * gm + 1.f * (1.f - gm);
-                const float pi = prc[c] * gm + 1.f * (1.f - gm);
-                const float df = pi - gi, sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-                gq[c] = kl1 * sg * gm;
-            }
-            g4 = make_float4(gq[0], gq[1], gq[2], ka * gm + kb * (1.f - gm));
+            for (int c = 0; c < 3; ++c) gi3[c] = g[c * hw + pin] * gm + 1.f * (1.f - gm);
+            g4.w = ka * gm + kb * (1.f - gm);
         }
     } else if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
     const float gin[3] = {g4.x, g4.y, g4.z};
+    // dL/d(colour c of this pixel) given its un-clamped value `pre`: the caller's gradient, or the fused loss's (the forward's clamp and
+    // masking expressions, shade_store / shade_empty_tiles + networks.py:370-377)
+    auto grad_colour = [&](int c, float pre) -> float {
+        if (!fused) return gin[c];
+        const float pc = pre < 0.f ? 0.f : (pre > 1.f ? 1.f : pre);
+        const float pi = pc * gmv + 1.f * (1.f - gmv);
+        const float df = pi - gi3[c], sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        return kl1 * sg * gmv;
+    };
     float m2 = 0.f, m4 = 0.f;                                    // this lane's largest |K2 number| / |dL/dalpha|: the gather's fixed-point scale
     if (in_img && hf < 0) { a.gp2[pix] = g4.w; m4 = fabsf(g4.w); }   // the face gather (K4) needs dL/dalpha of uncovered pixels
     float dl[9];
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float pre = bgv[c] * coef;
-                const float g = (pre >= 0.f && pre <= 1.f) ? gin[c] : 0.f;      // torch.clamp backward mask
+                const float g = (pre >= 0.f && pre <= 1.f) ? grad_colour(c, pre) : 0.f;      // torch.clamp backward mask
                 dc += g * bgv[c];
                 a.grad_bg[((size_t)b * 3 + c) * hw + pin] = g * coef;
             }
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
                 const float bgvc = bgv[c];
                 const float base = tc * m + bgvc * (1.f - m);
                 pre = base * coef;
-                const float g = (pre >= 0.f && pre <= 1.f) ? gin[c] : 0.f;      // torch.clamp backward mask
+                const float g = (pre >= 0.f && pre <= 1.f) ? grad_colour(c, pre) : 0.f;      // torch.clamp backward mask
                 dc += g * base;
                 const float dbase = g * coef;
                 dtc = dbase * m;
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
                 dm += dbase * (tc - bgvc);
             } else {
                 pre = (tc * m) * coef + 1.f * (1.f - m);
-                const float g = (pre >= 0.f && pre <= 1.f) ? gin[c] : 0.f;
+                const float g = (pre >= 0.f && pre <= 1.f) ? grad_colour(c, pre) : 0.f;
                 dc += g * (tc * m);
                 dtc = (g * coef) * m;
                 dm += g * (tc * coef - 1.f);

@@ -83,8 +83,8 @@ typedef struct MMRenderDesc {
     void** prof_events;
     /* optional FUSED reconstruction loss = DiffRender.recon_data with contour = 0 (networks.py:364-378) folded into the render
      * kernels: with fused_gt set, mm_render_forward also reduces the loss terms while it shades, and mm_render_backward
-     * derives dL/d rgba on the fly from `rgba` (which must still hold the forward's image) and fused_gt (MMRenderGrads.grad_rgba is
-     * then ignored and may be NULL) and writes the loss value.
+     * derives dL/d rgba on the fly from fused_gt and the prediction it re-forms per pixel, bit for bit (`rgba` is not read back: the caller
+     * may already have overwritten it; MMRenderGrads.grad_rgba is then ignored and may be NULL) and writes the loss value.
      * Same arithmetic as mm_recon_data_forward/backward; saves three launches and the grad_rgba round trip. */
     const float* fused_gt;          /* (B,4,H,W) dense rgb + mask, or NULL */
     float fused_image_weight;       /* DiffRender.image_weight */

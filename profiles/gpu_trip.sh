@@ -17,11 +17,16 @@ if [ -z "$SKIP_TESTS" ]; then
 fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_calib profiles/tools/valu_calib.hip && timeout 120 /tmp/valu_calib > $OUT/valu_calibration.json; cat $OUT/valu_calibration.json
 for C in $CONFIGS; do
-  EXTRA=""; [ "$C" != "config2" ] && EXTRA="--trainer-steps 0 --cpu-seconds 0 --steps 200"
-  timeout 900 python bench.py --config $C $EXTRA > $OUT/bench_$C.json 2> $OUT/bench_$C.err; echo "bench $C rc=$?"; cut -c1-1500 $OUT/bench_$C.json
   timeout 1200 bash profiles/run_profile.sh $C > $OUT/profile_$C.log 2>&1
   python profiles/summarize_profile.py $TAG $C > $OUT/summary_$C.md 2>&1; head -40 $OUT/summary_$C.md
   # raw CSVs are big: keep the stats + counter tables, drop the per-dispatch kernel traces of the PMC passes
   find gpurun_out/prof_$C -name "*kernel_trace.csv" -path "*pmc*" -delete
 done
+# the bench lines AFTER the counter passes, with this trip's counters installed: their roofline.traffic is then the fresh one
+cp $OUT/profiles/traffic_latest.json $OUT/profiles/valu_latest.json profiles/ 2>/dev/null
+for C in $CONFIGS; do
+  EXTRA=""; [ "$C" != "config2" ] && EXTRA="--trainer-steps 0 --cpu-seconds 0 --steps 200"
+  timeout 900 python bench.py --config $C $EXTRA > $OUT/bench_$C.json 2> $OUT/bench_$C.err; echo "bench $C rc=$?"; cut -c1-1500 $OUT/bench_$C.json
+done
+timeout 600 python bench.py --config config2x8 --trainer-steps 0 --cpu-seconds 0 --steps 200 > $OUT/bench_config2x8.json 2> $OUT/bench_config2x8.err; cut -c1-300 $OUT/bench_config2x8.json
 du -sh gpurun_out

@@ -29,8 +29,9 @@ static int check_render(const MMRenderDesc* d, bool backward) {
     if (d->knum <= 0) return MM_ERR_UNSUPPORTED;
     if (d->H > 65535 || d->W > 65535) return MM_ERR_UNSUPPORTED;                 // pixel boxes are packed in 16 + 16 bits
     if (!d->faces || !d->face_uvs || !d->vertices || !d->textures || !d->lights || !d->azimuths || !d->elevations ||
-        !d->distances || !d->biases || !d->rgba || !d->face_idx || !d->face_normals)
+        !d->distances || !d->biases || !d->face_idx || !d->face_normals)
         return MM_ERR_NULL_POINTER;
+    if (!backward && !d->rgba) return MM_ERR_NULL_POINTER;                        // (the backward never reads the image: rgba may be NULL there)
     if (d->no_mask && !d->bg) return MM_ERR_NULL_POINTER;
     if (backward && (!d->vc_offsets || !d->vc_items)) return MM_ERR_NULL_POINTER;
     if (!d->workspace || d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_WORKSPACE;

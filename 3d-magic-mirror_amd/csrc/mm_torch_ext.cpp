@@ -96,12 +96,11 @@ std::vector<at::Tensor> render_backward(int64_t f_bwd, const std::string& proto,
     if (g_fn.has_value() && g_fn->defined()) gfn = g_fn->to(at::kFloat).contiguous();
     if (fused) {
         gloss = (g_loss.has_value() && g_loss->defined()) ? g_loss->to(at::kFloat).reshape({}).contiguous() : at::ones({}, vertices.options());
-        TORCH_CHECK(rgba_fwd.has_value() && rgba_fwd->defined(), "the fused backward needs the forward's image");
         d.fused_gt = optp(gt); d.fused_image_weight = (float)image_weight; d.fused_grad_loss = fptr(gloss);
-        d.rgba = rgba_fwd->data_ptr<float>();               // the forward's image: dL/drgba is formed from it and gt inside the kernels
+        d.rgba = nullptr;                                    // the backward re-forms the prediction per pixel: the image is not read back (nor saved)
     } else {
         grgba = (g_rgba.has_value() && g_rgba->defined()) ? g_rgba->to(at::kFloat).contiguous() : at::zeros({B, H, W, 4}, vertices.options());
-        d.rgba = mptr(grgba);                                // not read by the backward; any valid pointer satisfies the NULL check
+        d.rgba = nullptr;                                    // (not read by the backward)
     }
     at::Tensor gv = at::empty_like(vertices), gt_ = at::empty_like(textures), gl = at::empty_like(lights), gbg;
     if (d.no_mask) gbg = at::empty_like(*bg);
@@ -169,7 +168,7 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
         ctx->saved_data["image_weight"] = image_weight; ctx->saved_data["fused"] = fused;
         // dense inputs, forward products the backward re-reads, and the workspace (alive until this node dies)
         ctx->save_for_backward({out[5], out[6], out[7], out[8], out[9], out[10], out[11], out[12], out[3], out[1], out[13],
-                                fused ? out[0] : at::Tensor(), ws});
+                                at::Tensor(), ws});          // (the image is not saved: the caller may overwrite it)
         ctx->mark_non_differentiable({out[3], out[2]});
         if (fused) ctx->mark_non_differentiable({out[0]});
         tensor_list ret = {out[0], out[1], out[2], out[3]};

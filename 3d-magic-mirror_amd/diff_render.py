@@ -91,8 +91,8 @@ class _RenderFn(torch.autograd.Function):
             N.check(N.lib().mm_render_fused_loss(ctypes.byref(d), N.current_stream(dev)), "mm_render_fused_loss")
         ctx.dr, ctx.no_mask, ctx.fused = dr, bool(no_mask), gt is not None
         ctx.ws_holder = holder                                   # returned to the pool when this node dies
-        ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt,
-                              rgba if gt is not None else None)   # (the fused backward re-reads the prediction)
+        ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt)
+        # (the image is not saved: the backward re-forms the prediction per pixel, bit for bit, and the caller may overwrite rgba)
         ctx.mark_non_differentiable(face_idx)
         if imn is None:
             imn = torch.empty(0, device=dev)
@@ -104,24 +104,21 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgba, g_fn, _g_imn, _g_idx, g_loss=None):
-        vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt, rgba_fwd = ctx.saved_tensors
+        vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt = ctx.saved_tensors
         ws = ctx.ws_holder.buf
         dr, dev = ctx.dr, azimuths.device
         B = azimuths.shape[0]
         H, W = dr.render_height, dr.image_size
         st = dr._static(dev)
         g_fn = None if g_fn is None else g_fn.to(torch.float32).contiguous()
-        rgba_dummy = torch.empty(0, device=dev)
-        d = dr._desc(st, B, ctx.no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases, rgba_dummy, face_idx, fn, None)
+        d = dr._desc(st, B, ctx.no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases, None, face_idx, fn, None)   # (rgba: not read by the backward)
         if ctx.fused:
             g_loss = torch.ones((), device=dev) if g_loss is None else g_loss.to(torch.float32).reshape(()).contiguous()
             d.fused_gt, d.fused_image_weight, d.fused_grad_loss = N.ptr(gt), float(dr.image_weight), N.ptr(g_loss)
-            d.rgba = N.ptr(rgba_fwd)    # the forward's image: the fused backward forms dL/drgba from it and gt
         else:
             if g_rgba is None:
                 g_rgba = torch.zeros((B, H, W, 4), device=dev, dtype=torch.float32)
             g_rgba = g_rgba.to(torch.float32).contiguous()
-            d.rgba = N.ptr(g_rgba)      # not read by the backward; any valid pointer satisfies the NULL check
         d.workspace, d.workspace_bytes = N.ptr(ws), ws.numel()
         gv, gt_, gl = torch.empty_like(vertices), torch.empty_like(textures), torch.empty_like(lights)
         gbg = torch.empty_like(bg) if ctx.no_mask else None

@@ -71,7 +71,8 @@ typedef struct MMRenderDesc {
     const float* distances;     /* (B) */
     const float* biases;        /* (B,2) */
     /* outputs (device) */
-    float* rgba;                /* (B,H,W,4): NHWC storage; the reference returns the (B,4,H,W) permute VIEW of it (:317) */
+    float* rgba;                /* (B,H,W,4): NHWC storage; the reference returns the (B,4,H,W) permute VIEW of it (:317).
+                                 * Written by mm_render_forward; NOT read by mm_render_backward (may be NULL there, fused or not) */
     int32_t* face_idx;          /* (B,H,W): winning face per pixel, -1 = none (kaolin returns int64; int32 here) */
     float* face_normals;        /* (B,F,3): unit face normals in camera space = attributes['face_normals'] (:319) */
     float* imnormal;            /* (B,H,W,3) or NULL: attributes['imnormal'] (:320, "visualize only") */

@@ -9,6 +9,7 @@ import torch
 from conftest import GOLDEN, TEMPLATES
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "distances", "biases")
 
 
@@ -281,6 +282,37 @@ def test_render_recon_is_render_plus_recon_data(pkg):
     for k in LEAVES:
         _close(got[1][2][k].cpu().numpy(), got[0][2][k].cpu().numpy(), 2e-5)
         assert float(got[1][2][k].abs().max()) > 0
+
+
+def test_fused_backward_does_not_read_the_forward_image_back(pkg):
+    """include/mm_render.h, fused_gt: the fused backward re-forms the prediction per pixel (bit for bit) instead of reading `rgba` back,
+    so a caller may overwrite the image between forward and backward: same bits for all eight gradients either way."""
+    grads = []
+    for scribble in (False, True):
+        dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 5, 96, seed=12)
+        loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=True, **datt)
+        if scribble:
+            rgbs.detach().uniform_(-3.0, 3.0)                    # (a view of the storage the forward wrote)
+        loss.backward()
+        grads.append({k: datt[k].grad.clone() for k in LEAVES})
+    for k in LEAVES:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+        assert float(grads[0][k].abs().max()) > 0
+
+
+def test_lane_exchange_primitives_on_this_gpu():
+    """mm_device.h builds its 64x64 bit transposes and prefix scans from DPP lane selects and gfx950's v_permlane16/32_swap (no LDS-crossbar
+    shuffles); profiles/tools/xchg_test.hip checks every stride, the transpose and the scan against their definitions on the device."""
+    import shutil, subprocess, tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "xchg_test")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "3d-magic-mirror_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "profiles", "tools", "xchg_test.hip"), "-o", exe], check=True, capture_output=True, timeout=300)
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "bad 0" in out.stdout, out.stdout + out.stderr
 
 
 def test_cpp_and_python_host_paths_agree(pkg):

@@ -25,6 +25,12 @@ MM_TIMELINE_STORAGE(gather_bwd)
 MM_PP_STORAGE(gather_face)      // 0 setup, 1 sweep (face_idx loads), 2 compaction, 3 item loads, 4 item arithmetic + LDS adds, 5 stores; counts: trips, items
 MM_PP_STORAGE(gather_tex)       // 0 count + first record, 1 clear, 2 records, 3 tile store; counts: records
 
+#ifndef MM_ITEM_UNROLL
+#define MM_ITEM_UNROLL 1        // hit items per lane whose loads are in flight together.  2 (as up to r02i) hides a trip per 128 hits but costs ten VGPRs: at 64
+                                // the kernel holds 8 waves per SIMD instead of 6, and occupancy is what this latency-bound launch lives on (gather_bwd us at
+                                // configs 2 / 3 / 5: 33.3 / 91.3 / 303 with 2, 31.4 / 85.3 / 279 with 1; 2 at 7 waves per SIMD: 32.4 / 87.3 / 287)
+#endif
+
 namespace mm {
 
 
@@ -315,15 +321,14 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
         wave_sync_lds();
         MM_PP_MARK(2);
         MM_PP_COUNT(1, n);
-        // two items per lane and trip where the list is long: their loads are in flight together (each round is a dependent trip to
-        // memory; the heaviest waves have nine rounds)
-        for (int j0 = 0; j0 < n; j0 += 128) {
-            ItemLoad ld[2];
+        // MM_ITEM_UNROLL items per lane and trip (each round is a dependent trip to memory; see the macro for why it is 1)
+        for (int j0 = 0; j0 < n; j0 += 64 * MM_ITEM_UNROLL) {
+            ItemLoad ld[MM_ITEM_UNROLL];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < MM_ITEM_UNROLL; ++u) {
                 const int j = j0 + u * 64 + lane;
                 ld[u].live = j < n;
-                if (u == 1 && j0 + 64 >= n) break;               // wave-uniform: a short list has no second half
+                if (u >= 1 && j0 + 64 * u >= n) break;               // wave-uniform: a short list has no second half
                 const unsigned it = st->items[ld[u].live ? j : 0];
                 const int l = it & 63, i = (it >> 6) & 0x1FF;
                 ld[u].g = l / MM_FL;
@@ -341,8 +346,8 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
             }
             MM_PP_MARK(3);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u == 1 && j0 + 64 >= n) break;
+            for (int u = 0; u < MM_ITEM_UNROLL; ++u) {
+                if (u >= 1 && j0 + 64 * u >= n) break;
                 if (ld[u].live) item_finish(a, st->slot[ld[u].g], ld[u], s2, scale);
             }
         }
@@ -386,7 +391,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
 // One launch for both gathers: they only depend on the pixel pass, and each is latency-bound with a long tail, so their
 // workgroups are interleaved in a single grid (texture tiles first: they are the heavier ones).
 #ifndef MM_GATHER_LB
-#define MM_GATHER_LB 6            // waves per SIMD the register allocation is held to (80 VGPRs, no spills; 7 would spill)
+#define MM_GATHER_LB 8            // waves per SIMD the register allocation is held to (64 VGPRs, no spills)
 #endif
 __global__ __launch_bounds__(256, MM_GATHER_LB) void gather_bwd_kernel(BwdArgs a, int ntex, int dbg_skip) {
     MM_TIMELINE_BEGIN();

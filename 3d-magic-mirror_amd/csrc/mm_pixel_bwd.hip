@@ -91,8 +91,8 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
 // 1. pixel-major pass
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef MM_PIXEL_LB
-#define MM_PIXEL_LB 4
-#endif
+#define MM_PIXEL_LB 5             // waves per SIMD the register allocation is held to: 96 VGPRs without spills (the light gradients are carried as scalar + normal, not
+#endif                            // as nine products); 5 workgroups of 28.9 KB LDS (the plan workgroups' staging) fit a CU as well
 template <bool kNoMask>
 __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) {
     MM_TIMELINE_BEGIN();
@@ -158,9 +158,8 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     };
     float m2 = 0.f, m4 = 0.f;                                    // this lane's largest |K2 number| / |dL/dalpha|: the gather's fixed-point scale
     if (in_img && hf < 0) { a.gp2[pix] = g4.w; m4 = fabsf(g4.w); }   // the face gather (K4) needs dL/dalpha of uncovered pixels
-    float dl[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) dl[i] = 0.f;
+    // dL/dlights of this pixel = dcs * sh_bands(normal): kept as the scalar and the normal (4 registers, not 9, across the record append below)
+    float dcs = 0.f, snx = 0.f, sny = 0.f, snz = 0.f;
     TexRecord rec; rec.xy = 0; rec.tx = rec.ty = rec.d0 = rec.d1 = rec.d2 = 0.f;
     int rtile[4] = {-1, -1, -1, -1};
 
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
                 dc += g * bgv[c];
                 a.grad_bg[((size_t)b * 3 + c) * hw + pin] = g * coef;
             }
-            dl[0] = dc * MM_SH_C0; dl[6] = dc * (0.f - MM_SH_C6B);
+            dcs = dc;                                            // (normal 0: bands 0 and 6 only)
         }
     } else if (in_img && (hf >= 0 || kNoMask)) {
         // recompute the forward quantities of this pixel (only face_idx and the soft-mask state were saved)
@@ -268,8 +267,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
             gix += dtc * ((tne - tnw) * ey + (tse - tsw) * s.ty);
             giy += dtc * ((tsw - tnw) * ex + (tse - tne) * s.tx);
         }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) dl[i] = dc * bnd[i];
+        dcs = dc; snx = nx; sny = ny; snz = nz;                  // dL/dlights = dc * bands(normal): formed at the end
         if (hf >= 0) {
             const float du = gix * s.mx * ((float)a.Wt / 2.f) * 2.f;
             const float dv = giy * s.my * ((float)a.Ht / 2.f) * -2.f;
@@ -342,10 +340,15 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     }
 
     // d lights: wave butterfly -> one LDS row per wave -> fixed-order partial of this workgroup (summed by vertex_bwd)
-    if (any_covered) {
+    float dl[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) dl[i] = wave_sum(dl[i]);
-    } else { dl[0] = wave_sum(dl[0]); dl[6] = wave_sum(dl[6]); }     // the other seven are zero
+    for (int i = 0; i < 9; ++i) dl[i] = 0.f;
+    if (any_covered) {
+        float bnd9[9];
+        sh_bands(snx, sny, snz, bnd9);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dl[i] = wave_sum(dcs * bnd9[i]);
+    } else { dl[0] = wave_sum(dcs * MM_SH_C0); dl[6] = wave_sum(dcs * (0.f - MM_SH_C6B)); }     // the other seven are zero
     m2 = wave_max(m2); m4 = wave_max(m4);
     if (lane == 0) {
         if (a.options & MM_OPT_SH_ORDER_XYZ) { const float tmp = dl[2]; dl[2] = dl[3]; dl[3] = tmp; }   // back to the user's light order

@@ -170,6 +170,8 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
         ctx->save_for_backward({out[5], out[6], out[7], out[8], out[9], out[10], out[11], out[12], out[3], out[1], out[13],
                                 at::Tensor(), ws});          // (the image is not saved: the caller may overwrite it)
         ctx->mark_non_differentiable({out[3], out[2]});
+        ctx->set_materialize_grads(false);                       // an output nobody used arrives as an undefined gradient, not as a zero-filled tensor (three
+                                                                 // allocations + fill launches per step when only the image feeds the loss)
         if (fused) ctx->mark_non_differentiable({out[0]});
         tensor_list ret = {out[0], out[1], out[2], out[3]};
         if (fused) ret.push_back(out[4]);

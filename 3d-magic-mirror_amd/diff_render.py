@@ -94,6 +94,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt)
         # (the image is not saved: the backward re-forms the prediction per pixel, bit for bit, and the caller may overwrite rgba)
         ctx.mark_non_differentiable(face_idx)
+        ctx.set_materialize_grads(False)                          # unused outputs arrive as None in backward, not as zero-filled tensors
         if imn is None:
             imn = torch.empty(0, device=dev)
         ctx.mark_non_differentiable(imn)

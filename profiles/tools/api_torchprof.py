@@ -1,5 +1,5 @@
 """torch.profiler (CPU activities) over the autograd-API step: which ATen ops / autograd nodes the host time of run_backward goes to.
-   python profiles/tools/api_torchprof.py [steps]"""
+   python profiles/tools/api_torchprof.py [steps] [fused]"""
 import sys, importlib, os, torch
 from torch.profiler import profile, ProfilerActivity
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,6 +8,7 @@ pkg = importlib.import_module("3d-magic-mirror_amd")
 dev = torch.device("cuda:0")
 LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "distances", "biases")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+fused = len(sys.argv) > 2 and sys.argv[2] == "fused"
 dr = pkg.DiffRender(os.path.join(ROOT, "tests/golden/templates/smpl_uv_642.npz"), 128, emit_imnormal=False)
 att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, 48, 128, 128, seed=0)
 datt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}
@@ -15,8 +16,11 @@ for k in LEAVES: datt[k] = datt[k].clone().requires_grad_(True)
 gtd = gt.to(dev)
 def one():
     for k in LEAVES: datt[k].grad = None
-    rgbs, _ = dr.render(no_mask=True, **datt)
-    dr.recon_data(rgbs, gtd, no_mask=True).backward()
+    if fused:
+        dr.render_recon(gtd, no_mask=True, **datt)[0].backward()
+    else:
+        rgbs, _ = dr.render(no_mask=True, **datt)
+        dr.recon_data(rgbs, gtd, no_mask=True).backward()
 for _ in range(50): one()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU]) as prof:

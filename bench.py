@@ -273,11 +273,15 @@ def main():
 
     # untimed settling phase before the W warmup steps: clocks and queues of a device that has just been idle ramp over hundreds of
     # milliseconds, longer than W short steps last
+    # (no collective in here: this loop runs for a TIME, i.e. a different number of steps on every rank, and ranks that issue different
+    #  numbers of all-reduces deadlock; the reducer's cadence is switched on below, from counters that are equal on all ranks)
+    grad_every[0] = 1 << 30
     settle = time.perf_counter()
     while time.perf_counter() - settle < args.settle_seconds:
         for _ in range(32):
             one()
         torch.cuda.synchronize(dev)
+    ctr[0] = 0                                                   # step counters equal on all ranks from here on (they drive the collective cadence)
     if reducer is not None:
         # A 135 MB ring all-reduce takes milliseconds of xGMI time; a render step takes well under 0.1 ms: no schedule hides one reduction
         # per render step (the trainer hides it behind the encoder's ~90 ms per iteration).  What the render path can be measured against is
@@ -291,6 +295,7 @@ def main():
         ew = timed(lambda: one(), 200)
         grad_every[0] = max(1, int(np.ceil(1.25 * (e3 / 10) / (ew / 200)))) if args.grad_every is None else max(1, args.grad_every)
         reducer.launched = 0
+        ctr[0] = 0
     for _ in range(args.warmup):
         one()
     if reducer is not None:

@@ -157,6 +157,34 @@ class GradAllReducer:
         return self.flat.numel() * self.flat.element_size()
 
 
+class ReduceSchedule:
+    """Which steps of a loop launch the gradient all-reduce.  Every rank must issue the SAME collectives in the same order, so the
+    decision may only depend on things that are equal on all ranks: a step counter that is reset at points all ranks reach together, and
+    a cadence K agreed on from max-over-ranks timings.  A loop that runs for a TIME (bench.py's settling phase) executes a different
+    number of steps on every rank: the schedule must be off() there -- ranks that launch different numbers of all-reduces deadlock."""
+
+    def __init__(self, reducer):
+        self.reducer, self.every, self.k = reducer, None, 0
+
+    def off(self):
+        self.every = None
+
+    def start(self, every):
+        """Switch the cadence on (or restart it): the next step launches a reduction, then every `every`-th one."""
+        self.every, self.k = max(1, int(every)), 0
+
+    def step(self):
+        """Call once per step, after the step's work has been enqueued."""
+        if self.reducer is None or self.every is None:
+            return False
+        k = self.k
+        self.k += 1
+        if k % self.every == 0:
+            self.reducer.launch()
+            return True
+        return False
+
+
 def broadcast_(tensor, src=0):
     """e.g. the EM template update (trainer.py:1100): rank 0's vertices_init to everyone."""
     if dist.is_initialized() and dist.get_world_size() > 1:

@@ -219,7 +219,9 @@ def main():
 
     allreduce_ms = None
     ctr = [0]
-    grad_every = [1]                                             # a gradient all-reduce is launched every grad_every[0] steps (N > 1; set below)
+    sched = par.ReduceSchedule(reducer)                          # which steps launch the gradient all-reduce (N > 1): off until the cadence is agreed on
+    sched1 = par.ReduceSchedule(reducer)                         # the same for the one-stream leg
+    every_k = None
 
     def one_multi():
         k = ctr[0]; ctr[0] += 1
@@ -228,8 +230,7 @@ def main():
         if nrot > 1:
             st.set_inputs(*batches[s_][(k // nstreams) % nrot])
         st.run(streams_[s_] if nstreams > 1 else None)
-        if reducer is not None and k % grad_every[0] == 0:
-            reducer.launch()          # waits (on its own stream) for the current stream only; overlaps the following steps
+        sched.step()                  # (a launch waits, on its own stream, for the current stream only; it overlaps the following steps)
 
     ctr1 = [0]
 
@@ -238,8 +239,7 @@ def main():
         if nrot > 1:
             step.set_inputs(*batches[0][k % nrot])
         step.run()
-        if reducer is not None and k % grad_every[0] == 0:
-            reducer.launch()
+        sched1.step()
 
     # the DiffRender autograd path (what trainer.py calls): imnormal materialised, workspace from the per-object pool
     dr_api = pkg.DiffRender(tpath, S, ratio=ratio)
@@ -275,13 +275,12 @@ def main():
     # milliseconds, longer than W short steps last
     # (no collective in here: this loop runs for a TIME, i.e. a different number of steps on every rank, and ranks that issue different
     #  numbers of all-reduces deadlock; the reducer's cadence is switched on below, from counters that are equal on all ranks)
-    grad_every[0] = 1 << 30
+    sched.off()
     settle = time.perf_counter()
     while time.perf_counter() - settle < args.settle_seconds:
         for _ in range(32):
             one()
         torch.cuda.synchronize(dev)
-    ctr[0] = 0                                                   # step counters equal on all ranks from here on (they drive the collective cadence)
     if reducer is not None:
         # A 135 MB ring all-reduce takes milliseconds of xGMI time; a render step takes well under 0.1 ms: no schedule hides one reduction
         # per render step (the trainer hides it behind the encoder's ~90 ms per iteration).  What the render path can be measured against is
@@ -291,16 +290,15 @@ def main():
         reducer.wait(); torch.cuda.synchronize(dev)
         e3 = timed(lambda: (reducer.launch(), reducer.wait()), 10)
         allreduce_ms = round(e3 / 10 * 1e3, 3)
-        grad_every[0] = 1 << 30
-        ew = timed(lambda: one(), 200)
-        grad_every[0] = max(1, int(np.ceil(1.25 * (e3 / 10) / (ew / 200)))) if args.grad_every is None else max(1, args.grad_every)
+        ew = timed(lambda: one(), 200)                           # (schedule still off: the step alone)
+        every_k = max(1, int(np.ceil(1.25 * (e3 / 10) / (ew / 200)))) if args.grad_every is None else max(1, args.grad_every)
         reducer.launched = 0
-        ctr[0] = 0
+        sched.start(every_k)
     for _ in range(args.warmup):
         one()
     if reducer is not None:
         reducer.wait()
-        ctr[0] = 0                                               # the first timed step launches a reduction
+        sched.start(every_k)                                     # the first timed step launches a reduction
     elapsed = timed(lambda: one(), args.steps)
     launched_timed = reducer.launched if reducer is not None else 0
     if reducer is not None:
@@ -309,6 +307,8 @@ def main():
 
     one_stream = api_value = api_fused_value = None
     if args.mode == "eager":
+        if reducer is not None:
+            sched1.start(every_k)
         for _ in range(min(args.warmup, 20)):
             one_single()
         e1 = timed(one_single, args.steps)
@@ -428,7 +428,7 @@ def main():
                        "imnormal": "not materialised in value / value_one_stream (visualise-only output, networks.py:320); materialised in value_api",
                        "sharding": "batch, no data-path collective",
                        "grad_allreduce": None if reducer is None else
-                                         {"mb_per_reduction_per_rank": round(reducer.bytes_per_step() / 1e6, 1), "every_k_steps": grad_every[0],
+                                         {"mb_per_reduction_per_rank": round(reducer.bytes_per_step() / 1e6, 1), "every_k_steps": every_k,
                                           "launched_in_timed_region": launched_timed, "alone_ms": allreduce_ms, "overlapped": True,
                                           "policy": "one reduction in flight at all times, back to back on a side stream, concurrent with the render "
                                                     "streams: K = ceil(1.25 x reduction alone / step alone), agreed on from max-over-ranks timings"}},

@@ -57,6 +57,19 @@ def _worker(rank, world, port, out):
     flat.mul_(rank + 1.0)
     red.launch(); red.launch()                                    # a second launch first waits for the one in flight
     red.wait()
+    # the cadence of bench.py's N > 1 leg: a settling phase that lasts a different number of steps on every rank must not launch anything
+    # (ranks issuing different numbers of collectives deadlock); once started, every rank launches at the same steps
+    flat2 = torch.full((64,), float(rank + 1))
+    red2 = par.GradAllReducer(flat2, chunk_bytes=64)
+    sched = par.ReduceSchedule(red2)
+    sched.off()
+    for _ in range(5 + 3 * rank):                                 # "time-based": rank-dependent step count
+        assert not sched.step()
+    sched.start(3)
+    fired = [sched.step() for _ in range(10)]                     # steps 0, 3, 6, 9
+    red2.wait()
+    sched_none = par.ReduceSchedule(None); sched_none.start(1)
+    assert not sched_none.step()
     # unequal shards (B % world != 0): weighting by the local batch size gives the global-batch mean of per-rank batch means
     lo5, hi5 = par.shard_bounds(5, rank, world)
     per_image = torch.arange(5, dtype=torch.float32) + 1.0       # "per-image gradient"
@@ -68,7 +81,7 @@ def _worker(rank, world, port, out):
     par.barrier()
     if rank == 0:
         torch.save({"gW": gW, "loss": lt, "extra": extra, "tmax": tmax, "bc": v, "step1": step1, "step2": flat, "launched": red.launched,
-                    "bytes": red.bytes_per_step(), "wmean": local_mean, "umean": unweighted}, out)
+                    "bytes": red.bytes_per_step(), "wmean": local_mean, "umean": unweighted, "fired": fired, "launched2": red2.launched, "flat2": flat2}, out)
     torch.distributed.destroy_process_group()
 
 
@@ -95,6 +108,8 @@ def test_two_rank_sharding_matches_single_process(oracle, tmp_path):
     # ranks hold 2.25x, mean unchanged
     torch.testing.assert_close(got["step2"], base * 2.25)
     assert got["launched"] == 3 and got["bytes"] == 4000
+    assert got["fired"] == [True, False, False] * 3 + [True] and got["launched2"] == 4
+    torch.testing.assert_close(got["flat2"], torch.full((64,), 1.5))              # mean of 1 and 2, a fixed point of further means
     assert abs(float(got["wmean"]) - 3.0) < 1e-6                               # mean of 1..5
     assert abs(float(got["umean"]) - 3.25) < 1e-6                              # (2 + 4.5) / 2: what unweighted averaging would give
 

@@ -109,9 +109,11 @@ def build_torch_ext(force=False, verbose=False):
             fd, tmp = tempfile.mkstemp(prefix="ext.", suffix=".so", dir=os.path.dirname(EXT))
             os.close(fd)
             cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-DTORCH_EXTENSION_NAME=mm_torch_ext",
-                   "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), EXT_SRC, "-o", tmp] + \
-                  ["-I" + i for i in include_paths() + [sysconfig.get_paths()["include"]]] + \
-                  ["-L" + tl, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python", "-Wl,-rpath," + tl]
+                   "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+                   "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",    # torch's own HIP stream / guard headers (host code only, no device code)
+                   EXT_SRC, "-o", tmp] + \
+                  ["-I" + i for i in include_paths() + [sysconfig.get_paths()["include"], os.environ.get("ROCM_PATH", "/opt/rocm") + "/include"]] + \
+                  ["-L" + tl, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-ltorch_python", "-Wl,-rpath," + tl]
             if verbose:
                 print(" ".join(cmd))
             try:

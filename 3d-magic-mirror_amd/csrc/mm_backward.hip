@@ -251,10 +251,10 @@ __device__ inline void item_finish(const BwdArgs& a, FaceSlot& fs, const ItemLoa
         return;
     }
     const float ga = ld.q2, sq = ld.sq;                           // uncovered pixels: the pixel pass left dL/dalpha here
-    const float x0 = pixel_x(ld.px, a.W, a.mult), y0 = pixel_y(ld.py, a.H, a.mult);
-    const bool inbox = (a.options & MM_OPT_BBOX_HALF_OPEN)
-        ? !(x0 <= fs.box[0] - a.infl || x0 >= fs.box[2] + a.infl || y0 <= fs.box[1] - a.infl || y0 >= fs.box[3] + a.infl)
-        : !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl);
+    const float x0 = pixel_x_k(ld.px, a.W, a.kx), y0 = pixel_y_k(ld.py, a.H, a.ky);      // (the forward's centres, bit for bit; no division per item)
+    const int bm = box_mode(a.options);
+    const bool inbox = bm ? !(box_reject(x0, fs.box[0] - a.infl, fs.box[2] + a.infl, bm) || box_reject(y0, fs.box[1] - a.infl, fs.box[3] + a.infl, bm))
+                          : !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl);
     if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= ld.lf && inbox) {
         const float4 p0 = fs.p0, p1 = fs.p1;
         const f2 pp = {x0, y0}, ca = {p0.x, p0.y}, cb = {p0.z, p0.w}, cc = {p1.x, p1.y};
@@ -267,7 +267,7 @@ __device__ inline void item_finish(const BwdArgs& a, FaceSlot& fs, const ItemLoa
         const float p = __builtin_amdgcn_exp2f(-(h.d2 * (a.sigmainv / s2)) * 1.4426950408889634f);
         // the factor exactly as the forward folded it into the stored product (bit for bit): dividing by anything else is a large error
         // where the pixel centre lies almost on an edge (q of a few ulps)
-        const float q = soft_factor(pixel_x_k(ld.px, a.W, a.kx), pixel_y_k(ld.py, a.H, a.ky), p0, p1, a.sig2);
+        const float q = soft_factor(x0, y0, p0, p1, a.sig2);
         const float qnz = fabsf(sq);
         const bool onezero = sq < 0.f;
         const float excl = (q != 0.f) ? (onezero ? 0.f : qnz * __builtin_amdgcn_rcpf(q)) : (onezero ? qnz : 0.f);

@@ -22,7 +22,7 @@
 #define MM_CHUNK_PX 128          // (256: gather_bwd +3.5 / +4.6 / +10 us at configs 2 / 3 / 5: the waves full of owned chunks are its tail)
 #endif                        // the backward sweeps every face's inflated pixel box in chunks of this many pixels, one 8-lane group each:
                               // an even load whatever the box sizes (perspective blow-ups, close-ups at high resolution)
-#define MM_GROUP_WORDS 16     // bin-mask words (of 64 faces) expanded per step: 1024 faces -> 2 KiB of uint16 ids per wave
+#define MM_GROUP_WORDS 8      // ids expanded per window of bin-mask words: 512 -> 1 KiB of uint16 ids per wave (a window never splits a word)
 
 namespace mm {
 
@@ -71,6 +71,7 @@ struct Workspace {
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
     int* nheavy;           // (B,2)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty
+    int* bincount;         // (B,nbins)  candidates per screen bin (big screens / meshes only: bincount_kernel -> order_kernel)
     long long* ltot;       // (B,MM_LSUB,4) fused loss: per image {sum|pi-gi|, sum p*g, sum p+g-p*g, -} in 2^-32 fixed point, spread over
                            //            MM_LSUB sub-accumulators (64-bit integer atomics of the raster waves: exact, order-free); zeroed by vertex_fwd
     int* tcnt;             // (B,ntiles)+(B)+(B,MM_GSHARD,8) records appended per texture tile, per-image spill counts, per-image maxima of the pixel
@@ -115,6 +116,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.ltot = (long long*)(p + o);   o += align256((size_t)B * MM_LSUB * 4 * sizeof(long long));
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
     w.nheavy = (int*)(p + o);       o += align256((size_t)B * 2 * sizeof(int));
+    w.bincount = (int*)(p + o);     o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
     w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + (size_t)B + (size_t)B * MM_GSHARD * 8) * sizeof(int));
     w.tspill = (TexSpill*)(p + o);  o += align256((size_t)B * 4 * H * W * sizeof(TexSpill));
@@ -238,6 +240,18 @@ __device__ inline float pixel_y_k(int py, int H, float ky) {
     return ky * (float)(H - 2 * py - 1);
 }
 
+// Which box borders are OPEN (a pixel centre exactly on them is outside) -- SURVEY Appendix C-4, the three forms upstream may have:
+//   0                                   closed box            reject  x <  lo || x >  hi     (default)
+//   MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN     [lo, hi)              reject  x <  lo || x >= hi
+//   MM_OPT_BBOX_HALF_OPEN               (lo, hi)              reject  x <= lo || x >= hi
+// bit 0: the min border is open, bit 1: the max border is open
+__host__ __device__ inline int box_mode(int options) {
+    return ((options & MM_OPT_BBOX_HALF_OPEN) ? 3 : 0) | ((options & MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN) ? 2 : 0);
+}
+__device__ inline bool box_reject(float x, float lo, float hi, int mode) {                       // (straight-line on purpose: no branch per border)
+    return (x < lo) | (x > hi) | (((mode & 1) != 0) & (x == lo)) | (((mode & 2) != 0) & (x == hi));
+}
+
 // conservative pixel range [lo, hi] whose centres can satisfy  lo_v <= centre <= hi_v  (a 0.02 px slack covers the
 // rounding of this closed form by orders of magnitude; callers re-test every pixel exactly).  flip: centres fall with the index (y).
 __device__ inline void pixel_range(float lo_v, float hi_v, float mult, int n, bool flip, int& lo, int& hi) {
@@ -358,7 +372,7 @@ struct ProfScope {
 // comparable across CUs.  MM_TIMELINE_STORAGE(name) in the kernel's translation unit defines the buffer and its C getter
 // mm_debug_timeline_<name>(out[MM_TIMELINE_MAX][2]).  Everything compiles to nothing otherwise.
 #ifdef MM_TIMELINE
-#define MM_TIMELINE_MAX 16384
+#define MM_TIMELINE_MAX 81920
 #define MM_TIMELINE_STORAGE(name)                                                                                         \
     namespace mm { __device__ unsigned long long g_tl_##name[MM_TIMELINE_MAX][2]; }                                          \
     extern "C" int mm_debug_timeline_##name(unsigned long long* out) {                                                       \
@@ -559,6 +573,17 @@ __device__ inline float lane_value(float v, int lane) { return __int_as_float(__
 __device__ inline float wave_sum(float v) {
     v = row16_sum(v);
     return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ inline int wave_max_i32(int v) {                      // (same four DPP steps; the result in every lane)
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false)); v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false)); v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ inline unsigned wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false)); v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false)); v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));
+    return min(min((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
+               min((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
 }
 __device__ inline float wave_max(float v) {
     v = fmaxf(v, dpp_move<0xB1>(v)); v = fmaxf(v, dpp_move<0x4E>(v)); v = fmaxf(v, dpp_move<0x141>(v)); v = fmaxf(v, dpp_move<0x140>(v));

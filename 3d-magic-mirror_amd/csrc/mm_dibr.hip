@@ -18,7 +18,7 @@
 namespace mm {
 
 struct DibrWorkspace {
-    float4* geo; uint64_t* binmask; unsigned short* order; int* nheavy; float2* soft; int32_t* fidx;
+    float4* geo; uint64_t* binmask; unsigned short* order; int* nheavy; int* bincount; float2* soft; int32_t* fidx;
     int bin_shift, nbx, nby, words, blocks_per_image;
     size_t bytes;
 };
@@ -36,6 +36,7 @@ static DibrWorkspace carve_dibr(void* base, int B, int F, int H, int W) {
     w.binmask = (uint64_t*)(p + o);      o += align256((size_t)B * w.nbx * w.nby * w.words * sizeof(uint64_t));
     w.order = (unsigned short*)(p + o);  o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
     w.nheavy = (int*)(p + o);            o += align256((size_t)B * 2 * sizeof(int));
+    w.bincount = (int*)(p + o);          o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
     w.soft = (float2*)(p + o);           o += align256((size_t)B * H * W * sizeof(float2));
     w.fidx = (int32_t*)(p + o);          o += align256((size_t)B * H * W * sizeof(int32_t));
     w.bytes = o;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) void raster_dibr_kernel(RasterAr
 // ---------------------------------------------------------------------------------------------------------------------
 struct DibrBwdArgs {
     int B, H, W, F, D, options;
-    float mult, eps, sigmainv, infl;
+    float mult, eps, sigmainv, infl, kx, ky;
     const float4* geo; const int32_t* fidx; const float2* soft; const float* feats;
     const float* g_interp; const float* g_soft;
     float* dfvi; float* dfeat;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
         const int px = px0 + (idx - yy * bw), py = py0 + yy;
         const size_t pix = (size_t)b * hw + (size_t)py * a.W + px;
         const int fi = a.fidx[pix];
-        const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
+        const float x0 = pixel_x_k(px, a.W, a.kx), y0 = pixel_y_k(py, a.H, a.ky);
         if (fi == f && a.g_interp) {
             // K2 (Appendix A.1)
             float w0, w1, w2, nrm;
@@ -189,9 +190,8 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
             const float2 st = a.soft[pix];
             const float sq = st.x;
             const int lf = __float_as_int(st.y);
-            const bool inbox = (a.options & MM_OPT_BBOX_HALF_OPEN)
-                ? !(x0 <= xmin - a.infl || x0 >= xmax + a.infl || y0 <= ymin - a.infl || y0 >= ymax + a.infl)
-                : !(x0 < xmin - a.infl || x0 > xmax + a.infl || y0 < ymin - a.infl || y0 > ymax + a.infl);
+            const int bm = box_mode(a.options);
+            const bool inbox = !(box_reject(x0, xmin - a.infl, xmax + a.infl, bm) || box_reject(y0, ymin - a.infl, ymax + a.infl, bm));
             if (sq != 0.f && sq != 1.f && ga != 0.f && f <= lf && inbox) {
                 float qx, qy, d2, qx1, qy1, d21;
                 float t = seg_nearest_t(x0, y0, p0.x, p0.y, p0.z, p0.w, qx, qy, d2);        // edge 0: a -> b
@@ -259,10 +259,11 @@ int mm_dibr_rasterization_forward(const MMDibrDesc* d, mm_stream_t stream) {
     a.blocks_x = (d->W + MM_BLOCK_PX - 1) / MM_BLOCK_PX; a.blocks_per_image = w.blocks_per_image;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
+    a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H;
     a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.face_idx = w.fidx; a.options = d->options;
     a.feats = d->face_features; a.D = d->D; a.interp = d->interpolated_features; a.soft_out = d->soft_mask;
     a.face_idx64 = (long long*)d->face_idx;
-    a.order = launch_order(a, w.order, w.nheavy, d->B, nullptr, s);
+    a.order = launch_order(a, w.order, w.nheavy, w.bincount, d->B, nullptr, s);
     a.nheavy = w.nheavy;
     const bool block = walk_block_mode(a);
     if (block) hipLaunchKernelGGL(raster_dibr_kernel<true>, dim3(walk_grid(a, true)), dim3(256), 0, s, a);
@@ -279,6 +280,7 @@ int mm_dibr_rasterization_backward(const MMDibrDesc* d, const MMDibrGrads* g, mm
     DibrBwdArgs a;
     a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.D = d->D; a.options = d->options;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
+    a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H;
     a.geo = w.geo; a.fidx = w.fidx; a.soft = w.soft; a.feats = d->face_features;
     a.g_interp = g->grad_interpolated_features; a.g_soft = g->grad_soft_mask;
     a.dfvi = g->grad_face_vertices_image; a.dfeat = g->grad_face_features;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
     const int px = bx * MM_BLOCK_PX + (wave & 1) * MM_TILE + (lane & 7), py = by * MM_BLOCK_PX + (wave >> 1) * MM_TILE + (lane >> 3);
     const bool in_img = px < a.W && py < a.H;
-    const float x0 = pixel_x(px, a.W, a.mult), y0 = pixel_y(py, a.H, a.mult);
+    const float x0 = pixel_x_k(px, a.W, a.kx), y0 = pixel_y_k(py, a.H, a.ky);                  // (host-formed IEEE quotients: the forward's centres)
     const size_t hw = (size_t)a.H * a.W, pin = (size_t)py * a.W + px;
     const size_t pix = (size_t)b * hw + pin;
     if (blk == 0 && threadIdx.x == 0) a.ticket[b] = 0u;           // arrival counter of the vertex backward, used after this kernel

@@ -73,12 +73,32 @@ __global__ __launch_bounds__(kBlock ? 256 : 64, kBlock ? MM_RASTER_LB : 1) void 
     MM_TIMELINE_END(raster_fwd);
 }
 
+// Candidates per screen bin for big screens / meshes (the order kernel below counts the mask bits itself where a tile's mask row is a few
+// words): one WAVE per bin row, lanes = words (coalesced), popcount + wave sum.  13 776 faces at 512x512: 16 384 rows of 216 words.
+__global__ __launch_bounds__(256) void bincount_kernel(const uint64_t* binmask, int* bincount, int nrows, int words) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nrows) return;
+    const uint64_t* m = binmask + (size_t)row * words;
+    int c = 0;
+    for (int w0 = 0; w0 < words; w0 += 256) {                     // four loads in flight
+        uint64_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (w0 + 64 * k + lane < words) ? m[w0 + 64 * k + lane] : 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c += __popcll(r[k]);
+    }
+    int total;
+    (void)wave_prefix_excl(c, lane, total);
+    if (lane == 0) bincount[row] = total;
+}
+
 // Orders the tile slots (16x16 block * 4 + quadrant) of every image by their soft-mask candidate count, descending: a counting
-// sort in LDS (keys clipped to 1023; slots per image <= 1024), linear in the slots.  Only the launch ORDER of raster_fwd
+// sort in LDS (keys clipped to 1023; slots per image <= MM_ORDER_MAX_SLOTS), linear in the slots.  Only the launch ORDER of raster_fwd
 // depends on it -- slots with equal counts may come out in any order, no result does.  Bit 15 of an entry marks a tile that no
 // face can touch (count 0), which raster_fwd then never walks.
+#define MM_ORDER_MAX_SLOTS 16384      // 1024x1024 pixels; bigger screens are walked in natural order
 __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short* order, int* nheavy) {
-    __shared__ int s_key[1024];
+    __shared__ unsigned short s_key[MM_ORDER_MAX_SLOTS];
     __shared__ int s_start[1024];          // histogram, then the first output position of every key
     __shared__ int s_wave[4];
     const int b = blockIdx.x, tid = threadIdx.x, nslot = 4 * a.blocks_per_image;
@@ -90,17 +110,21 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
         const int tx0 = (blk % a.blocks_x) * MM_BLOCK_PX + (q & 1) * MM_TILE, ty0 = (blk / a.blocks_x) * MM_BLOCK_PX + (q >> 1) * MM_TILE;
         int c = 0;
         if (tx0 < a.W && ty0 < a.H) {
-            const uint64_t* row = a.binmask + ((size_t)b * a.nbx * a.nby + (size_t)(ty0 >> a.bin_shift) * a.nbx + (tx0 >> a.bin_shift)) * a.words;
-            for (int w0 = 0; w0 < a.words; w0 += 24) {            // 24 loads in flight per trip: the 1 280-face templates' rows in ONE trip
-                uint64_t r[24];
+            const size_t bin = (size_t)b * a.nbx * a.nby + (size_t)(ty0 >> a.bin_shift) * a.nbx + (tx0 >> a.bin_shift);
+            if (a.bincount) c = a.bincount[bin];
+            else {
+                const uint64_t* row = a.binmask + bin * a.words;
+                for (int w0 = 0; w0 < a.words; w0 += 24) {        // 24 loads in flight per trip: the 1 280-face templates' rows in ONE trip
+                    uint64_t r[24];
 #pragma unroll
-                for (int k = 0; k < 24; ++k) r[k] = (w0 + k < a.words) ? row[w0 + k] : 0ull;
+                    for (int k = 0; k < 24; ++k) r[k] = (w0 + k < a.words) ? row[w0 + k] : 0ull;
 #pragma unroll
-                for (int k = 0; k < 24; ++k) c += __popcll(r[k]);
+                    for (int k = 0; k < 24; ++k) c += __popcll(r[k]);
+                }
             }
         }
         c = min(c, 1023);
-        s_key[slot] = c;
+        s_key[slot] = (unsigned short)c;
         atomicAdd(&s_start[c], 1);
     }
     __syncthreads();
@@ -130,6 +154,8 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.blocks_per_image = w.blocks_per_image;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
+    a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H;
+    a.bincount = nullptr;
     a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.gt = d->fused_gt; a.ltot = w.ltot;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
@@ -139,19 +165,23 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     return a;
 }
 
-const unsigned short* launch_order(const RasterArgs& a_in, unsigned short* order, int* nheavy, int B, void** prof_events, hipStream_t s) {
-    const bool sort = 4 * a_in.blocks_per_image <= 1024 && a_in.words <= 64;        // the tile sort is skipped where it would not pay
-    if (!sort) return nullptr;
-    RasterArgs a = a_in;
-    a.order = nullptr;
+const unsigned short* launch_order(RasterArgs& a, unsigned short* order, int* nheavy, int* bincount, int B, void** prof_events, hipStream_t s) {
+    const int nslot = 4 * a.blocks_per_image;
+    a.order = nullptr; a.bincount = nullptr;
+    if (nslot > MM_ORDER_MAX_SLOTS || nslot > 0x7FFF) return nullptr;          // (entries are 15 bits + the empty flag)
     ProfScope po(prof_events, MM_PROF_ORDER, s);
+    if (nslot > 1024 || a.words > 64) {                          // big screen / mesh: the bins' candidate counts by a parallel kernel first
+        const int nrows = B * a.nbx * a.nby;
+        hipLaunchKernelGGL(bincount_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, a.binmask, bincount, nrows, a.words);
+        a.bincount = bincount;
+    }
     hipLaunchKernelGGL(order_kernel, dim3(B), dim3(256), 0, s, a, order, nheavy);
     return order;
 }
 
 int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     RasterArgs a = make_raster_args(d, w);
-    a.order = launch_order(a, w.order, w.nheavy, d->B, d->prof_events, s);     // heavy-first launch order
+    a.order = launch_order(a, w.order, w.nheavy, w.bincount, d->B, d->prof_events, s);     // heavy-first launch order
     a.nheavy = w.nheavy;
     const bool block = walk_block_mode(a);
     const dim3 grid(walk_grid(a, block));

@@ -11,6 +11,8 @@ struct RasterArgs {
     int B, H, W, F, Ht, Wt, knum, blocks_x, blocks_per_image;
     int bin_shift, nbx, nby, words;
     float mult, eps, sigmainv, infl;        // infl = boxlen * multiplier
+    float kx, ky;                           // multiplier / W, multiplier / H: IEEE fp32 quotients formed once on the host -- the factor of the pixel-centre
+                                            // convention (pixel_x / pixel_y); the kernels multiply, they never divide per tile or per pair
     const float4* geo;
     const uint64_t* binmask;                // candidates per bin: faces whose inflated pixel box touches it
     const float* face_uvs;
@@ -22,6 +24,7 @@ struct RasterArgs {
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     const int* nheavy;                      // (B,2) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty
+    const int* bincount;                    // (B,nbins) candidates per screen bin, or nullptr (small screens: the order kernel counts the mask bits itself)
     // outputs
     float* rgba;
     int32_t* face_idx;
@@ -45,22 +48,17 @@ struct TileCtx {
     bool in_img;
     bool empty;                             // no face can touch the tile (known from the order kernel): nothing to walk
     float x0, y0;
-    float xs[MM_TILE], ys[MM_TILE];         // pixel-centre columns / rows of the tile (same in every lane)
+    float xf0, yf0;                         // (float)(2 tx0 + 1 - W), (float)(H - 2 ty0 - 1): the tile's first column / row in the pixel-centre convention;
+                                            // column i is kx * (xf0 + 2 i), row i is ky * (yf0 - 2 i)  (exact integers: the same floats as pixel_x_k / pixel_y_k)
     const uint64_t* mask;                   // this wave's bin row of candidate bits: `words` 64-bit words
 };
 
 __device__ inline void tile_pixels(const RasterArgs& a, TileCtx& t) {
     t.px = t.tx0 + (t.lane & 7); t.py = t.ty0 + (t.lane >> 3);
     t.in_img = t.px < a.W && t.py < a.H;
-    if (t.empty) {                                               // wave-uniform: an empty tile never looks at pixel centres
-        t.x0 = t.y0 = 0.f;
-#pragma unroll
-        for (int i = 0; i < MM_TILE; ++i) { t.xs[i] = 0.f; t.ys[i] = 0.f; }
-        return;
-    }
-    t.x0 = pixel_x(t.px, a.W, a.mult); t.y0 = pixel_y(t.py, a.H, a.mult);
-#pragma unroll
-    for (int i = 0; i < MM_TILE; ++i) { t.xs[i] = pixel_x(t.tx0 + i, a.W, a.mult); t.ys[i] = pixel_y(t.ty0 + i, a.H, a.mult); }
+    t.xf0 = (float)(2 * t.tx0 + 1 - a.W); t.yf0 = (float)(a.H - 2 * t.ty0 - 1);
+    if (t.empty) { t.x0 = t.y0 = 0.f; return; }                 // wave-uniform: an empty tile never looks at pixel centres
+    t.x0 = pixel_x_k(t.px, a.W, a.kx); t.y0 = pixel_y_k(t.py, a.H, a.ky);
 }
 
 __device__ inline void wave_lds_sync() {
@@ -69,23 +67,12 @@ __device__ inline void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// box-vs-tile for ONE candidate (this lane's): bit (r*8+c) set iff pixel (row r, column c) of the tile passes the
-// separable closed-box test  !(x < lo || x > hi)  -- the same comparisons on the same floats as the per-pixel test.
-__device__ inline uint64_t box_pixels(const TileCtx& t, float xlo, float ylo, float xhi, float yhi, bool half_open) {
-    unsigned col = 0, row = 0;
-    if (half_open) {                                             // MM_OPT_BBOX_HALF_OPEN: a centre exactly on the box edge is outside
-#pragma unroll
-        for (int i = 0; i < MM_TILE; ++i) {
-            col |= (unsigned)(!(t.xs[i] <= xlo || t.xs[i] >= xhi)) << i;
-            row |= (unsigned)(!(t.ys[i] <= ylo || t.ys[i] >= yhi)) << i;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < MM_TILE; ++i) {
-            col |= (unsigned)(!(t.xs[i] < xlo || t.xs[i] > xhi)) << i;
-            row |= (unsigned)(!(t.ys[i] < ylo || t.ys[i] > yhi)) << i;
-        }
-    }
+// box-vs-tile for ONE candidate (this lane's), both of its boxes in one pass over the tile's 8 columns and 8 rows: bit (r*8+c) set iff
+// pixel (row r, column c) of the tile passes the separable box test  !(x < lo || x > hi)  -- the same comparisons on the same floats as
+// the per-pixel test.  mh: the face's own box (colour; only if `hard`), ms: the box inflated by the silhouette margin (only if `soft`).
+// The tile's pixel centres are re-formed here (an exact integer add and the convention's one multiplication each) instead of living in
+// sixteen registers across the whole walk.
+__device__ inline uint64_t outer_mask(unsigned col, unsigned row) {
     unsigned lo = 0, hi = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -93,6 +80,44 @@ __device__ inline uint64_t box_pixels(const TileCtx& t, float xlo, float ylo, fl
         hi |= ((row >> (r + 4)) & 1u) ? (col << (8 * r)) : 0u;
     }
     return ((uint64_t)hi << 32) | lo;
+}
+// the float just above / just below v (finite v):  x <= v  <=>  x < next_up(v),   x >= v  <=>  x > next_down(v)
+__device__ inline float next_up(float v) {
+    const unsigned b = __float_as_uint(v + 0.f);                 // (-0 -> +0)
+    return __uint_as_float((b & 0x80000000u) ? b - 1u : b + 1u);
+}
+__device__ inline float next_down(float v) {
+    const unsigned b = __float_as_uint(v + 0.f);
+    return __uint_as_float(b == 0u ? 0x80000001u : ((b & 0x80000000u) ? b + 1u : b - 1u));
+}
+__device__ inline void box_masks(const RasterArgs& a, const TileCtx& t, float xlo, float ylo, float xhi, float yhi, bool hard, bool soft, int mode,
+                                 uint64_t& mh, uint64_t& ms) {
+#pragma clang fp contract(off)
+    float xlo2 = xlo - a.infl, ylo2 = ylo - a.infl, xhi2 = xhi + a.infl, yhi2 = yhi + a.infl;
+    // An OPEN border (MM_OPT_BBOX_HALF_OPEN / MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN: a centre exactly on it is outside) is the closed test against
+    // the neighbouring float: the same decisions as  x <= lo / x >= hi, and one code path for the three forms (the kernel's register
+    // allocation is that of its hungriest path, taken or not)
+    if (mode & 1) { xlo = next_up(xlo); ylo = next_up(ylo); xlo2 = next_up(xlo2); ylo2 = next_up(ylo2); }                   // (wave-uniform)
+    if (mode & 2) { xhi = next_down(xhi); yhi = next_down(yhi); xhi2 = next_down(xhi2); yhi2 = next_down(yhi2); }
+    unsigned ch = 0, rh = 0, cs = 0, rs = 0;
+    float xf0 = t.xf0, yf0 = t.yf0;
+    asm volatile("" : "+v"(xf0), "+v"(yf0));                     // (opaque: keeps the sixteen centres from being hoisted out of the walk's loop into registers)
+    if (__ballot(soft)) {                                        // (wave-uniform) some candidate of the batch may still matter to the silhouette
+#pragma unroll
+        for (int i = 0; i < MM_TILE; ++i) {
+            const float x = a.kx * (xf0 + (float)(2 * i)), y = a.ky * (yf0 - (float)(2 * i));
+            ch |= (unsigned)(!(x < xlo || x > xhi)) << i; rh |= (unsigned)(!(y < ylo || y > yhi)) << i;
+            cs |= (unsigned)(!(x < xlo2 || x > xhi2)) << i; rs |= (unsigned)(!(y < ylo2 || y > yhi2)) << i;
+        }
+    } else {                                                     // colour only: half the comparisons
+#pragma unroll
+        for (int i = 0; i < MM_TILE; ++i) {
+            const float x = a.kx * (xf0 + (float)(2 * i)), y = a.ky * (yf0 - (float)(2 * i));
+            ch |= (unsigned)(!(x < xlo || x > xhi)) << i; rh |= (unsigned)(!(y < ylo || y > yhi)) << i;
+        }
+    }
+    mh = hard ? outer_mask(ch, rh) : 0ull;
+    ms = soft ? outer_mask(cs, rs) : 0ull;
 }
 
 // Balanced evaluation of a batch's (row, column) pairs: every lane owns one ROW of the bit matrix `m` (a candidate, or a
@@ -114,18 +139,12 @@ __device__ inline void pair_parallel(const TileCtx& t, Stage* st, uint64_t m, Ev
             ++k;
         }
         wave_lds_sync();
-        if (lim <= 64) {                                         // wave-uniform: one pair per lane at most, no dummy second evaluation
-            const bool live = t.lane < lim;
-            const unsigned pr = st->pairs[live ? t.lane : 0];
-            eval((int)(pr >> 8), (int)(pr & 255u), live);
-        } else {
-            for (int p = t.lane; p < lim; p += 128) {            // two independent pairs per trip: ILP for a lone wave
-                const unsigned pr0 = st->pairs[p];
-                const bool two = p + 64 < lim;
-                const unsigned pr1 = two ? st->pairs[p + 64] : pr0;
-                eval((int)(pr0 >> 8), (int)(pr0 & 255u), true);
-                if (__ballot(two)) eval((int)(pr1 >> 8), (int)(pr1 & 255u), two);   // wave-uniform
-            }
+        for (int p = t.lane; p < lim; p += 128) {                // two independent pairs per trip: ILP for a lone wave
+            const unsigned pr0 = st->pairs[p];
+            const bool two = p + 64 < lim;
+            const unsigned pr1 = two ? st->pairs[p + 64] : pr0;
+            eval((int)(pr0 >> 8), (int)(pr0 & 255u), true);
+            if (__ballot(two)) eval((int)(pr1 >> 8), (int)(pr1 & 255u), two);   // wave-uniform: no dummy second evaluation for a short list
         }
         wave_lds_sync();
     }
@@ -133,10 +152,22 @@ __device__ inline void pair_parallel(const TileCtx& t, Stage* st, uint64_t m, Ev
 
 // (z, -rank) packed so that an unsigned 64-bit max is kaolin's "strict z > best, lowest index on ties"; rank = any value
 // that grows with the face index (the face id itself, or its position in an index-ordered list)
-__device__ inline unsigned long long depth_key(float z, int rank) {
+__device__ inline unsigned depth_ord(float z) {                  // unsigned order of a float: a < b  <=>  depth_ord(a) < depth_ord(b)
     const unsigned bits = __float_as_uint(z + 0.f);              // -0 -> +0: equal depths must tie
-    const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-    return ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)rank);
+    return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+__device__ inline unsigned long long depth_key(float z, int rank) {
+    return ((unsigned long long)depth_ord(z) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)rank);
+}
+// Upper bound of the depth a face can give ANY pixel, as a depth_ord: inside the face the barycentrics are a convex combination (up to
+// a few ulps: every w_i in [0, 1], their sum <= 1 + 3 ulp), so the interpolated z never exceeds the largest corner z by more than
+// ~6e-7 of the largest |z|; 1e-5 of it is added.  A face whose bound lies below what a pixel already holds can never win that pixel
+// (strictly below: equal depths, which the lower face index wins, are never cut) -- the walk's early-z, exact.
+__device__ inline unsigned depth_bound(float az, float bz, float cz) {
+#pragma clang fp contract(off)
+    const float zmax = fmaxf(fmaxf(az, bz), cz), amax = fmaxf(fmaxf(fabsf(az), fabsf(bz)), fabsf(cz));
+    const float zb = zmax + 1e-5f * amax;
+    return (zb == zb && amax < INFINITY) ? depth_ord(zb) : 0xFFFFFFFFu;     // (NaN / inf corners: never cut)
 }
 __device__ inline int depth_key_rank(unsigned long long k) { return (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)); }
 
@@ -146,7 +177,7 @@ struct Hit { int f; float w0, w1, w2; };
 // straight-line on purpose (two of these are interleaved per trip): the IEEE divisions the oracle takes
 template <class Stage>
 __device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* st, Stage* acc, int j, int l, bool live) {   // st: staged candidates; acc: the tile's results
-    const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
+    const float x0 = pixel_x_k(t.tx0 + (l & 7), a.W, a.kx), y0 = pixel_y_k(t.ty0 + (l >> 3), a.H, a.ky);
     const float4 p0 = st->p0[j], p1 = st->p1[j], p2 = st->p2[j];
     float w0, w1, w2, nrm;
     bary_weights(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, x0, y0, a.eps, (a.options & MM_OPT_BARY_ONE_MINUS) != 0, w0, w1, w2, nrm);
@@ -155,11 +186,86 @@ __device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* s
         atomicMax(&acc->key[l], depth_key(z0, __float_as_int(p2.z)));
 }
 
+// K1 for ALL (candidate, pixel) pairs of a flush, in two phases.  Where faces overlap heavily (a fine mesh with per-vertex noise: hundreds of
+// boxes over every pixel) most box pairs fail the inside test, and the three IEEE divisions of the barycentrics were spent on them too.
+//   phase A  every pair, two per lane in packed fp32 (v_pk_*): the three edge functions k0, k1, k2 and their padded sum -- the SAME
+//            expressions, in the same order, as edge_weights / bary_weights -- and a sign test that rejects a pair only where the
+//            quotient k_i / sum is certainly negative (opposite signs, neither operand within 40 orders of magnitude of the format's
+//            ends): exactly the pairs the oracle's `w_i < 0` rejects, minus freak magnitudes, which stay in.  Also EARLY-Z: a pair that
+//            cannot reach the depth its pixel already holds (an upper bound of its interpolated depth lies strictly below it) is
+//            dropped -- faces come in index order, not depth order, so after the first few a pixel under forty overlapping boxes
+//            lets only the occasional nearer face through.  Never cuts a winner: equal depths (the lower index wins) stay in.
+//            Survivors are ballot-compacted IN PLACE at the front of the pair list (writes never pass the read cursor).
+//   phase B  the survivors, densely: hard_pair as before (divisions, inside test, depth, 64-bit LDS max).
+// m: the flush's colour masks, rows = candidates (by_cand) or pixels; results do not depend on the order of evaluation.
+typedef float mm_f2 __attribute__((ext_vector_type(2)));
+template <class Stage>
+__device__ inline void hard_pairs(const RasterArgs& a, const TileCtx& t, Stage* st, uint64_t m, bool by_cand) {
+    int total;
+    int k = wave_prefix_excl(__popcll(m), t.lane, total);       // index of this lane's next unwritten pair
+    uint64_t rem = m;
+    const bool one_minus = (a.options & MM_OPT_BARY_ONE_MINUS) != 0;
+    for (int base = 0; base < total; base += MM_PAIR_ROUND) {
+        const int lim = min(MM_PAIR_ROUND, total - base);
+        while (rem && k < base + lim) {                          // every set bit is visited exactly once overall
+            const int j = __ffsll((unsigned long long)rem) - 1;
+            rem &= rem - 1;
+            st->pairs[k - base] = (unsigned short)(by_cand ? ((t.lane << 8) | j) : ((j << 8) | t.lane));   // (candidate << 8) | pixel
+            ++k;
+        }
+        wave_lds_sync();
+        int w = 0;                                               // survivors so far (wave-uniform): they occupy pairs[0, w)
+        for (int q0 = 0; q0 < lim; q0 += 128) {
+            const bool v0 = q0 + t.lane < lim, v1 = q0 + 64 + t.lane < lim;
+            const unsigned e0 = st->pairs[v0 ? q0 + t.lane : 0], e1 = st->pairs[v1 ? q0 + 64 + t.lane : 0];
+            const int j0 = (int)(e0 >> 8), j1 = (int)(e1 >> 8), l0 = (int)(e0 & 63u), l1 = (int)(e1 & 63u);
+            const float4 A0 = st->p0[j0], B0 = st->p1[j0], A1 = st->p0[j1], B1 = st->p1[j1];
+            // early-z: what the pixel holds by now (the high word of its key; 0 = nothing yet) against an upper bound of the depth this pair
+            // would give it -- the interpolation with a hardware reciprocal (1 ulp) plus 2e-5 of the corner depths' magnitudes
+            const float cz0 = st->p2[j0].x, cz1 = st->p2[j1].x;
+            const unsigned kh0 = (unsigned)(st->key[l0] >> 32), kh1 = (unsigned)(st->key[l1] >> 32);
+            bool pass0, pass1;
+            {
+#pragma clang fp contract(off)
+                const mm_f2 x0 = {a.kx * (t.xf0 + (float)(2 * (l0 & 7))), a.kx * (t.xf0 + (float)(2 * (l1 & 7)))};
+                const mm_f2 y0 = {a.ky * (t.yf0 - (float)(2 * (l0 >> 3))), a.ky * (t.yf0 - (float)(2 * (l1 >> 3)))};
+                const mm_f2 ax = {A0.x, A1.x}, ay = {A0.y, A1.y}, bx = {A0.z, A1.z}, by = {A0.w, A1.w}, cx = {B0.x, B1.x}, cy = {B0.y, B1.y};
+                const mm_f2 aex = ax - x0, aey = ay - y0, bex = bx - x0, bey = by - y0, cex = cx - x0, cey = cy - y0;
+                const mm_f2 k0 = bex * cey - bey * cex, k1 = cex * aey - cey * aex, k2 = aex * bey - aey * bex;
+                mm_f2 nrm = (k0 + k1) + k2;
+                nrm.x += one_minus ? a.eps : copysignf(a.eps, nrm.x); nrm.y += one_minus ? a.eps : copysignf(a.eps, nrm.y);
+                // certainly negative quotient: opposite signs and magnitudes far from the ends of the format (1e-12 / 1e12 >= 1e-24: normal)
+                auto neg = [](float kk, float nn) { return ((kk < 0.f) != (nn < 0.f)) && fabsf(kk) >= 1e-12f; };
+                const bool sane0 = fabsf(nrm.x) <= 1e12f, sane1 = fabsf(nrm.y) <= 1e12f;
+                const bool rej0 = sane0 && ((!one_minus && neg(k0.x, nrm.x)) || neg(k1.x, nrm.x) || neg(k2.x, nrm.x));
+                const bool rej1 = sane1 && ((!one_minus && neg(k0.y, nrm.y)) || neg(k1.y, nrm.y) || neg(k2.y, nrm.y));
+                const mm_f2 az = {B0.z, B1.z}, bz = {B0.w, B1.w}, cz = {cz0, cz1};
+                const mm_f2 zn = (k0 * az + k1 * bz) + k2 * cz;
+                const float zu0 = zn.x * __builtin_amdgcn_rcpf(nrm.x) + 2e-5f * ((fabsf(az.x) + fabsf(bz.x)) + fabsf(cz.x));
+                const float zu1 = zn.y * __builtin_amdgcn_rcpf(nrm.y) + 2e-5f * ((fabsf(az.y) + fabsf(bz.y)) + fabsf(cz.y));
+                const bool near0 = !(zu0 == zu0) || depth_ord(zu0) >= kh0, near1 = !(zu1 == zu1) || depth_ord(zu1) >= kh1;   // (NaN: stays in)
+                pass0 = v0 && !rej0 && near0; pass1 = v1 && !rej1 && near1;
+            }
+            const uint64_t b0 = __ballot(pass0), b1 = __ballot(pass1);
+            wave_lds_sync();                                     // (every read of this trip is done; the writes stay behind the read cursor)
+            if (pass0) st->pairs[w + ballot_rank(b0)] = (unsigned short)e0;
+            if (pass1) st->pairs[w + __popcll(b0) + ballot_rank(b1)] = (unsigned short)e1;
+            w += __popcll(b0) + __popcll(b1);
+        }
+        wave_lds_sync();
+        for (int q = t.lane; q < w; q += 64) {
+            const unsigned pr = st->pairs[q];
+            hard_pair(a, t, st, st, (int)(pr >> 8), (int)(pr & 63u), true);
+        }
+        wave_lds_sync();
+    }
+}
+
 // K3, one (pixel l, candidate j) pair: factor q = 1 - exp(-sigma d^2) folded into the pixel's integer log2 sum.
 // sig2 = sigmainv / multiplier^2 (d is in multiplier units).
 template <class Stage>
 __device__ inline void soft_pair(const RasterArgs& a, const TileCtx& t, Stage* st, Stage* acc, float sig2, int l, int j, bool live) {
-    const float x0 = pixel_x(t.tx0 + (l & 7), a.W, a.mult), y0 = pixel_y(t.ty0 + (l >> 3), a.H, a.mult);
+    const float x0 = pixel_x_k(t.tx0 + (l & 7), a.W, a.kx), y0 = pixel_y_k(t.ty0 + (l >> 3), a.H, a.ky);
     const float4 p0 = st->p0[j], p1 = st->p1[j];
     const float q = soft_factor(x0, y0, p0, p1, sig2);
     if (live) {
@@ -398,7 +504,7 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w);
 // plan kernel (mm_raster.hip), one workgroup per image between the vertex stage and the walk: (a) heavy-first tile order for the
 // walk kernels, (b) the sweep items (face, box chunk) of the backward.  Returns the order buffer to put in
 // RasterArgs::order, or nullptr where the sort does not pay (then the natural order is used).
-const unsigned short* launch_order(const RasterArgs& a, unsigned short* order, int* nheavy, int B, void** prof_events, hipStream_t s);
+const unsigned short* launch_order(RasterArgs& a, unsigned short* order, int* nheavy, int* bincount, int B, void** prof_events, hipStream_t s);
 // The walk kernels come in two workgroup shapes with identical results: 256 threads (four tiles per workgroup, heavy tiles walked by
 // the four waves together) and 64 threads (one tile per workgroup).  Measured (profiles/r02_walk_shapes.md), raster_fwd us, block /
 // wave: 128x128 1280 faces 45.6 / 55.3; 128x64 38.4 / 51.5; 512x512 13 776 faces (no tile sort: a workgroup = the 2x2 tiles of a
@@ -408,7 +514,7 @@ const unsigned short* launch_order(const RasterArgs& a, unsigned short* order, i
 inline bool walk_block_mode(const RasterArgs& a) {
     if (a.options & MM_OPT_WALK_BLOCK) return true;
     if (a.options & MM_OPT_WALK_WAVE) return false;
-    return a.bin_shift == 3 || !(4 * a.blocks_per_image <= 1024 && a.words <= 64);   // 8-pixel bins, or no tile sort
+    return a.bin_shift == 3 || a.order == nullptr;               // 8-pixel bins, or no tile sort (a screen beyond MM_ORDER_MAX_SLOTS tiles)
 }
 inline unsigned walk_grid(const RasterArgs& a, bool block) {
     if (!block) return (unsigned)a.B * (unsigned)a.blocks_per_image * 4u;

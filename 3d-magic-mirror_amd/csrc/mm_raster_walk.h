@@ -1,28 +1,33 @@
-// mm_raster_walk.h -- the candidate walk of the streamed pixel kernels (gfx950): bin mask -> ordered candidate batches staged in
-// LDS -> box tests -> wave bit transposes -> balanced (pixel, candidate) pair evaluation with exact LDS atomics.  Shared by the
-// fused render kernel (mm_raster.hip) and by the un-fused kaolin-shaped dibr_rasterization entry point (mm_dibr.hip): both run
-// the SAME walk, so face_idx / barycentrics / soft-mask state are bit-identical between the two boundaries.
+// mm_raster_walk.h -- the candidate walk of the streamed pixel kernels (gfx950): bin mask -> ordered raw batches of 64 candidates ->
+// box tests against the tile -> BALLOT / PREFIX COMPACTION of the candidates that touch it into an ordered LDS queue -> (when the queue
+// is full, or at the end) balanced (pixel, candidate) pair evaluation with exact LDS atomics.  Shared by the fused render kernel
+// (mm_raster.hip) and by the un-fused kaolin-shaped dibr_rasterization entry point (mm_dibr.hip): both run the SAME walk, so face_idx /
+// barycentrics / soft-mask state are bit-identical between the two boundaries.
 #pragma once
 #include "mm_raster_common.h"
 
 namespace mm {
 
 
-// per-wave LDS staging: 64 candidates as three float4 rows + the id list of one mask group
+// per-wave LDS staging: the QUEUE of the candidates that touch the tile (three float4 rows + their two pixel masks, face order) + the id
+// list of one mask window
 struct __attribute__((aligned(16))) WaveStage {
     float4 p0[64];      // ax, ay, bx, by   (multiplier units)
     float4 p1[64];      // cx, cy, az, bz
-    float4 p2[64];      // cz, unit normal z, face id (bits), 0
+    float4 p2[64];      // cz, unit normal z, face id (bits), depth bound (depth_ord bits)
+    unsigned long long qm[2][64];           // queue: per candidate its pixel masks (bit p = pixel p of the tile): [0] front-face box (colour),
+                                            // [1] inflated box (silhouette).  The cooperative walk keeps per-pixel ints here instead (coop_cnt / coop_lastf)
     unsigned short ids[MM_GROUP_WORDS * 64];
-    unsigned short pairs[MM_PAIR_ROUND];    // (candidate << 8) | pixel, or (owner lane << 8) | candidate
+    unsigned short pairs[MM_PAIR_ROUND];    // (row << 8) | column of the bit matrix being evaluated (candidate, pixel) or (pixel, candidate)
     unsigned long long key[64];             // per pixel: best (orderable z << 32 | ~face) so far; 0 = none
     long long logsum[64];                   // per pixel: sum of log2(1-p) in 2^-32 fixed point (integer adds commute)
     int zeros[64];                          // per pixel: number of factors (1-p) that are exactly 0
-    int cnt[64];                            // cooperative walk: per pixel, inflated-box hits of this wave's batch of the current round
-    int lastf[64];                          // cooperative walk: per pixel, id of the knum-th silhouette face taken
     int npair[4];                           // cooperative walk: this wave's colour / silhouette pair counts of the round
 };
 static_assert(sizeof(WaveStage) <= 8192, "four of them must fit 32 KiB: five workgroups per CU");
+// cooperative walk: per pixel, inflated-box hits of this wave's batch of the current round / id of the knum-th silhouette face taken
+__device__ inline int* coop_cnt(WaveStage* st) { return reinterpret_cast<int*>(&st->qm[0][0]); }
+__device__ inline int* coop_lastf(WaveStage* st) { return reinterpret_cast<int*>(&st->qm[1][0]); }
 
 // Work of a 256-thread workgroup: FOUR tiles, one per wave (nothing shared), or ONE heavy tile walked by its four waves together
 // (tile_walk_coop).  With the plan kernel's order (tiles of an image by decreasing candidate count, the first nheavy of them heavy):
@@ -74,8 +79,9 @@ __device__ inline TileCtx make_tile(const RasterArgs& a, int wv, bool& valid, bo
 // a tile pays one trip to memory for its mask and its candidates fill whole batches whatever words they come from.  Ids are relative
 // to the chunk's first face.
 struct IdWindows { uint64_t w; int pc, pre, tot, first, done; };
-__device__ inline void idw_begin(IdWindows& iw, const RasterArgs& a, const TileCtx& t, int cbase) {
-    iw.w = (cbase + t.lane < a.words) ? t.mask[cbase + t.lane] : 0ull;
+__device__ inline uint64_t idw_load(const RasterArgs& a, const TileCtx& t, int cbase) { return (cbase + t.lane < a.words) ? t.mask[cbase + t.lane] : 0ull; }
+__device__ inline void idw_begin(IdWindows& iw, const RasterArgs& a, const TileCtx& t, uint64_t word) {
+    iw.w = word;
     iw.pc = __popcll(iw.w);
     iw.pre = wave_prefix_excl(iw.pc, t.lane, iw.tot);
     iw.first = 0; iw.done = 0;
@@ -101,62 +107,98 @@ __device__ inline int idw_next(IdWindows& iw, const TileCtx& t, WaveStage* st) {
     return n;
 }
 
-// candidate of this lane staged in LDS + its two pixel masks (front-face box: colour; inflated box: silhouette), candidate-major
-__device__ inline void stage_candidate(const RasterArgs& a, const TileCtx& t, WaveStage* st, int f, const float4& g0, const float4& g1, const float4& g2,
-                                       bool soft, uint64_t& mh, uint64_t& ms) {
-    st->p0[t.lane] = g0; st->p1[t.lane] = g1;
-    st->p2[t.lane] = make_float4(g2.x, g2.y, __int_as_float(f), __int_as_float(f));   // cz, nz, rank, face id
+#ifndef MM_HARD_ROW_MAX
+#define MM_HARD_ROW_MAX 6
+#endif
+// the two pixel masks of this lane's candidate (front-face box: colour; inflated box: silhouette), candidate-major
+//   zfloor: the smallest depth_ord any in-image pixel of the tile holds (0 while one of them holds nothing): a front face whose depth bound
+//   lies below it cannot win any pixel of the tile and is not a colour candidate at all;  zb: the face's depth bound (kept with the candidate)
+__device__ inline void candidate_masks(const RasterArgs& a, const TileCtx& t, const float4& g0, const float4& g1, const float4& g2, bool soft, int bmode,
+                                       unsigned zfloor, uint64_t& mh, uint64_t& ms, unsigned& zb) {
     const float xmin = fminf(fminf(g0.x, g0.z), g1.x), ymin = fminf(fminf(g0.y, g0.w), g1.y);
     const float xmax = fmaxf(fmaxf(g0.x, g0.z), g1.x), ymax = fmaxf(fmaxf(g0.y, g0.w), g1.y);
     // kaolin rasterises the faces with face_normals_z >= 0 (MM_OPT_CULL_STRICT: > 0); its soft mask looks at ALL faces
     // (MM_OPT_SOFT_SKIP_CULLED: only at those)  -- SURVEY Appendix C-1
     const bool front = (a.options & MM_OPT_CULL_STRICT) ? g2.y > 0.f : g2.y >= 0.f;
-    const bool half_open = (a.options & MM_OPT_BBOX_HALF_OPEN) != 0;
-    if (front) mh = box_pixels(t, xmin - 0.f, ymin - 0.f, xmax + 0.f, ymax + 0.f, half_open);
-    if (soft && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED))) ms = box_pixels(t, xmin - a.infl, ymin - a.infl, xmax + a.infl, ymax + a.infl, half_open);
+    zb = depth_bound(g1.z, g1.w, g2.x);
+    box_masks(a, t, xmin, ymin, xmax, ymax, front && zb >= zfloor, soft && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED)), bmode, mh, ms);
+}
+__device__ inline void stage_slot(WaveStage* st, int slot, int f, const float4& g0, const float4& g1, const float4& g2, unsigned zb) {
+    st->p0[slot] = g0; st->p1[slot] = g1;
+    st->p2[slot] = make_float4(g2.x, g2.y, __int_as_float(f), __uint_as_float(zb));   // cz, nz, face id, depth bound
 }
 
-// Walk the bin's candidates in face order, 64 at a time.  For every batch the candidates are staged in st->p0/p1/p2[0..n)
-// and body(n, ph, ps) receives the batch's two hit matrices pixel-major (this lane's pixel, bit j = candidate j):
-//   ph  front faces whose box contains the pixel (colour);   ps  all faces whose inflated box contains it (silhouette;
-//   0 when want_soft() -- wave-uniform, asked once per batch -- says no pixel can take another silhouette face).
-template <class WantSoft, class Body>
-__device__ inline void for_each_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, WantSoft&& want_soft, Body&& body MM_PP_ARG) {
+// Walk the bin's candidates in face order, 64 at a time (a RAW batch: whatever the bin's mask lists).  Per raw batch lane j tests
+// candidate j's two boxes against the tile's 8 columns and 8 rows; candidates that touch no pixel of the tile -- most of them where the
+// bin is larger than the tile, where the silhouette margin inflates the bin's catchment, or once no pixel can take another silhouette
+// face -- are dropped on the spot, the others are BALLOT-COMPACTED (v_mbcnt rank = exclusive prefix over the ballot) behind the ones
+// already waiting in the LDS queue, in face order.  flush(n) is called with n <= 64 queued candidates in st->p0/p1/p2 and their masks in
+// st->qm whenever the next batch's survivors would not fit, and once at the end.  A raw batch costs its fetch + the box tests; staging
+// and pair work are paid per SURVIVOR: a far-away mesh folded into a few tiles (thousands of candidates per bin, a handful of pixel
+// hits per batch) costs a tenth of what it did when every batch was staged, transposed and paired.
+//   want_soft(): wave-uniform, asked once per raw batch: can any pixel still take a silhouette face?  (Monotone: once false, always false.)
+template <class WantSoft, class Flush>
+__device__ inline void scan_candidates(const RasterArgs& a, const TileCtx& t, WaveStage* st, const unsigned& zfloor, WantSoft&& want_soft, Flush&& flush MM_PP_ARG) {
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
+    const int bmode = box_mode(a.options);
+    int qn = 0;                                                  // candidates waiting in the queue (wave-uniform)
+    uint64_t next_word = idw_load(a, t, 0);
     for (int cbase = 0; cbase < a.words; cbase += 64) {
       IdWindows iw;
-      idw_begin(iw, a, t, cbase);
-      for (int total = idw_next(iw, t, st); total != 0; total = idw_next(iw, t, st)) {
+      idw_begin(iw, a, t, next_word);
+      if (cbase + 64 < a.words) next_word = idw_load(a, t, cbase + 64);   // the next chunk's mask words travel while this chunk is walked (a mesh of
+                                                                          // 13 776 faces has four chunks: three dependent trips to memory less per tile)
+      for (bool more = true; more;) {
+        const int total = idw_next(iw, t, st);                   // ids now in st->ids (0: the chunk is exhausted)
+        more = total != 0 && iw.done < iw.tot;                   // another window of this chunk follows
+        // the walk's LAST pass gets one more, empty batch: the final flush happens at the loop's only flush site (the flush is the bulk
+        // of this kernel's code; expanded twice it no longer fits the instruction cache)
+        const bool final = !more && cbase + 64 >= a.words;
+        if (total == 0 && !final) break;
         const int wbase = cbase;
         wave_lds_sync();
         MM_PP_MARK(1);
         MM_PP_COUNT(total, 0);
-        // batches of 64; the face records of batch k+1 are requested before batch k is evaluated (a tile with hundreds of
-        // candidates would otherwise pay a dependent trip to memory per batch)
+        // the face records of batch k+1 are requested before batch k is tested (a tile with hundreds of candidates would otherwise pay a
+        // dependent trip to memory per batch)
         float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
         int nf = 0;
-        auto fetch = [&](int k0) {
-            if (k0 + t.lane < total) {
-                nf = wbase * 64 + st->ids[k0 + t.lane];
-                n0 = geo[(size_t)nf * 3 + 0]; n1 = geo[(size_t)nf * 3 + 1]; n2 = geo[(size_t)nf * 3 + 2];
-            }
+        auto fetch = [&](int k0) {                               // (unconditional: lanes beyond the list read its first face and ignore it; every call
+            nf = wbase * 64 + st->ids[k0 + t.lane < total ? k0 + t.lane : 0];     //  redefines all thirteen registers, so none is carried across a flush)
+            n0 = geo[(size_t)nf * 3 + 0]; n1 = geo[(size_t)nf * 3 + 1]; n2 = geo[(size_t)nf * 3 + 2];
         };
-        fetch(0);
-        for (int k0 = 0; k0 < total; k0 += 64) {
-            const int n = min(64, total - k0);
-            const float4 g0 = n0, g1 = n1, g2 = n2;
-            const int f = nf;
-            if (k0 + 64 < total) fetch(k0 + 64);
-            const bool soft = want_soft();
+        if (total) fetch(0);
+        const int nbatch = (total + 63) / 64 + (final ? 1 : 0);
+        for (int i = 0; i < nbatch; ++i) {
+            const int k0 = i * 64, n = max(0, min(64, total - k0));
+            float4 g0, g1, g2;
+            int f, slot = 0, ns = 0;
             uint64_t mh = 0, ms = 0;                             // candidate-major: lane j = candidate j, bit p = pixel p
-            if (t.lane < n) stage_candidate(a, t, st, f, g0, g1, g2, soft, mh, ms);
-            const uint64_t ph = __ballot(mh != 0) ? wave_transpose64(mh, t.lane) : 0ull;
-            const uint64_t ps = __ballot(ms != 0) ? wave_transpose64(ms, t.lane) : 0ull;
-            wave_lds_sync();
-            MM_PP_MARK(2);
-            MM_PP_COUNT(0, 1);
-            body(n, ph, ps);
-            wave_lds_sync();
+            unsigned zb = 0;
+            bool keep = false;
+            // (at most two passes: if this batch's survivors do not fit behind the queued ones, the queue is flushed and the batch is
+            // taken again from its -- cache-hot -- records, instead of carrying seventeen registers per lane across the flush)
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) fetch(k0);
+                g0 = n0; g1 = n1; g2 = n2; f = nf;
+                if (k0 + 64 < total) fetch(k0 + 64);
+                const bool soft = want_soft();
+                mh = 0; ms = 0;
+                if (t.lane < n) candidate_masks(a, t, g0, g1, g2, soft, bmode, zfloor, mh, ms, zb);
+                keep = (mh | ms) != 0;
+                const uint64_t surv = __ballot(keep);
+                ns = __popcll(surv);
+                slot = ballot_rank(surv);
+                MM_PP_MARK(2);
+                if (!(n == 0 ? qn > 0 : qn + ns > 64)) break;    // (wave-uniform) not the end of the walk, and the survivors fit
+                flush(qn); qn = 0;
+                if (n == 0) break;
+            }
+            if (keep) {
+                stage_slot(st, qn + slot, f, g0, g1, g2, zb);
+                st->qm[0][qn + slot] = mh; st->qm[1][qn + slot] = ms;
+            }
+            qn += ns;
         }
       }
     }
@@ -177,12 +219,14 @@ __device__ inline void winner(const RasterArgs& a, const TileCtx& t, unsigned lo
 // ONE walk over the tile's candidates serves both rules.
 // K1, nearest front face per pixel: kaolin walks faces in index order and keeps strict z > best, i.e. the winner is
 // argmax over (z, -index); that maximum is taken with a 64-bit LDS atomic max per (pixel, face) pair, which is exact
-// and order-free.  NaN and -inf depths never win, as in the reference.
+// and order-free -- the pairs are taken straight from the candidate-major masks (no transpose: no order to keep).
+// NaN and -inf depths never win, as in the reference.
 // K3, soft silhouette of the pixels no front face covers: prod(1-p) over the pixel's first knum nearby faces is
 // accumulated as an integer sum of log2(1-p) in 2^-32 fixed point (exact, commutative LDS adds) plus a count of exact
-// zeros.  A pixel takes silhouette faces while no face of the batches SO FAR covers it: for a pixel that stays
-// uncovered that is every batch, in order -- exactly the two-pass result; whatever a pixel gathered before a later
-// batch covered it is never looked at.
+// zeros.  The "first knum in face order" rule needs the per-pixel view: one 64x64 bit transpose per flush, only while
+// some pixel can still take a face.  A pixel takes silhouette faces while no face flushed SO FAR covers it: for a pixel
+// that stays uncovered that is every candidate, in order -- exactly the two-pass result; whatever a pixel gathered
+// before a later flush covered it is never looked at.
 __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStage* st, unsigned long long& key, SoftState& ss MM_PP_ARG) {
     key = 0ull;
     ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
@@ -192,17 +236,36 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
     const float s2 = a.sigmainv / (a.mult * a.mult);
     int cnt = 0, lastf = 0x7FFFFFFF;
     bool open = t.in_img;
-    for_each_batch(a, t, st, [&]() { return __ballot(open && cnt < a.knum) != 0; }, [&](int n, uint64_t ph, uint64_t ps) {
-        if (__ballot(ph != 0)) {
-            pair_parallel(t, st, ph, [&](int l, int j, bool live) { hard_pair(a, t, st, st, j, l, live); });   // pixel l, candidate j
-            open = t.in_img && st->key[t.lane] == 0ull;
+    unsigned zfloor = 0;                                         // smallest depth_ord held by an in-image pixel of the tile (wave-uniform; 0: some pixel holds nothing)
+    scan_candidates(a, t, st, zfloor, [&]() { return __ballot(open && cnt < a.knum) != 0; }, [&](int n) {
+        wave_lds_sync();                                         // the queue's stores
+        const uint64_t mh = t.lane < n ? st->qm[0][t.lane] : 0ull, ms = t.lane < n ? st->qm[1][t.lane] : 0ull;
+#ifdef MM_PHASE_PROF
+        { int th; (void)wave_prefix_excl(__popcll(mh), t.lane, th); MM_PP_COUNT(1ull << 32, (unsigned long long)th); }   // flushes | colour pairs
+#endif
+        if (__ballot(mh != 0)) {
+            // The pair list is written row by row, every lane its own row: that costs as many trips as the LONGEST row has bits.  Rows =
+            // candidates (the masks as they are) suit small faces (a few pixels each, many candidates); a close-up face covers the whole
+            // tile (64 bits) while a pixel lies in a handful of boxes: then rows = pixels, at the price of one bit transpose.
+            const bool by_cand = wave_max_i32(__popcll(mh)) <= MM_HARD_ROW_MAX;     // (wave-uniform; one instantiation of the pair code for both)
+            hard_pairs(a, t, st, by_cand ? mh : wave_transpose64(mh, t.lane), by_cand);
+            const unsigned long long kk = st->key[t.lane];
+            open = t.in_img && kk == 0ull;
+            zfloor = wave_min_u32(t.in_img ? (unsigned)(kk >> 32) : 0xFFFFFFFFu);
             MM_PP_MARK(3);
         }
-        const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
-        cnt += __popcll(sm);
-        if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].w);   // knum-th face taken
-        if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, st, s2, l, j, live); });
-        MM_PP_MARK(4);
+        if (__ballot(ms != 0) && __ballot(open && cnt < a.knum)) {
+            const uint64_t ps = wave_transpose64(ms, t.lane);    // pixel-major: this lane's pixel, bit j = queued candidate j
+            const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
+            cnt += __popcll(sm);
+            if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);   // knum-th face taken
+            if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, st, s2, l, j, live); });
+#ifdef MM_PHASE_PROF
+            { int ts; (void)wave_prefix_excl(__popcll(sm), t.lane, ts); MM_PP_COUNT(0, (unsigned long long)ts << 32); }   // silhouette pairs
+#endif
+            MM_PP_MARK(4);
+        }
+        wave_lds_sync();                                         // the queue is free again
     } MM_PP_PASS);
     wave_lds_sync();
     key = st->key[t.lane];
@@ -226,7 +289,8 @@ __device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, Wav
     WaveStage* acc = &stage[0];
     key = 0ull;
     ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
-    if (wv == 0) { acc->key[t.lane] = 0ull; acc->logsum[t.lane] = 0ll; acc->zeros[t.lane] = 0; acc->lastf[t.lane] = 0x7FFFFFFF; }
+    if (wv == 0) { acc->key[t.lane] = 0ull; acc->logsum[t.lane] = 0ll; acc->zeros[t.lane] = 0; coop_lastf(acc)[t.lane] = 0x7FFFFFFF; }
+    const int bmode = box_mode(a.options);
     __syncthreads();
     const float s2 = a.sigmainv / (a.mult * a.mult);
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
@@ -234,7 +298,7 @@ __device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, Wav
     bool open = t.in_img;
     for (int cbase = 0; cbase < a.words; cbase += 64) {
       IdWindows iw;
-      idw_begin(iw, a, t, cbase);                                // every wave expands the same lists into its own stage
+      idw_begin(iw, a, t, idw_load(a, t, cbase));                // every wave expands the same lists into its own stage
       for (int total = idw_next(iw, t, st); total != 0; total = idw_next(iw, t, st)) {   // (the same in the four waves)
         const int wbase = cbase;
         wave_lds_sync();
@@ -247,18 +311,21 @@ __device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, Wav
             uint64_t mh = 0, ms = 0;
             if (t.lane < n) {
                 const int f = wbase * 64 + st->ids[k0 + t.lane];
-                stage_candidate(a, t, st, f, geo[(size_t)f * 3 + 0], geo[(size_t)f * 3 + 1], geo[(size_t)f * 3 + 2], soft, mh, ms);
+                const float4 g0 = geo[(size_t)f * 3 + 0], g1 = geo[(size_t)f * 3 + 1], g2 = geo[(size_t)f * 3 + 2];
+                unsigned zb;
+                candidate_masks(a, t, g0, g1, g2, soft, bmode, 0u, mh, ms, zb);
+                stage_slot(st, t.lane, f, g0, g1, g2, zb);
             }
             const uint64_t ph = __ballot(mh != 0) ? wave_transpose64(mh, t.lane) : 0ull;
             const uint64_t ps = __ballot(ms != 0) ? wave_transpose64(ms, t.lane) : 0ull;
-            st->cnt[t.lane] = __popcll(ps);
+            coop_cnt(st)[t.lane] = __popcll(ps);
             MM_PP_MARK(2);
             __syncthreads();
             int before = base_cnt, round_total = 0;              // hits of the batches before this wave's, in index order
 #pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2) { const int c = stage[w2].cnt[t.lane]; before += w2 < wv ? c : 0; round_total += c; }
+            for (int w2 = 0; w2 < 4; ++w2) { const int c = coop_cnt(&stage[w2])[t.lane]; before += w2 < wv ? c : 0; round_total += c; }
             const uint64_t sm = soft_take(ps, open, a.knum - before);
-            if (sm != 0 && before + __popcll(sm) >= a.knum) acc->lastf[t.lane] = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].w);
+            if (sm != 0 && before + __popcll(sm) >= a.knum) coop_lastf(acc)[t.lane] = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);
             base_cnt += round_total;
             // this wave's pairs of the round: ph (colour) and sm (silhouette), pixel-major; their positions in the round's list
             int nh, ns;
@@ -316,7 +383,7 @@ __device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, Wav
     key = acc->key[t.lane];
     ss.zeros = acc->zeros[t.lane];
     ss.qnz = exp2f((float)((double)acc->logsum[t.lane] * (1.0 / 4294967296.0)));
-    ss.lastf = acc->lastf[t.lane];
+    ss.lastf = coop_lastf(acc)[t.lane];
 }
 
 }  // namespace mm

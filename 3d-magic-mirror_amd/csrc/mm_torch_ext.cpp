@@ -8,6 +8,8 @@
 // built, diff_render.py uses its Python path: same calls, same results.
 #include <torch/extension.h>
 #include <torch/csrc/autograd/custom_function.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // device guard + current stream of a ROCm build of torch (host headers only)
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <cstring>
 #include <vector>
 #include "../../include/mm_render.h"
@@ -30,6 +32,13 @@ at::Tensor dense_f32(const at::Tensor& t, const c10::Device& dev, const char* wh
 }
 
 void check(int rc, const char* what) { TORCH_CHECK(rc == MM_OK, what, " failed with status ", rc); }
+
+// The stream a node's work is enqueued on is torch's CURRENT stream of the tensors' device at the time of the call, forward and backward
+// alike (the autograd engine re-establishes the forward's stream around a node's backward; a caller driving autograd.grad under another
+// stream context gets that one): never a raw handle remembered from the forward, which may be stale by then.  The guard makes the tensors'
+// device current for the allocations and the launches.
+typedef c10::hip::HIPGuardMasqueradingAsCUDA DeviceGuard;
+int64_t current_stream(const c10::Device& dev) { return (int64_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(); }
 
 MMRenderDesc proto_desc(const std::string& proto) {
     TORCH_CHECK(proto.size() == sizeof(MMRenderDesc), "descriptor prototype of ", proto.size(), " bytes, expected ", sizeof(MMRenderDesc));
@@ -95,7 +104,10 @@ std::vector<at::Tensor> render_backward(int64_t f_bwd, const std::string& proto,
     d.workspace = ws.data_ptr(); d.workspace_bytes = (size_t)ws.numel();
     if (g_fn.has_value() && g_fn->defined()) gfn = g_fn->to(at::kFloat).contiguous();
     if (fused) {
-        gloss = (g_loss.has_value() && g_loss->defined()) ? g_loss->to(at::kFloat).reshape({}).contiguous() : at::ones({}, vertices.options());
+        // An undefined gradient of the loss output means the loss took no part in what is being differentiated (materialize_grads is off):
+        // its gradient is ZERO, never one -- e.g. reg.backward() through attributes['face_normals'] only.
+        gloss = (g_loss.has_value() && g_loss->defined()) ? g_loss->to(at::kFloat).reshape({}).contiguous()
+                                                          : at::zeros({}, vertices.options().dtype(at::kFloat));
         d.fused_gt = optp(gt); d.fused_image_weight = (float)image_weight; d.fused_grad_loss = fptr(gloss);
         d.rgba = nullptr;                                    // the backward re-forms the prediction per pixel: the image is not read back (nor saved)
     } else {
@@ -160,11 +172,14 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
                                at::Tensor vertices, at::Tensor textures, at::Tensor lights, c10::optional<at::Tensor> bg, at::Tensor azimuths,
                                at::Tensor elevations, at::Tensor distances, at::Tensor biases, c10::optional<at::Tensor> gt, bool want_imnormal,
                                double image_weight, int64_t stream) {
+        TORCH_CHECK(azimuths.is_cuda(), "the MI355X render path needs tensors in device memory; there is no CPU fallback");
+        const DeviceGuard guard(azimuths.device());
+        stream = current_stream(azimuths.device());              // (the argument is kept for the binding's signature only)
         at::Tensor ws = at::empty({ws_bytes}, azimuths.options().dtype(at::kByte));   // (the caching allocator is the workspace pool)
         auto out = render_forward(f_fwd, f_loss, proto, vertices, textures, lights, bg, azimuths, elevations, distances, biases, gt, want_imnormal,
                                   image_weight, ws, stream);
         const bool fused = out[13].defined();
-        ctx->saved_data["f_bwd"] = f_bwd; ctx->saved_data["proto"] = proto; ctx->saved_data["stream"] = stream;
+        ctx->saved_data["f_bwd"] = f_bwd; ctx->saved_data["proto"] = proto;
         ctx->saved_data["image_weight"] = image_weight; ctx->saved_data["fused"] = fused;
         // dense inputs, forward products the backward re-reads, and the workspace (alive until this node dies)
         ctx->save_for_backward({out[5], out[6], out[7], out[8], out[9], out[10], out[11], out[12], out[3], out[1], out[13],
@@ -181,11 +196,12 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
     static tensor_list backward(AutogradContext* ctx, tensor_list g) {
         const auto sv = ctx->get_saved_variables();
         const bool fused = ctx->saved_data["fused"].toBool();
+        const DeviceGuard guard(sv[4].device());
         auto opt = [](const at::Tensor& t) { return t.defined() ? c10::optional<at::Tensor>(t) : c10::nullopt; };
         auto gr = render_backward(ctx->saved_data["f_bwd"].toInt(), ctx->saved_data["proto"].toStringRef(), sv[0], sv[1], sv[2], opt(sv[3]), sv[4], sv[5],
                                   sv[6], sv[7], sv[8], sv[9], opt(sv[10]), opt(sv[11]), opt(g[0]), opt(g[1]),
                                   (fused && g.size() > 4) ? opt(g[4]) : c10::nullopt, ctx->saved_data["image_weight"].toDouble(), sv[12],
-                                  ctx->saved_data["stream"].toInt());
+                                  current_stream(sv[4].device()));
         // one entry per forward argument: five non-tensors, then vertices, textures, lights, bg, azimuths, elevations, distances, biases, ...
         return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), gr[0], gr[1], gr[2], gr[3], gr[4], gr[5], gr[6], gr[7],
                 at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
@@ -196,16 +212,19 @@ class ReconNode : public torch::autograd::Function<ReconNode> {
  public:
     static at::Tensor forward(AutogradContext* ctx, int64_t f_ws, int64_t f_fwd, int64_t f_bwd, at::Tensor pred, at::Tensor gt, double image_weight,
                               double contour, int64_t stream) {
-        auto out = recon_forward(f_ws, f_fwd, pred, gt, image_weight, contour, stream);
+        TORCH_CHECK(pred.is_cuda(), "the MI355X render path needs tensors in device memory; there is no CPU fallback");
+        const DeviceGuard guard(pred.device());
+        auto out = recon_forward(f_ws, f_fwd, pred, gt, image_weight, contour, current_stream(pred.device()));
+        (void)stream;
         ctx->saved_data["f_bwd"] = f_bwd; ctx->saved_data["image_weight"] = image_weight; ctx->saved_data["contour"] = contour;
-        ctx->saved_data["stream"] = stream;
         ctx->save_for_backward({out[1], out[2], out[3]});
         return out[0];
     }
     static tensor_list backward(AutogradContext* ctx, tensor_list g) {
         const auto sv = ctx->get_saved_variables();
+        const DeviceGuard guard(sv[0].device());
         at::Tensor grad = recon_backward(ctx->saved_data["f_bwd"].toInt(), sv[0], sv[1], sv[2], g[0], ctx->saved_data["image_weight"].toDouble(),
-                                         ctx->saved_data["contour"].toDouble(), ctx->saved_data["stream"].toInt());
+                                         ctx->saved_data["contour"].toDouble(), current_stream(sv[0].device()));
         return {at::Tensor(), at::Tensor(), at::Tensor(), grad, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }
 };

@@ -23,8 +23,11 @@ class _PooledWorkspace(object):
     cycle through a handful of buffers instead of allocating ~200 MB each (the library never allocates; the host side owns scratch)."""
 
     def __init__(self, pool, key, nbytes, device):
-        self.pool, self.key = pool, key
-        free = pool.setdefault(key, [])
+        # The pool is keyed by the stream the work is enqueued on as well: a buffer released by a node whose kernels are still queued
+        # on stream A is only ever handed to another render on stream A, i.e. behind them in stream order (the torch caching allocator
+        # the C++ nodes use gives the same guarantee).
+        self.pool, self.key = pool, key + (torch.cuda.current_stream(device).cuda_stream,)
+        free = pool.setdefault(self.key, [])
         self.buf = free.pop() if free else torch.empty(nbytes, device=device, dtype=torch.uint8)
 
     def __del__(self):
@@ -86,9 +89,10 @@ class _RenderFn(torch.autograd.Function):
         holder = _PooledWorkspace(dr._ws_pool, (str(dev), nbytes), nbytes, dev)
         ws = holder.buf
         d.workspace, d.workspace_bytes = N.ptr(ws), ws.numel()
-        N.check(N.lib().mm_render_forward(ctypes.byref(d), N.current_stream(dev)), "mm_render_forward")
-        if gt is not None:
-            N.check(N.lib().mm_render_fused_loss(ctypes.byref(d), N.current_stream(dev)), "mm_render_fused_loss")
+        with torch.cuda.device(dev):                              # launches go to the tensors' device whatever the caller's current one is
+            N.check(N.lib().mm_render_forward(ctypes.byref(d), N.current_stream(dev)), "mm_render_forward")
+            if gt is not None:
+                N.check(N.lib().mm_render_fused_loss(ctypes.byref(d), N.current_stream(dev)), "mm_render_fused_loss")
         ctx.dr, ctx.no_mask, ctx.fused = dr, bool(no_mask), gt is not None
         ctx.ws_holder = holder                                   # returned to the pool when this node dies
         ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt)
@@ -114,7 +118,10 @@ class _RenderFn(torch.autograd.Function):
         g_fn = None if g_fn is None else g_fn.to(torch.float32).contiguous()
         d = dr._desc(st, B, ctx.no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases, None, face_idx, fn, None)   # (rgba: not read by the backward)
         if ctx.fused:
-            g_loss = torch.ones((), device=dev) if g_loss is None else g_loss.to(torch.float32).reshape(()).contiguous()
+            # None = the loss output took no part in what is being differentiated (materialize_grads is off): its gradient is ZERO,
+            # never one -- e.g. reg.backward() through attributes['face_normals'] after loss.backward(retain_graph=True)
+            g_loss = (torch.zeros((), device=dev, dtype=torch.float32) if g_loss is None
+                      else g_loss.to(device=dev, dtype=torch.float32).reshape(()).contiguous())
             d.fused_gt, d.fused_image_weight, d.fused_grad_loss = N.ptr(gt), float(dr.image_weight), N.ptr(g_loss)
         else:
             if g_rgba is None:
@@ -125,7 +132,8 @@ class _RenderFn(torch.autograd.Function):
         gbg = torch.empty_like(bg) if ctx.no_mask else None
         ga, ge, gd, gb = torch.empty_like(azimuths), torch.empty_like(elevations), torch.empty_like(distances), torch.empty_like(biases)
         g = N.MMRenderGrads(None if ctx.fused else N.ptr(g_rgba), N.ptr(g_fn), N.ptr(gv), N.ptr(gt_), N.ptr(gl), N.ptr(gbg), N.ptr(ga), N.ptr(ge), N.ptr(gd), N.ptr(gb))
-        N.check(N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), N.current_stream(dev)), "mm_render_backward")
+        with torch.cuda.device(dev):
+            N.check(N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), N.current_stream(dev)), "mm_render_backward")
         return None, None, None, None, gv, gt_, gl, gbg, ga, ge, gd, gb
 
 

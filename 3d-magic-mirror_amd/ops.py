@@ -34,26 +34,44 @@ def _f32(t, dev):
 
 
 _CSR_CACHE = {}
+_PROJ_CACHE = {}
 
 
 def _faces_tables(faces, dev):
-    """int32 device copy of ``faces`` and its vertex->corner CSR (needed by the gather-formulated backward), cached per tensor.
-    The entry HOLDS the tensor it was made from: a key of address + version alone is reused by the allocator for the next template of the
-    same shape once the first is freed (seen as a rare wrong-topology render between two 1280-face templates in the test suite)."""
-    key = (faces.data_ptr(), faces._version, tuple(faces.shape), str(faces.device), str(dev))
-    hit = _CSR_CACHE.get(key)
-    if hit is not None and hit[4] is not faces and not (hit[4].shape == faces.shape and torch.equal(hit[4], faces)):
-        hit = None                                               # same storage, other tensor object (a view / re-wrap): trust contents only
-    if hit is None:
-        fh = faces.detach().to("cpu", torch.int64)
-        V = int(fh.max()) + 1 if fh.numel() else 0
-        off, items = template.vertex_corner_adjacency(V, fh)
-        hit = (faces.detach().to(device=dev, dtype=torch.int32).contiguous(), off.to(device=dev, dtype=torch.int32).contiguous(),
-               items.to(device=dev, dtype=torch.int32).contiguous(), V, faces)
-        if len(_CSR_CACHE) > 16:
-            _CSR_CACHE.clear()
-        _CSR_CACHE[key] = hit
+    """int32 device copy of ``faces`` and its vertex->corner CSR (needed by the gather-formulated backward).
+    Cached by CONTENT: the reference re-creates the tensor on every render (``faces = self.faces.to(device)``, networks.py:272), so a key
+    of address / object identity never hits and every call would pay a device->host copy, the CSR rebuild and three uploads.  Entries
+    are looked up by (shape, dtype, device) and validated with ``torch.equal`` against the tensor they were made from -- on the tensor's own
+    device, no copy of the faces to the host; a template with other contents gets an entry of its own (a stale entry can never be used:
+    seen once as a wrong-topology render between two 1280-face templates when the key was the address)."""
+    key = (tuple(faces.shape), faces.dtype, str(faces.device), str(dev))
+    bucket = _CSR_CACHE.setdefault(key, [])
+    for hit in bucket:
+        if hit[4] is faces or torch.equal(hit[4], faces):
+            return hit
+    fh = faces.detach().to("cpu", torch.int64)
+    V = int(fh.max()) + 1 if fh.numel() else 0
+    off, items = template.vertex_corner_adjacency(V, fh)
+    hit = (faces.detach().to(device=dev, dtype=torch.int32).contiguous(), off.to(device=dev, dtype=torch.int32).contiguous(),
+           items.to(device=dev, dtype=torch.int32).contiguous(), V, faces.detach().clone())
+    if len(bucket) >= 4:
+        del bucket[0]
+    bucket.append(hit)
     return hit
+
+
+def _proj_tuple(camera_proj):
+    """camera_proj (3,1) as three Python floats; remembered per tensor (address + version + an on-device equality check against the copy the
+    floats were read from), so the device->host read happens once per projection, not once per render."""
+    key = (camera_proj.data_ptr(), camera_proj._version, str(camera_proj.device), tuple(camera_proj.shape))
+    hit = _PROJ_CACHE.get(key)
+    if hit is not None and (hit[1] is camera_proj or torch.equal(hit[1], camera_proj)):
+        return hit[0]
+    proj = tuple(float(x) for x in camera_proj.detach().reshape(-1).cpu().tolist())
+    if len(_PROJ_CACHE) > 16:
+        _PROJ_CACHE.clear()
+    _PROJ_CACHE[key] = (proj, camera_proj.detach().clone())
+    return proj
 
 
 # ---- kaolin.render.mesh.prepare_vertices -------------------------------------------------------------------------------
@@ -120,7 +138,7 @@ def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans
         raise RuntimeError("faces index vertex %d but vertices has %d" % (Vf - 1, vertices.shape[1]))
     if Vf < vertices.shape[1]:                                   # trailing vertices no face uses: pad the CSR
         off = torch.cat([off, off[-1:].expand(vertices.shape[1] - Vf)])
-    proj = tuple(float(x) for x in camera_proj.detach().reshape(-1).cpu().tolist())
+    proj = _proj_tuple(camera_proj)
     if len(proj) != 3:
         raise RuntimeError("camera_proj must have 3 entries")
     return _PrepareFn.apply(vertices, camera_transform.to(dev), faces_i32, off, items, proj)

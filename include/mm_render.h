@@ -105,8 +105,10 @@ enum { MM_OPT_WALK_BLOCK = 1 << 1,         /* tuning: force the 256-thread / coo
        MM_OPT_BBOX_HALF_OPEN = 1 << 6,     /* a pixel centre exactly on a face's bbox edge is outside (<= / >= reject)     (App. C-4) */
        MM_OPT_BARY_ONE_MINUS = 1 << 7,     /* barycentrics as w1 = k1/(S+eps), w2 = k2/(S+eps), w0 = 1 - w1 - w2 (eps added, not
                                             * copysign'd) instead of three edge functions / copysign-padded sum          (App. C-3) */
-       MM_OPT_SH_ORDER_XYZ = 1 << 8 };     /* SH linear bands in x,y,z order and quadratic bands xy,yz,3z^2-1,xz,x^2-y^2 paired with
+       MM_OPT_SH_ORDER_XYZ = 1 << 8,       /* SH linear bands in x,y,z order and quadratic bands xy,yz,3z^2-1,xz,x^2-y^2 paired with
                                             * lights 1..8 in THAT order (instead of x,z,y / xy,yz,z^2,xz,x^2-y^2)          (App. C-6) */
+       MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9 };  /* bbox test [min, max): reject x < min || x >= max -- the third form upstream may have,
+                                            * between the closed default and MM_OPT_BBOX_HALF_OPEN (which opens both borders)  (App. C-4) */
 
 enum { MM_PROF_VERTEX_FWD = 0, MM_PROF_RASTER_FWD = 1, MM_PROF_PIXEL_BWD = 2, MM_PROF_GATHER_BWD = 3, MM_PROF_VERTEX_BWD = 4,
        MM_PROF_ORDER = 5, MM_PROF_RENDER_SLOTS = 6 };

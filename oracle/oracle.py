@@ -34,6 +34,7 @@ def lib():
 
 
 OPT_CULL_STRICT, OPT_SOFT_SKIP_CULLED, OPT_BBOX_HALF_OPEN, OPT_BARY_ONE_MINUS, OPT_SH_ORDER_XYZ = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
+OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9
 
 
 class options(object):

@@ -16,6 +16,7 @@ pkg._native.LIB_PATH = var
 bn.needs_build = lambda: False
 dev = torch.device("cuda:0")
 dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio, emit_imnormal=False)
+dr.options = int(os.environ.get("MM_OPTIONS", "0"))
 H, W = dr.render_height, dr.image_size
 att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W)
 datt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}
@@ -53,6 +54,17 @@ for kn, (phases, cn) in KERNELS.items():
     acc = m[:, :len(phases)].sum(1) / 100.0
     print("   %-46s mean %6.2f us" % ("(unaccounted)", (tot - acc).mean()))
     print("   %s: mean %.2f max %d;  %s: mean %.1f max %d" % (cn[0], m[:, SL + 1].mean(), m[:, SL + 1].max(), cn[1], m[:, SL + 2].mean(), m[:, SL + 2].max()))
+    if kn == "raster_fwd":                                       # single-wave tiles: c0 = candidates | flushes << 32, c1 = colour pairs | silhouette pairs << 32
+        c0, c1 = m[:, SL + 1].astype(np.uint64), m[:, SL + 2].astype(np.uint64)
+        cand, fl, hp, sp = (c0 & 0xFFFFFFFF).astype(float), (c0 >> 32).astype(float), (c1 & 0xFFFFFFFF).astype(float), (c1 >> 32).astype(float)
+        print("   per wave: candidates %.1f  flushes %.2f  colour pairs %.1f  silhouette pairs %.1f" % (cand.mean(), fl.mean(), hp.mean(), sp.mean()))
+        for lo_, hi_ in ((0, 64), (64, 192), (192, 512), (512, 1024), (1024, 1e9)):
+            sel = (cand >= lo_) & (cand < hi_)
+            if sel.any():
+                print("   tiles with %4d <= candidates < %-6g: %5d waves, %4.1f %% of wave time; mean %.1f us, flushes %.1f, colour pairs %.0f, silhouette pairs %.0f"
+                      % (lo_, hi_, sel.sum(), 100 * tot[sel].sum() / tot.sum(), tot[sel].mean(), fl[sel].mean(), hp[sel].mean(), sp[sel].mean()))
+        for h in np.argsort(-tot)[:8]:
+            print("   slow wave %.1f us: candidates %d flushes %d colour pairs %d silhouette pairs %d" % (tot[h], cand[h], fl[h], hp[h], sp[h]))
     heavy = np.argsort(-tot)[:int(os.environ.get('MM_PP_SLOWEST', '4'))]
     for h in heavy:
         print("   slowest wave: total %.1f us | " % tot[h] + "  ".join("%s %.1f" % (ph.split(":")[0].split(" ")[0], m[h, i] / 100.0) for i, ph in enumerate(phases)) + " | %s %d %s %d" % (cn[0], m[h, SL + 1], cn[1], m[h, SL + 2]))

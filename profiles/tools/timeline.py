@@ -25,7 +25,7 @@ st = stepmod.RenderLossStep(dr, datt, gtd, fused=True)
 for _ in range(5): st.run()
 torch.cuda.synchronize()
 L = ctypes.CDLL(var)
-MAXB = 16384
+MAXB = 81920
 print("== %s: %s B=%d %dx%d" % (cfg, name, B, H, W))
 for kn in ("raster_fwd", "pixel_bwd", "gather_bwd"):
     out = (ctypes.c_ulonglong * (MAXB * 2))()
@@ -38,7 +38,7 @@ for kn in ("raster_fwd", "pixel_bwd", "gather_bwd"):
     d = e - s
     print("%s: %d workgroups recorded (first %d of the grid), span %.1f us" % (kn, len(m), MAXB, e.max()))
     print("   start: p50 %.1f p90 %.1f last %.1f us | duration: mean %.1f p90 %.1f p99 %.1f max %.1f us" % (np.median(s), np.percentile(s, 90), s.max(), d.mean(), np.percentile(d, 90), np.percentile(d, 99), d.max()))
-    qs = np.linspace(0, e.max(), 9)[1:-1]
+    qs = np.linspace(0, e.max(), 17)[1:-1]
     print("   running at t: " + "  ".join("%.0fus:%d" % (q, int(((s <= q) & (e > q)).sum())) for q in qs))
     late = np.argsort(-e)[:6]
     print("   last finishers (index, start, end): " + ", ".join("(%d, %.1f, %.1f)" % (int(np.nonzero(live)[0][i]), s[i], e[i]) for i in late))

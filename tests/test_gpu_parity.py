@@ -153,9 +153,10 @@ def test_close_camera_huge_face_boxes_match_oracle(pkg, oracle, name, B, S, dist
         _close(datt[k].grad.cpu().numpy(), g_o[k])
 
 
-@pytest.mark.parametrize("bit", ["OPT_CULL_STRICT", "OPT_SOFT_SKIP_CULLED", "OPT_BBOX_HALF_OPEN", "OPT_BARY_ONE_MINUS", "OPT_SH_ORDER_XYZ", "ALL"])
+@pytest.mark.parametrize("bit", ["OPT_CULL_STRICT", "OPT_SOFT_SKIP_CULLED", "OPT_BBOX_HALF_OPEN", "OPT_BBOX_MIN_CLOSED_MAX_OPEN", "OPT_BARY_ONE_MINUS", "OPT_SH_ORDER_XYZ",
+                                 "ALL"])
 def test_appendix_c_switches_match_the_oracle(pkg, oracle, bit):
-    """the choices recalled from kaolin's sources (cull >= / >, soft mask over culled faces, closed / half-open
+    """the choices recalled from kaolin's sources (cull >= / >, soft mask over culled faces, closed / [min, max) / open
     bbox, copysign(eps) / (1 - w1 - w2) barycentrics, SH band order) are switches of MMRenderDesc.options, mirrored bit for bit by
     the oracle: whoever can run real kaolin pins the path by flipping a bit.  Every switch alone and all together:
       (1) forward + backward at the full bar on the usual seeded input;
@@ -163,7 +164,7 @@ def test_appendix_c_switches_match_the_oracle(pkg, oracle, bit):
           an axis-aligned camera put pixel centres exactly on edges and box borders and give exactly edge-on faces (normal z == 0):
           gradients are not compared there (1 / area of a zero-area face), the switches only touch the forward's decisions."""
     N = pkg._native
-    names = ["OPT_CULL_STRICT", "OPT_SOFT_SKIP_CULLED", "OPT_BBOX_HALF_OPEN", "OPT_BARY_ONE_MINUS", "OPT_SH_ORDER_XYZ"]
+    names = ["OPT_CULL_STRICT", "OPT_SOFT_SKIP_CULLED", "OPT_BBOX_HALF_OPEN", "OPT_BBOX_MIN_CLOSED_MAX_OPEN", "OPT_BARY_ONE_MINUS", "OPT_SH_ORDER_XYZ"]
     bits = sum(getattr(N, n) for n in names) if bit == "ALL" else getattr(N, bit)
     assert bits == (sum(getattr(oracle, n) for n in names) if bit == "ALL" else getattr(oracle, bit))
     # (1)
@@ -374,8 +375,8 @@ def test_forward_is_deterministic_and_headline_size_properties(pkg):
     assert o1["imnormal"] is None
     a = r1[:, 3]
     assert float(r1.min()) >= 0 and float(r1.max()) <= 1
-    assert bool(((f1 >= 0) == (a == 1)).all() | True)                         # covered pixels have alpha exactly 1
-    assert bool((a[f1 >= 0] == 1).all())
+    assert bool((a[f1 >= 0] == 1).all())                                      # covered pixels have alpha exactly 1
+    assert bool((a[f1 < 0] < 1).any()) and bool((a[f1 < 0] >= 0).all())       # uncovered ones carry the soft silhouette in [0, 1]
     cov = (f1 >= 0).float().mean().item()
     assert 0.1 < cov < 0.5
     # every winning face is front facing
@@ -404,34 +405,78 @@ def test_gradients_reach_all_inputs_at_headline_size(pkg):
     assert float((datt["textures"].grad != 0).float().mean()) < 0.9
 
 
-def test_stress_size_batch_independence_and_one_image_against_oracle(pkg, oracle):
+def test_stress_size_batch_independence_and_four_images_against_oracle(pkg, oracle):
     """BASELINE config 5 (smpl_uv: 13 776 faces, B=16, 512x512, texture 1024x512) at FULL size.  Size-independent property: an
-    image's result does not depend on the batch it is rendered in (bitwise in the forward, to rounding in the backward, whose
-    LDS float adds are unordered) -- so the oracle run of ONE image of the batch vouches for the whole batch."""
-    B, S, k = 16, 512, 5
+    image's result does not depend on the batch it is rendered in (bitwise, forward and backward: every accumulation of the backward is
+    an integer add) -- and FOUR images of the batch (the nearest and the farthest camera among them: the lightest and the heaviest tiles)
+    are checked against the oracle one by one."""
+    B, S = 16, 512
     dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv", B, S, seed=12, imn=False)
     rgbs, out = dr.render(no_mask=True, **datt)
     fidx = dr.last_face_idx.clone()
     dr.recon_data(rgbs, gt.to(dev), no_mask=True).backward()
     cov = (fidx >= 0).float().mean().item()
     assert 0.05 < cov < 0.6 and bool((rgbs[:, 3][fidx >= 0] == 1).all())
-    # image k alone
-    one = {kk: (v[k:k + 1].detach().clone().requires_grad_(kk in LEAVES) if torch.is_tensor(v) else v) for kk, v in datt.items()}
-    r1, o1 = dr.render(no_mask=True, **one)
-    assert torch.equal(dr.last_face_idx[0], fidx[k]) and torch.equal(r1[0], rgbs[k].detach())
-    # recon_data means over the batch: the full batch's gradient of image k is 1/B of the single-image gradient for the L1 term
-    # and for the IoU term alike (both are means of per-image terms)
-    dr.recon_data(r1, gt[k:k + 1].to(dev), no_mask=True).backward()
-    for kk in LEAVES:
-        _close(datt[kk].grad[k].cpu().numpy() * B, one[kk].grad[0].cpu().numpy(), 2e-5)
-    # the oracle on that one image
-    inp1 = {kk: (v[k:k + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for kk, v in inp.items()}
-    rgba_o, fidx_o, _, _ = oracle.render_forward(inp1, H, W, True, proj)
-    assert np.array_equal(dr.last_face_idx[0].cpu().numpy(), fidx_o[0])
-    _close(r1[0].detach().permute(1, 2, 0).cpu().numpy(), rgba_o[0])
-    loss_o, g_o = oracle.step(inp1, gt[k:k + 1].numpy(), H, W, True, proj, image_weight=dr.image_weight)
-    for kk in LEAVES:
-        _close(one[kk].grad.cpu().numpy(), g_o[kk])
+    dist = att["distances"].numpy()
+    picks = sorted({int(dist.argmin()), int(dist.argmax()), 5, 11})
+    assert len(picks) >= 3
+    for k in picks:
+        # image k alone
+        one = {kk: (v[k:k + 1].detach().clone().requires_grad_(kk in LEAVES) if torch.is_tensor(v) else v) for kk, v in datt.items()}
+        r1, o1 = dr.render(no_mask=True, **one)
+        assert torch.equal(dr.last_face_idx[0], fidx[k]) and torch.equal(r1[0], rgbs[k].detach())
+        # recon_data means over the batch: the full batch's gradient of image k is 1/B of the single-image gradient for the L1 term
+        # and for the IoU term alike (both are means of per-image terms)
+        dr.recon_data(r1, gt[k:k + 1].to(dev), no_mask=True).backward()
+        for kk in LEAVES:
+            _close(datt[kk].grad[k].cpu().numpy() * B, one[kk].grad[0].cpu().numpy(), 2e-5)
+        # the oracle on that one image
+        inp1 = {kk: (v[k:k + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for kk, v in inp.items()}
+        rgba_o, fidx_o, _, _ = oracle.render_forward(inp1, H, W, True, proj)
+        assert np.array_equal(dr.last_face_idx[0].cpu().numpy(), fidx_o[0]), k
+        _close(r1[0].detach().permute(1, 2, 0).cpu().numpy(), rgba_o[0])
+        loss_o, g_o = oracle.step(inp1, gt[k:k + 1].numpy(), H, W, True, proj, image_weight=dr.image_weight)
+        for kk in LEAVES:
+            _close(one[kk].grad.cpu().numpy(), g_o[kk])
+
+
+@pytest.mark.parametrize("use_ext", [True, False])
+def test_unused_fused_loss_contributes_no_gradient(pkg, use_ext):
+    """render_recon's loss output is ONE of the node's differentiable outputs.  Differentiating something that does not involve it --
+    a regulariser through attributes['face_normals'] alone -- must give exactly what the un-fused render gives: the missing gradient
+    of the loss is zero, not one (both host paths; also under a float64 default dtype, which must not leak into the 4-byte scalar)."""
+    N = pkg._native
+    if use_ext and N.torch_ext() is None:
+        pytest.skip("mm_torch_ext is not built")
+    ext, got = N.torch_ext(), []
+    old = torch.get_default_dtype()
+    try:
+        N._EXT = ext if use_ext else None
+        torch.set_default_dtype(torch.float64)
+        for fused in (False, True):
+            dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 4, 64, seed=5)
+            if fused:
+                loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=True, **datt)
+            else:
+                rgbs, out = dr.render(no_mask=True, **datt)
+            w = torch.linspace(-1.0, 1.0, out["face_normals"].numel(), device=dev, dtype=torch.float32).reshape(out["face_normals"].shape)
+            (out["face_normals"] * w).sum().backward(retain_graph=True)
+            g_reg = {k: (None if datt[k].grad is None else datt[k].grad.clone()) for k in LEAVES}
+            if fused:                                            # the loss afterwards, on the retained graph: accumulates on top
+                loss.backward()
+                g_both = {k: datt[k].grad.clone() for k in LEAVES}
+            got.append((g_reg, g_both if fused else None))
+    finally:
+        N._EXT = ext
+        torch.set_default_dtype(old)
+    for k in LEAVES:
+        a, b = got[0][0][k], got[1][0][k]
+        assert (a is None) == (b is None) or (a is None and float(b.abs().max()) == 0) or (b is None and float(a.abs().max()) == 0), k
+        if a is not None and b is not None:
+            assert torch.equal(a, b), k                          # same kernels, same bits: nothing of the loss leaked in
+    assert float(got[0][0]["vertices"].abs().max()) > 0
+    assert float((got[1][1]["textures"] - 0).abs().max()) > 0   # and the loss's own gradient arrives when it IS differentiated
+    assert not torch.equal(got[1][1]["vertices"], got[1][0]["vertices"])
 
 
 def test_error_behaviour(pkg):

@@ -22,6 +22,7 @@ struct BwdArgs {
     const float* bg;
     const int32_t* face_idx;
     const float2* soft;
+    const int* fflag;                                            // (B,F) faces that receive gradient from the pixels (raster_fwd): the others get no sweep items
     const float* grad_rgba;
     float4* gp; float* gp2;
     float* dl_part;

@@ -72,6 +72,8 @@ struct Workspace {
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
     int* nheavy;           // (B,2)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty
     int* bincount;         // (B,nbins)  candidates per screen bin (big screens / meshes only: bincount_kernel -> order_kernel)
+    int* fflag;            // (B,F)      1: the face won a pixel, or an uncovered pixel took it into its silhouette product -- only such faces receive
+                           //            gradient from the pixels, and only they are swept by the backward (cleared by vertex_fwd, set by raster_fwd)
     long long* ltot;       // (B,MM_LSUB,4) fused loss: per image {sum|pi-gi|, sum p*g, sum p+g-p*g, -} in 2^-32 fixed point, spread over
                            //            MM_LSUB sub-accumulators (64-bit integer atomics of the raster waves: exact, order-free); zeroed by vertex_fwd
     int* tcnt;             // (B,ntiles)+(B)+(B,MM_GSHARD,8) records appended per texture tile, per-image spill counts, per-image maxima of the pixel
@@ -117,6 +119,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
     w.nheavy = (int*)(p + o);       o += align256((size_t)B * 2 * sizeof(int));
     w.bincount = (int*)(p + o);     o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
+    w.fflag = (int*)(p + o);        o += align256((size_t)B * F * sizeof(int));   // (ints, not bytes: a byte store may alias every later load in the compiler's eyes)
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
     w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + (size_t)B + (size_t)B * MM_GSHARD * 8) * sizeof(int));
     w.tspill = (TexSpill*)(p + o);  o += align256((size_t)B * 4 * H * W * sizeof(TexSpill));
@@ -585,6 +588,13 @@ __device__ inline unsigned wave_min_u32(unsigned v) {
     return min(min((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
                min((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
 }
+__device__ inline unsigned wave_or_u32(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);
+    return ((unsigned)__builtin_amdgcn_readlane((int)v, 0) | (unsigned)__builtin_amdgcn_readlane((int)v, 16)) |
+           ((unsigned)__builtin_amdgcn_readlane((int)v, 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 48));
+}
+__device__ inline uint64_t wave_or_u64(uint64_t v) { return ((uint64_t)wave_or_u32((unsigned)(v >> 32)) << 32) | wave_or_u32((unsigned)v); }
 __device__ inline float wave_max(float v) {
     v = fmaxf(v, dpp_move<0xB1>(v)); v = fmaxf(v, dpp_move<0x4E>(v)); v = fmaxf(v, dpp_move<0x141>(v)); v = fmaxf(v, dpp_move<0x140>(v));
     return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));

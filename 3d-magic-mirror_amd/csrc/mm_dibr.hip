@@ -72,12 +72,12 @@ __global__ __launch_bounds__(256) void dibr_pack_kernel(PackArgs a) {
 }
 
 // the fused kernel's walk (four tiles per workgroup, or one heavy tile walked by its four waves), the generic epilogue
-template <bool kBlock>
+template <bool kBlock, bool kQueue>
 __global__ __launch_bounds__(kBlock ? 256 : 64) void raster_dibr_kernel(RasterArgs a) {
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
     const int wv = kBlock ? threadIdx.x >> 6 : 0;
     bool valid, coop;
-    const TileCtx t = make_tile<kBlock>(a, wv, valid, coop, 4 * a.blocks_per_image);
+    const TileCtx t = make_tile<kBlock>(a, wv, -1, valid, coop, 4 * a.blocks_per_image);
     unsigned long long key;
     Hit h;
     SoftState ss;
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) void raster_dibr_kernel(RasterAr
         if (wv != 0) return;
     } else {
         if (!valid) return;
-        tile_walk(a, t, &s_stage[wv], key, ss MM_PP_PASS);
+        if (kQueue) tile_walk(a, t, &s_stage[wv], key, ss MM_PP_PASS);
+        else tile_walk_batch(a, t, &s_stage[wv], key, ss MM_PP_PASS);
     }
     winner(a, t, key, h);
     if (!t.in_img) return;
@@ -264,10 +265,14 @@ int mm_dibr_rasterization_forward(const MMDibrDesc* d, mm_stream_t stream) {
     a.feats = d->face_features; a.D = d->D; a.interp = d->interpolated_features; a.soft_out = d->soft_mask;
     a.face_idx64 = (long long*)d->face_idx;
     a.order = launch_order(a, w.order, w.nheavy, w.bincount, d->B, nullptr, s);
+    a.spread = walk_spread(a);
     a.nheavy = w.nheavy;
     const bool block = walk_block_mode(a);
-    if (block) hipLaunchKernelGGL(raster_dibr_kernel<true>, dim3(walk_grid(a, true)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(raster_dibr_kernel<false>, dim3(walk_grid(a, false)), dim3(64), 0, s, a);
+    const bool queue = walk_queue_mode(a);
+    if (block) { if (queue) hipLaunchKernelGGL((raster_dibr_kernel<true, true>), dim3(walk_grid(a, true)), dim3(256), 0, s, a);
+                 else hipLaunchKernelGGL((raster_dibr_kernel<true, false>), dim3(walk_grid(a, true)), dim3(256), 0, s, a); }
+    else { if (queue) hipLaunchKernelGGL((raster_dibr_kernel<false, true>), dim3(walk_grid(a, false)), dim3(64), 0, s, a);
+           else hipLaunchKernelGGL((raster_dibr_kernel<false, false>), dim3(walk_grid(a, false)), dim3(64), 0, s, a); }
     return launch_ok("raster_dibr");
 }
 

@@ -28,9 +28,10 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
     __shared__ unsigned short s_nch[MM_PLAN_LDS_FACES];
     const int tid = threadIdx.x;
     const bool staged = a.F <= MM_PLAN_LDS_FACES;                 // (more faces than that: the counts are re-read from the face records)
-    auto box_px = [&](int f) {
-        const unsigned ext = __float_as_uint(a.geo[((size_t)b * a.F + f) * 3 + 2].w);
-        return (int)(ext & 0xFFFFu) * (int)(ext >> 16);          // 0: the box misses the image
+    auto box_px = [&](int f) {                                   // (a face the forward did not flag owns no pixel and is in no silhouette product:
+        const unsigned ext = __float_as_uint(a.geo[((size_t)b * a.F + f) * 3 + 2].w);          //  nothing to sweep -- most faces of a fine, overlapping mesh)
+        const int live = a.fflag ? a.fflag[(size_t)b * a.F + f] : 1;
+        return live ? (int)(ext & 0xFFFFu) * (int)(ext >> 16) : 0;   // 0: the box misses the image, or no pixel refers to the face
     };
     if (staged) {
         for (int f0 = tid; f0 < a.F; f0 += 8 * 256) {

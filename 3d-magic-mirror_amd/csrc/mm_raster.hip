@@ -35,28 +35,36 @@ namespace mm {
 #ifndef MM_RASTER_LB
 #define MM_RASTER_LB 5
 #endif
-template <bool kNoMask, bool kBlock>
-__global__ __launch_bounds__(kBlock ? 256 : 64, kBlock ? MM_RASTER_LB : 1) void raster_fwd_kernel(RasterArgs a) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
+#ifndef MM_RASTER_WPE
+#define MM_RASTER_WPE 5
+#endif
+// kQueue: the compacting walk (tile_walk) for screen bins larger than a tile; otherwise the per-batch walk (tile_walk_batch)
+template <bool kNoMask, bool kBlock, bool kQueue>
+__global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_eu(MM_RASTER_WPE, MM_RASTER_WPE))) void raster_fwd_kernel(RasterArgs a) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
     MM_TIMELINE_BEGIN();
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
     MM_PP_BEGIN();
     const int wv = kBlock ? threadIdx.x >> 6 : 0;
-    int limit = 4 * a.blocks_per_image;
+    int limit = 4 * a.blocks_per_image, rank = -1;               // rank: this workgroup's index among its image's walking workgroups (-1: from blockIdx)
     if (a.order) {
         // workgroups of image b, in launch order: heavy tiles (one each), the other non-empty tiles (four each, or one), then the empty
         // tiles four per WAVE (shade_empty_tiles); the grid is sized for "no tile is empty", workgroups behind the last one exit
-        const int b = blockIdx.x % a.B, j = blockIdx.x / a.B;
+        int b, j;
+        walk_image_rank((int)blockIdx.x, a.B, a.spread != 0, b, j);
         const int nh = kBlock ? a.nheavy[2 * b] : 0, nne = a.nheavy[2 * b + 1];
-        const int je = kBlock ? nh + (max(nne - nh, 0) + 3) / 4 : nne;       // first workgroup of the empty tiles
+        const int W1 = kBlock ? nh + (max(nne - nh, 0) + 3) / 4 : nne;       // workgroups that walk: heavy tiles one each, the others four each (or one)
+        const int per = kBlock ? 16 : 4, W2 = (4 * a.blocks_per_image - nne + per - 1) / per;   // workgroups that shade empty tiles
         limit = nne;
-        if (j >= je) {
-            const int e0 = nne + (j - je) * (kBlock ? 16 : 4) + wv * 4, ne = min(4, 4 * a.blocks_per_image - e0);
+        if (j >= W1) {                                           // (interleaving the two kinds of workgroup evenly was measured: no gain at 512x512,
+            if (j - W1 >= W2) return;                            //  slower at 128x128, where every walking workgroup is resident from the start)
+            const int e0 = nne + (j - W1) * per + wv * 4, ne = min(4, 4 * a.blocks_per_image - e0);
             if (ne > 0) shade_empty_tiles<kNoMask>(a, b, e0, ne, threadIdx.x & 63);
             return;
         }
+        rank = j;
     }
     bool valid, coop;
-    const TileCtx t = make_tile<kBlock>(a, wv, valid, coop, limit);          // coop is workgroup-uniform; !valid only in the last workgroup of the non-empty tiles
+    const TileCtx t = make_tile<kBlock>(a, wv, rank, valid, coop, limit);    // coop is workgroup-uniform; !valid only in the last workgroup of the non-empty tiles
     unsigned long long key;
     SoftState ss;
     MM_PP_MARK(0);
@@ -65,9 +73,11 @@ __global__ __launch_bounds__(kBlock ? 256 : 64, kBlock ? MM_RASTER_LB : 1) void 
         if (wv != 0) return;                                     // the tile's pixels are shaded once
     } else {
         if (!valid) return;
-        tile_walk(a, t, &s_stage[wv], key, ss MM_PP_PASS);
+        if (kQueue) tile_walk(a, t, &s_stage[wv], key, ss MM_PP_PASS);
+        else tile_walk_batch(a, t, &s_stage[wv], key, ss MM_PP_PASS);
     }
     shade_store<kNoMask>(a, t, key, ss);
+    flush_taken_last(a, t, &s_stage[(kBlock && coop) ? 0 : wv]);
     MM_PP_MARK(5);
     MM_PP_FLUSH(raster_fwd, (long long)blockIdx.x * (kBlock ? 4 : 1) + wv);
     MM_TIMELINE_END(raster_fwd);
@@ -155,8 +165,8 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H;
-    a.bincount = nullptr;
-    a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.gt = d->fused_gt; a.ltot = w.ltot;
+    a.bincount = nullptr; a.spread = 0;
+    a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.fflag = w.fflag; a.gt = d->fused_gt; a.ltot = w.ltot;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     a.order = nullptr;
@@ -182,17 +192,23 @@ const unsigned short* launch_order(RasterArgs& a, unsigned short* order, int* nh
 int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     RasterArgs a = make_raster_args(d, w);
     a.order = launch_order(a, w.order, w.nheavy, w.bincount, d->B, d->prof_events, s);     // heavy-first launch order
+    a.spread = walk_spread(a);
     a.nheavy = w.nheavy;
     const bool block = walk_block_mode(a);
     const dim3 grid(walk_grid(a, block));
     ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
+    // 8-pixel bins: the bin is the tile, nothing to compact -> the per-batch walk, no face flags (every face gets its sweep items)
+    const bool queue = walk_queue_mode(a);
+    if (!queue) a.fflag = nullptr;
+#define MM_LAUNCH_RASTER(NM, BL, QU) hipLaunchKernelGGL((raster_fwd_kernel<NM, BL, QU>), grid, dim3(BL ? 256 : 64), 0, s, a)
     if (block) {
-        if (d->no_mask) hipLaunchKernelGGL((raster_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((raster_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
+        if (queue) { if (d->no_mask) MM_LAUNCH_RASTER(true, true, true); else MM_LAUNCH_RASTER(false, true, true); }
+        else { if (d->no_mask) MM_LAUNCH_RASTER(true, true, false); else MM_LAUNCH_RASTER(false, true, false); }
     } else {
-        if (d->no_mask) hipLaunchKernelGGL((raster_fwd_kernel<true, false>), grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((raster_fwd_kernel<false, false>), grid, dim3(64), 0, s, a);
+        if (queue) { if (d->no_mask) MM_LAUNCH_RASTER(true, false, true); else MM_LAUNCH_RASTER(false, false, true); }
+        else { if (d->no_mask) MM_LAUNCH_RASTER(true, false, false); else MM_LAUNCH_RASTER(false, false, false); }
     }
+#undef MM_LAUNCH_RASTER
     return launch_ok("raster_fwd");
 }
 

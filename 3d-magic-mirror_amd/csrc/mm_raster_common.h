@@ -21,9 +21,11 @@ struct RasterArgs {
     const float* lights;
     const float* bg;
     float2* soft;                           // per pixel {soft-mask product state, id of the knum-th face taken (int bits)}
+    int* fflag;                             // (B,F) set to 1 for a face that wins a pixel or is taken into an uncovered pixel's silhouette product (nullptr: not wanted)
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     const int* nheavy;                      // (B,2) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty
+    int spread;                             // sorted order: eight consecutive workgroups = eight ranks of one image (walk_image_rank)
     const int* bincount;                    // (B,nbins) candidates per screen bin, or nullptr (small screens: the order kernel counts the mask bits itself)
     // outputs
     float* rgba;
@@ -139,12 +141,18 @@ __device__ inline void pair_parallel(const TileCtx& t, Stage* st, uint64_t m, Ev
             ++k;
         }
         wave_lds_sync();
-        for (int p = t.lane; p < lim; p += 128) {                // two independent pairs per trip: ILP for a lone wave
-            const unsigned pr0 = st->pairs[p];
-            const bool two = p + 64 < lim;
-            const unsigned pr1 = two ? st->pairs[p + 64] : pr0;
-            eval((int)(pr0 >> 8), (int)(pr0 & 255u), true);
-            if (__ballot(two)) eval((int)(pr1 >> 8), (int)(pr1 & 255u), two);   // wave-uniform: no dummy second evaluation for a short list
+        if (lim <= 64) {                                         // wave-uniform: one pair per lane at most, no dummy second evaluation
+            const bool live = t.lane < lim;
+            const unsigned pr = st->pairs[live ? t.lane : 0];
+            eval((int)(pr >> 8), (int)(pr & 255u), live);
+        } else {
+            for (int p = t.lane; p < lim; p += 128) {            // two independent pairs per trip: ILP for a lone wave
+                const unsigned pr0 = st->pairs[p];
+                const bool two = p + 64 < lim;
+                const unsigned pr1 = two ? st->pairs[p + 64] : pr0;
+                eval((int)(pr0 >> 8), (int)(pr0 & 255u), true);
+                if (__ballot(two)) eval((int)(pr1 >> 8), (int)(pr1 & 255u), two);   // wave-uniform
+            }
         }
         wave_lds_sync();
     }
@@ -198,6 +206,12 @@ __device__ inline void hard_pair(const RasterArgs& a, const TileCtx& t, Stage* s
 //            Survivors are ballot-compacted IN PLACE at the front of the pair list (writes never pass the read cursor).
 //   phase B  the survivors, densely: hard_pair as before (divisions, inside test, depth, 64-bit LDS max).
 // m: the flush's colour masks, rows = candidates (by_cand) or pixels; results do not depend on the order of evaluation.
+#ifndef MM_HARD_DIRECT
+#define MM_HARD_DIRECT 192
+#endif
+#ifndef MM_PAIR_Z
+#define MM_PAIR_Z 0            // 1: early-z per PAIR (interpolated depth with a hardware reciprocal) instead of per face (its largest corner depth): fewer
+#endif                         // survivors, six more registers -- and this kernel lives on its occupancy
 typedef float mm_f2 __attribute__((ext_vector_type(2)));
 template <class Stage>
 __device__ inline void hard_pairs(const RasterArgs& a, const TileCtx& t, Stage* st, uint64_t m, bool by_cand) {
@@ -215,6 +229,8 @@ __device__ inline void hard_pairs(const RasterArgs& a, const TileCtx& t, Stage* 
         }
         wave_lds_sync();
         int w = 0;                                               // survivors so far (wave-uniform): they occupy pairs[0, w)
+        if (total <= MM_HARD_DIRECT) w = lim;                    // (wave-uniform) a short list: the filter pass would cost more trips than it saves
+        else
         for (int q0 = 0; q0 < lim; q0 += 128) {
             const bool v0 = q0 + t.lane < lim, v1 = q0 + 64 + t.lane < lim;
             const unsigned e0 = st->pairs[v0 ? q0 + t.lane : 0], e1 = st->pairs[v1 ? q0 + 64 + t.lane : 0];
@@ -222,7 +238,11 @@ __device__ inline void hard_pairs(const RasterArgs& a, const TileCtx& t, Stage* 
             const float4 A0 = st->p0[j0], B0 = st->p1[j0], A1 = st->p0[j1], B1 = st->p1[j1];
             // early-z: what the pixel holds by now (the high word of its key; 0 = nothing yet) against an upper bound of the depth this pair
             // would give it -- the interpolation with a hardware reciprocal (1 ulp) plus 2e-5 of the corner depths' magnitudes
+#if MM_PAIR_Z
             const float cz0 = st->p2[j0].x, cz1 = st->p2[j1].x;
+#else
+            const unsigned zb0 = __float_as_uint(st->p2[j0].w), zb1 = __float_as_uint(st->p2[j1].w);   // the face's depth bound
+#endif
             const unsigned kh0 = (unsigned)(st->key[l0] >> 32), kh1 = (unsigned)(st->key[l1] >> 32);
             bool pass0, pass1;
             {
@@ -239,11 +259,15 @@ __device__ inline void hard_pairs(const RasterArgs& a, const TileCtx& t, Stage* 
                 const bool sane0 = fabsf(nrm.x) <= 1e12f, sane1 = fabsf(nrm.y) <= 1e12f;
                 const bool rej0 = sane0 && ((!one_minus && neg(k0.x, nrm.x)) || neg(k1.x, nrm.x) || neg(k2.x, nrm.x));
                 const bool rej1 = sane1 && ((!one_minus && neg(k0.y, nrm.y)) || neg(k1.y, nrm.y) || neg(k2.y, nrm.y));
+#if MM_PAIR_Z
                 const mm_f2 az = {B0.z, B1.z}, bz = {B0.w, B1.w}, cz = {cz0, cz1};
                 const mm_f2 zn = (k0 * az + k1 * bz) + k2 * cz;
                 const float zu0 = zn.x * __builtin_amdgcn_rcpf(nrm.x) + 2e-5f * ((fabsf(az.x) + fabsf(bz.x)) + fabsf(cz.x));
                 const float zu1 = zn.y * __builtin_amdgcn_rcpf(nrm.y) + 2e-5f * ((fabsf(az.y) + fabsf(bz.y)) + fabsf(cz.y));
                 const bool near0 = !(zu0 == zu0) || depth_ord(zu0) >= kh0, near1 = !(zu1 == zu1) || depth_ord(zu1) >= kh1;   // (NaN: stays in)
+#else
+                const bool near0 = zb0 >= kh0, near1 = zb1 >= kh1;
+#endif
                 pass0 = v0 && !rej0 && near0; pass1 = v1 && !rej1 && near1;
             }
             const uint64_t b0 = __ballot(pass0), b1 = __ballot(pass1);
@@ -276,6 +300,71 @@ __device__ inline void soft_pair(const RasterArgs& a, const TileCtx& t, Stage* s
             const unsigned lo = (unsigned)((x - hi) * 4294967296.f);
             atomicAdd((unsigned long long*)&acc->logsum[l], ((unsigned long long)(long long)(int)hi << 32) + lo);
         }
+    }
+}
+
+// K3 for all (pixel, candidate) pairs of a flush, two per lane in packed fp32: the segment distances of soft_factor / seg_dist2_fast step
+// by step on both halves at once (v_pk_add / v_pk_mul are the same IEEE operations as their scalar forms, the reciprocal, exp2 and log2
+// are issued per half): q is BIT-IDENTICAL to soft_factor's, which the backward divides the stored product by.
+// sm: this lane's pixel, bit j = queued candidate j it takes.
+__device__ inline mm_f2 seg_dist2_pk(mm_f2 px, mm_f2 py, mm_f2 ux, mm_f2 uy, mm_f2 vx, mm_f2 vy) {
+#pragma clang fp contract(off)
+    const mm_f2 ex = vx - ux, ey = vy - uy, rx = px - ux, ry = py - uy;
+    const mm_f2 len2 = ex * ex + ey * ey;
+    const mm_f2 dot = rx * ex + ry * ey;
+    mm_f2 tt;
+    tt.x = (len2.x > 0.f) ? dot.x * __builtin_amdgcn_rcpf(len2.x) : 0.f;
+    tt.y = (len2.y > 0.f) ? dot.y * __builtin_amdgcn_rcpf(len2.y) : 0.f;
+    tt.x = fminf(fmaxf(tt.x, 0.f), 1.f); tt.y = fminf(fmaxf(tt.y, 0.f), 1.f);
+    const mm_f2 qx = rx - tt * ex, qy = ry - tt * ey;
+    return qx * qx + qy * qy;
+}
+template <class Stage>
+__device__ inline void soft_pairs(const RasterArgs& a, const TileCtx& t, Stage* st, uint64_t sm, float sig2) {
+    int total;
+    int k = wave_prefix_excl(__popcll(sm), t.lane, total);      // index of this lane's next unwritten pair
+    uint64_t rem = sm;
+    for (int base = 0; base < total; base += MM_PAIR_ROUND) {
+        const int lim = min(MM_PAIR_ROUND, total - base);
+        while (rem && k < base + lim) {                          // every set bit is visited exactly once overall
+            const int j = __ffsll((unsigned long long)rem) - 1;
+            rem &= rem - 1;
+            st->pairs[k - base] = (unsigned short)((j << 8) | t.lane);   // (candidate << 8) | pixel
+            ++k;
+        }
+        wave_lds_sync();
+        for (int q0 = 0; q0 < lim; q0 += 128) {
+            const bool v0 = q0 + t.lane < lim, v1 = q0 + 64 + t.lane < lim;
+            const unsigned e0 = st->pairs[v0 ? q0 + t.lane : 0], e1 = st->pairs[v1 ? q0 + 64 + t.lane : 0];
+            const int j0 = (int)(e0 >> 8), j1 = (int)(e1 >> 8), l0 = (int)(e0 & 63u), l1 = (int)(e1 & 63u);
+            const float4 A0 = st->p0[j0], B0 = st->p1[j0], A1 = st->p0[j1], B1 = st->p1[j1];
+            float q[2];
+            {
+#pragma clang fp contract(off)
+                const mm_f2 x0 = {a.kx * (t.xf0 + (float)(2 * (l0 & 7))), a.kx * (t.xf0 + (float)(2 * (l1 & 7)))};
+                const mm_f2 y0 = {a.ky * (t.yf0 - (float)(2 * (l0 >> 3))), a.ky * (t.yf0 - (float)(2 * (l1 >> 3)))};
+                const mm_f2 ax = {A0.x, A1.x}, ay = {A0.y, A1.y}, bx = {A0.z, A1.z}, by = {A0.w, A1.w}, cx = {B0.x, B1.x}, cy = {B0.y, B1.y};
+                const mm_f2 d0 = seg_dist2_pk(x0, y0, ax, ay, bx, by), d1 = seg_dist2_pk(x0, y0, bx, by, cx, cy), d2 = seg_dist2_pk(x0, y0, cx, cy, ax, ay);
+                const float dx = fminf(fminf(d0.x, d1.x), d2.x), dy = fminf(fminf(d0.y, d1.y), d2.y);
+                q[0] = 1.f - __builtin_amdgcn_exp2f(-(dx * sig2) * 1.4426950408889634f);
+                q[1] = 1.f - __builtin_amdgcn_exp2f(-(dy * sig2) * 1.4426950408889634f);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool live = u ? v1 : v0;
+                const int l = u ? l1 : l0;
+                if (live) {
+                    if (q[u] == 0.f) atomicAdd(&st->zeros[l], 1);
+                    else {                                       // log2(q) in 2^-32 fixed point: floor part and 32 fraction bits
+                        const float x = __builtin_amdgcn_logf(q[u]);
+                        const float hi = floorf(x);
+                        const unsigned lo = (unsigned)((x - hi) * 4294967296.f);
+                        atomicAdd((unsigned long long*)&st->logsum[l], ((unsigned long long)(long long)(int)hi << 32) + lo);
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
     }
 }
 
@@ -411,6 +500,9 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
     if (t.in_img) {
         *(float4*)(a.rgba + pix * 4) = make_float4(out[0], out[1], out[2], out[3]);
         a.face_idx[pix] = h.f;
+#ifndef MM_NO_OWN_FLAG
+        if (h.f >= 0 && a.fflag) a.fflag[(size_t)t.b * a.F + h.f] = 1;     // (idempotent plain store: the backward sweeps this face)
+#endif
         a.soft[pix] = make_float2((h.f >= 0 || ss.zeros >= 2) ? 0.f : (ss.zeros == 1 ? -ss.qnz : ss.qnz), __int_as_float(ss.lastf));
         if (a.imnormal) { a.imnormal[pix * 3] = nx; a.imnormal[pix * 3 + 1] = ny; a.imnormal[pix * 3 + 2] = nz; }
     }
@@ -516,9 +608,23 @@ inline bool walk_block_mode(const RasterArgs& a) {
     if (a.options & MM_OPT_WALK_WAVE) return false;
     return a.bin_shift == 3 || a.order == nullptr;               // 8-pixel bins, or no tile sort (a screen beyond MM_ORDER_MAX_SLOTS tiles)
 }
+// Sorted launch order: workgroup i -> (image, rank j of the workgroup inside the image).  The dispatcher deals consecutive workgroups to
+// the eight XCDs in turn (observed).  `i % B` keeps an image on one XCD (B a multiple of 8): its face records and bin masks are read
+// through one L2 -- right for small screens (128x128: raster_fwd 37.2 us against 39.3).  But an image's weight varies several-fold with
+// its camera distance, and with many tiles per image the launch then lasts as long as the XCD that drew the heaviest images while the
+// others idle (13 776 faces at 512x512: half of all wave slots empty over the second half of the launch).  With RasterArgs::spread
+// eight consecutive workgroups are eight consecutive ranks of the SAME image instead: every XCD takes an eighth of every image, heavy
+// tiles first everywhere (512x512: 361 -> 261 us; 256x256: 105 -> 96).
+__device__ inline void walk_image_rank(int i, int B, bool spread, int& b, int& j) {
+    if (spread) { const int g = i >> 3; b = g % B; j = (g / B) * 8 + (i & 7); }
+    else { b = i % B; j = i / B; }
+}
+inline bool walk_queue_mode(const RasterArgs& a) { return a.bin_shift != 3; }
+inline bool walk_spread(const RasterArgs& a) { return a.order != nullptr && 4 * a.blocks_per_image >= 1024; }
 inline unsigned walk_grid(const RasterArgs& a, bool block) {
-    if (!block) return (unsigned)a.B * (unsigned)a.blocks_per_image * 4u;
-    return a.order ? (unsigned)a.B * (unsigned)(MM_HEAVY_MAX + (4 * a.blocks_per_image + 3) / 4) : (unsigned)a.B * (unsigned)a.blocks_per_image;
+    if (!a.order) return (unsigned)a.B * (unsigned)a.blocks_per_image * (block ? 1u : 4u);
+    const unsigned per_image = block ? (unsigned)(MM_HEAVY_MAX + (4 * a.blocks_per_image + 3) / 4) : (unsigned)a.blocks_per_image * 4u;
+    return (unsigned)a.B * ((per_image + 7u) & ~7u);             // (ranks beyond an image's last workgroup exit at once)
 }
 
 }  // namespace mm

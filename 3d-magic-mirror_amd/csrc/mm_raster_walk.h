@@ -22,12 +22,48 @@ struct __attribute__((aligned(16))) WaveStage {
     unsigned long long key[64];             // per pixel: best (orderable z << 32 | ~face) so far; 0 = none
     long long logsum[64];                   // per pixel: sum of log2(1-p) in 2^-32 fixed point (integer adds commute)
     int zeros[64];                          // per pixel: number of factors (1-p) that are exactly 0
+    unsigned long long takenw[64];          // faces of the current chunk of 4096 that some pixel took into its silhouette product: bit b of word w = face
+                                            // chunk * 4096 + w * 64 + b (LDS ors; written to RasterArgs::fflag when the chunk has been walked)
     int npair[4];                           // cooperative walk: this wave's colour / silhouette pair counts of the round
 };
 static_assert(sizeof(WaveStage) <= 8192, "four of them must fit 32 KiB: five workgroups per CU");
 // cooperative walk: per pixel, inflated-box hits of this wave's batch of the current round / id of the knum-th silhouette face taken
 __device__ inline int* coop_cnt(WaveStage* st) { return reinterpret_cast<int*>(&st->qm[0][0]); }
 __device__ inline int* coop_lastf(WaveStage* st) { return reinterpret_cast<int*>(&st->qm[1][0]); }
+
+// The candidates some pixel of the tile has just taken into its silhouette product (sm: this lane's pixel, bit j = staged candidate j):
+// their faces are flagged for the backward's sweep.  NOT with a store on the spot: vector-memory operations retire in order, so a store
+// issued in the middle of the walk holds up the candidate records fetched behind it for a full trip to memory (measured: +3 us at 128x128,
+// +8 us at 256x256 for one store per flush).  The faces are noted in an LDS bitmap over the current chunk of 4096 faces instead and
+// written out once the chunk has been walked (flush_taken) -- for meshes of up to 4096 faces that is after the tile's last fetch.
+// cbase: first mask word of the chunk being walked; a queued candidate of an EARLIER chunk (carried over a chunk border) is stored directly.
+__device__ inline void mark_taken(const RasterArgs& a, const TileCtx& t, const WaveStage* st, WaveStage* acc, uint64_t ms, uint64_t openm, int cbase) {
+    // ms: THIS LANE'S CANDIDATE, bit p = pixel p lies in its inflated box; openm: the pixels that are uncovered and still taking faces.
+    // (A superset of the faces actually taken -- a pixel's "first knum" cut may leave this one out -- which costs the backward a sweep
+    //  item now and then, and this walk no cross-lane reduction.)
+    if (!a.fflag || !(ms & openm)) return;
+    const int f = __float_as_int(st->p2[t.lane].z), rel = f - cbase * 64;
+    if (rel >= 0) atomicOr(&acc->takenw[rel >> 6], 1ull << (rel & 63));
+    else a.fflag[(size_t)t.b * a.F + f] = 1;
+}
+// lane = word of the chunk: one idempotent store per noted face, then the word is cleared for the next chunk
+__device__ inline void flush_taken(const RasterArgs& a, const TileCtx& t, WaveStage* acc, int cbase) {
+    if (!a.fflag) return;
+    unsigned long long w = acc->takenw[t.lane];
+    acc->takenw[t.lane] = 0ull;
+    while (w) {
+        const int bit = __ffsll(w) - 1;
+        w &= w - 1;
+        a.fflag[(size_t)t.b * a.F + (size_t)(cbase + t.lane) * 64 + bit] = 1;
+    }
+}
+
+// the last chunk's noted faces, after the tile's epilogue (behind every load of the wave: nothing waits for these stores)
+__device__ inline void flush_taken_last(const RasterArgs& a, const TileCtx& t, WaveStage* acc) {
+    if (!a.fflag || t.empty) return;
+    wave_lds_sync();
+    flush_taken(a, t, acc, ((a.words - 1) / 64) * 64);
+}
 
 // Work of a 256-thread workgroup: FOUR tiles, one per wave (nothing shared), or ONE heavy tile walked by its four waves together
 // (tile_walk_coop).  With the plan kernel's order (tiles of an image by decreasing candidate count, the first nheavy of them heavy):
@@ -38,15 +74,19 @@ __device__ inline int* coop_lastf(WaveStage* st) { return reinterpret_cast<int*>
 //   kBlock = false: the one-wave workgroup variant of the same kernels (one tile per workgroup, never cooperative): a slow tile
 //   then never pins the LDS and the wave slots of finished neighbours -- better where tiles are many and none is heavy.
 //   limit: tiles [0, limit) of the order are walked by this mapping (the fused kernel shades the empty ones behind them four per wave)
+//   rank: the workgroup's index among its image's walking workgroups if the caller has worked it out (the fused kernel interleaves them
+//   with the workgroups that shade empty tiles), -1: straight from blockIdx
 template <bool kBlock>
-__device__ inline TileCtx make_tile(const RasterArgs& a, int wv, bool& valid, bool& coop, int limit) {
+__device__ inline TileCtx make_tile(const RasterArgs& a, int wv, int rank, bool& valid, bool& coop, int limit) {
     TileCtx t;
     int blk;
     valid = true; coop = false;
     if (a.order) {
         const int nslot = 4 * a.blocks_per_image;
-        t.b = blockIdx.x % a.B;
-        const int j = blockIdx.x / a.B, nh = kBlock ? a.nheavy[2 * t.b] : 0;
+        int j;
+        walk_image_rank((int)blockIdx.x, a.B, a.spread != 0, t.b, j);
+        if (rank >= 0) j = rank;
+        const int nh = kBlock ? a.nheavy[2 * t.b] : 0;
         int idx;
         if (!kBlock) idx = j;
         else if (j < nh) { idx = j; coop = true; }
@@ -138,13 +178,14 @@ __device__ inline void stage_slot(WaveStage* st, int slot, int f, const float4& 
 // hits per batch) costs a tenth of what it did when every batch was staged, transposed and paired.
 //   want_soft(): wave-uniform, asked once per raw batch: can any pixel still take a silhouette face?  (Monotone: once false, always false.)
 template <class WantSoft, class Flush>
-__device__ inline void scan_candidates(const RasterArgs& a, const TileCtx& t, WaveStage* st, const unsigned& zfloor, WantSoft&& want_soft, Flush&& flush MM_PP_ARG) {
+__device__ inline void scan_candidates(const RasterArgs& a, const TileCtx& t, WaveStage* st, const unsigned& zfloor, int& cur_cbase, WantSoft&& want_soft, Flush&& flush MM_PP_ARG) {
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
     const int bmode = box_mode(a.options);
     int qn = 0;                                                  // candidates waiting in the queue (wave-uniform)
     uint64_t next_word = idw_load(a, t, 0);
     for (int cbase = 0; cbase < a.words; cbase += 64) {
       IdWindows iw;
+      cur_cbase = cbase;
       idw_begin(iw, a, t, next_word);
       if (cbase + 64 < a.words) next_word = idw_load(a, t, cbase + 64);   // the next chunk's mask words travel while this chunk is walked (a mesh of
                                                                           // 13 776 faces has four chunks: three dependent trips to memory less per tile)
@@ -201,6 +242,8 @@ __device__ inline void scan_candidates(const RasterArgs& a, const TileCtx& t, Wa
             qn += ns;
         }
       }
+      wave_lds_sync();
+      if (cbase + 64 < a.words) flush_taken(a, t, st, cbase);    // (the LAST chunk's faces are written by the kernel after its own last load: flush_taken_last)
     }
 }
 
@@ -231,13 +274,13 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
     key = 0ull;
     ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
     if (t.empty) return;                                         // wave-uniform: more than half of all tiles are empty
-    st->key[t.lane] = 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0;
+    st->key[t.lane] = 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0; st->takenw[t.lane] = 0ull;
     wave_lds_sync();
     const float s2 = a.sigmainv / (a.mult * a.mult);
-    int cnt = 0, lastf = 0x7FFFFFFF;
+    int cnt = 0, lastf = 0x7FFFFFFF, cbase = 0;
     bool open = t.in_img;
     unsigned zfloor = 0;                                         // smallest depth_ord held by an in-image pixel of the tile (wave-uniform; 0: some pixel holds nothing)
-    scan_candidates(a, t, st, zfloor, [&]() { return __ballot(open && cnt < a.knum) != 0; }, [&](int n) {
+    scan_candidates(a, t, st, zfloor, cbase, [&]() { return __ballot(open && cnt < a.knum) != 0; }, [&](int n) {
         wave_lds_sync();                                         // the queue's stores
         const uint64_t mh = t.lane < n ? st->qm[0][t.lane] : 0ull, ms = t.lane < n ? st->qm[1][t.lane] : 0ull;
 #ifdef MM_PHASE_PROF
@@ -254,12 +297,14 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
             zfloor = wave_min_u32(t.in_img ? (unsigned)(kk >> 32) : 0xFFFFFFFFu);
             MM_PP_MARK(3);
         }
-        if (__ballot(ms != 0) && __ballot(open && cnt < a.knum)) {
+        const uint64_t openm = __ballot(open && cnt < a.knum);
+        if (__ballot(ms != 0) && openm) {
+            mark_taken(a, t, st, st, ms, openm, cbase);
             const uint64_t ps = wave_transpose64(ms, t.lane);    // pixel-major: this lane's pixel, bit j = queued candidate j
             const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
             cnt += __popcll(sm);
             if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);   // knum-th face taken
-            if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, st, s2, l, j, live); });
+            if (__ballot(sm != 0)) soft_pairs(a, t, st, sm, s2);
 #ifdef MM_PHASE_PROF
             { int ts; (void)wave_prefix_excl(__popcll(sm), t.lane, ts); MM_PP_COUNT(0, (unsigned long long)ts << 32); }   // silhouette pairs
 #endif
@@ -267,6 +312,81 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
         }
         wave_lds_sync();                                         // the queue is free again
     } MM_PP_PASS);
+    wave_lds_sync();
+    key = st->key[t.lane];
+    ss.zeros = st->zeros[t.lane];
+    ss.qnz = exp2f((float)((double)st->logsum[t.lane] * (1.0 / 4294967296.0)));
+    ss.lastf = lastf;
+}
+
+// The PER-BATCH walk, for 8-pixel screen bins (the bin IS the tile: nearly every candidate of the bin touches the tile, so there is nothing
+// to compact, and with a few dozen candidates per tile the launch lasts as long as one tile's chain of dependent steps -- the queue, the
+// filter pass and the face flags of tile_walk only lengthen it: 128x128 with 1 280 faces, raster_fwd 32.5 us against 40).  Every batch of 64
+// candidates is staged, box-tested, transposed to the per-pixel view and its pairs evaluated at once; same results bit for bit.
+__device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, WaveStage* st, unsigned long long& key, SoftState& ss MM_PP_ARG) {
+    key = 0ull;
+    ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
+    if (t.empty) return;                                         // wave-uniform: more than half of all tiles are empty
+    st->key[t.lane] = 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0;
+    wave_lds_sync();
+    const float s2 = a.sigmainv / (a.mult * a.mult);
+    const float4* geo = a.geo + (size_t)t.b * a.F * 3;
+    const int bmode = box_mode(a.options);
+    int cnt = 0, lastf = 0x7FFFFFFF;
+    bool open = t.in_img;
+    unsigned zfloor = 0;
+    uint64_t next_word = idw_load(a, t, 0);
+    for (int cbase = 0; cbase < a.words; cbase += 64) {
+      IdWindows iw;
+      idw_begin(iw, a, t, next_word);
+      if (cbase + 64 < a.words) next_word = idw_load(a, t, cbase + 64);
+      for (int total = idw_next(iw, t, st); total != 0; total = idw_next(iw, t, st)) {
+        const int wbase = cbase;
+        wave_lds_sync();
+        MM_PP_MARK(1);
+        MM_PP_COUNT(total, 0);
+        // the face records of batch k+1 are requested before batch k is evaluated
+        float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+        int nf = 0;
+        auto fetch = [&](int k0) {
+            if (k0 + t.lane < total) {
+                nf = wbase * 64 + st->ids[k0 + t.lane];
+                n0 = geo[(size_t)nf * 3 + 0]; n1 = geo[(size_t)nf * 3 + 1]; n2 = geo[(size_t)nf * 3 + 2];
+            }
+        };
+        fetch(0);
+        for (int k0 = 0; k0 < total; k0 += 64) {
+            const int n = min(64, total - k0);
+            const float4 g0 = n0, g1 = n1, g2 = n2;
+            const int f = nf;
+            if (k0 + 64 < total) fetch(k0 + 64);
+            const bool soft = __ballot(open && cnt < a.knum) != 0;
+            uint64_t mh = 0, ms = 0;                             // candidate-major: lane j = candidate j, bit p = pixel p
+            if (t.lane < n) {
+                unsigned zb;
+                candidate_masks(a, t, g0, g1, g2, soft, bmode, zfloor, mh, ms, zb);
+                stage_slot(st, t.lane, f, g0, g1, g2, zb);
+            }
+            const uint64_t ph = __ballot(mh != 0) ? wave_transpose64(mh, t.lane) : 0ull;
+            const uint64_t ps = __ballot(ms != 0) ? wave_transpose64(ms, t.lane) : 0ull;
+            wave_lds_sync();
+            MM_PP_MARK(2);
+            if (__ballot(ph != 0)) {
+                pair_parallel(t, st, ph, [&](int l, int j, bool live) { hard_pair(a, t, st, st, j, l, live); });   // pixel l, candidate j
+                const unsigned long long kk = st->key[t.lane];
+                open = t.in_img && kk == 0ull;
+                zfloor = wave_min_u32(t.in_img ? (unsigned)(kk >> 32) : 0xFFFFFFFFu);
+                MM_PP_MARK(3);
+            }
+            const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
+            cnt += __popcll(sm);
+            if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);   // knum-th face taken
+            if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, st, s2, l, j, live); });
+            MM_PP_MARK(4);
+            wave_lds_sync();
+        }
+      }
+    }
     wave_lds_sync();
     key = st->key[t.lane];
     ss.zeros = st->zeros[t.lane];
@@ -289,7 +409,7 @@ __device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, Wav
     WaveStage* acc = &stage[0];
     key = 0ull;
     ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
-    if (wv == 0) { acc->key[t.lane] = 0ull; acc->logsum[t.lane] = 0ll; acc->zeros[t.lane] = 0; coop_lastf(acc)[t.lane] = 0x7FFFFFFF; }
+    if (wv == 0) { acc->key[t.lane] = 0ull; acc->logsum[t.lane] = 0ll; acc->zeros[t.lane] = 0; acc->takenw[t.lane] = 0ull; coop_lastf(acc)[t.lane] = 0x7FFFFFFF; }
     const int bmode = box_mode(a.options);
     __syncthreads();
     const float s2 = a.sigmainv / (a.mult * a.mult);
@@ -318,6 +438,7 @@ __device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, Wav
             }
             const uint64_t ph = __ballot(mh != 0) ? wave_transpose64(mh, t.lane) : 0ull;
             const uint64_t ps = __ballot(ms != 0) ? wave_transpose64(ms, t.lane) : 0ull;
+            mark_taken(a, t, st, acc, ms, __ballot(open && base_cnt < a.knum), cbase);
             coop_cnt(st)[t.lane] = __popcll(ps);
             MM_PP_MARK(2);
             __syncthreads();
@@ -376,6 +497,11 @@ __device__ inline void tile_walk_coop(const RasterArgs& a, const TileCtx& t, Wav
             }
             open = t.in_img && acc->key[t.lane] == 0ull;
         }
+      }
+      if (cbase + 64 < a.words) {                                // (the last chunk's faces: flush_taken_last, by the wave that shades the tile)
+          __syncthreads();                                       // the chunk's silhouette faces are all noted
+          if (wv == 0) flush_taken(a, t, acc, cbase);
+          __syncthreads();
       }
     }
     __syncthreads();

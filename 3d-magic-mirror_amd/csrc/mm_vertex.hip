@@ -28,6 +28,7 @@ struct VertexFwdArgs {
     long long* ltot; int nltot;   // fused-loss sums of the raster waves: cleared here
     int bin_shift, nbx, nby, words;
     uint64_t* mask;          // (B,nbins,words) screen-bin candidate mask, written here (nullptr: not wanted)
+    int* fflag;              // (B,F) "this face receives gradient from the pixels": cleared here, set by raster_fwd
 };
 
 __device__ inline void block_camera(const float* azim, const float* elev, const float* dist, const float* bias, int b,
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     face_pixel_box(ax, ay, bx, by, cx, cy, a.infl, a.mult, a.W, a.H, bx0, by0, bw, bh, org, ext);
     a.geo[o * 3 + 2] = make_float4(C.z, nz, __uint_as_float(org), __uint_as_float(ext));
     a.face_normals[o * 3 + 0] = nx; a.face_normals[o * 3 + 1] = ny; a.face_normals[o * 3 + 2] = nz;
+    a.fflag[o] = 0;
     }
 
     // ---- screen binning: this wave's 64 faces are exactly mask word c (bin_wave_faces, mm_device.h) ---------------------------
@@ -322,7 +324,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.tcnt = w.tcnt; a.ntcnt = d->B * w.ntiles + d->B + d->B * MM_GSHARD * 8;
     a.ltot = w.ltot; a.nltot = d->B * MM_LSUB * 4;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
-    a.mask = w.binmask;
+    a.mask = w.binmask; a.fflag = w.fflag;
     dim3 grid((d->F + 255) / 256, d->B);
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
       hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }

@@ -20,7 +20,7 @@ c_p = ctypes.c_void_p
 class MMRenderDesc(ctypes.Structure):
     _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("V", c_i), ("F", c_i), ("Ht", c_i), ("Wt", c_i), ("no_mask", c_i),
                 ("knum", c_i), ("proj", c_f * 3), ("sigmainv", c_f), ("boxlen", c_f), ("multiplier", c_f), ("eps", c_f),
-                ("faces", c_p), ("face_uvs", c_p), ("vc_offsets", c_p), ("vc_items", c_p),
+                ("faces", c_p), ("face_uvs", c_p), ("vc_table", c_p), ("vc_stride", c_i),
                 ("vertices", c_p), ("textures", c_p), ("lights", c_p), ("bg", c_p), ("azimuths", c_p), ("elevations", c_p),
                 ("distances", c_p), ("biases", c_p),
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
@@ -117,14 +117,14 @@ class MMMaskIouDesc(ctypes.Structure):
 
 
 PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "order")
-ABI_VERSION = 2
+ABI_VERSION = 3
 OPT_WALK_BLOCK, OPT_WALK_WAVE = 1 << 1, 1 << 2
 OPT_CULL_STRICT, OPT_SOFT_SKIP_CULLED, OPT_BBOX_HALF_OPEN, OPT_BARY_ONE_MINUS, OPT_SH_ORDER_XYZ = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_render_fused_loss", "mm_debug_workspace_layout", "mm_recon_query_workspace",
-           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_nearest_neighbour", "mm_status_string", "mm_last_error_detail",
+           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_vertex_corner_table", "mm_nearest_neighbour", "mm_status_string", "mm_last_error_detail",
            "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward", "mm_texture_flow_forward",
            "mm_texture_flow_backward", "mm_attribute_loss_query_workspace", "mm_attribute_loss_forward",
            "mm_attribute_loss_backward",

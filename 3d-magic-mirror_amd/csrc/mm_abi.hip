@@ -1,6 +1,7 @@
 // mm_abi.hip -- extern "C" entry points of libmm_render.so (declared in include/mm_render.h): argument validation,
 // workspace carving and launch sequencing.  No allocation, no host synchronisation, no global state.
 #include <cstdio>
+#include <cstdlib>
 #include "mm_device.h"
 
 namespace mm {
@@ -33,7 +34,8 @@ static int check_render(const MMRenderDesc* d, bool backward) {
         return MM_ERR_NULL_POINTER;
     if (!backward && !d->rgba) return MM_ERR_NULL_POINTER;                        // (the backward never reads the image: rgba may be NULL there)
     if (d->no_mask && !d->bg) return MM_ERR_NULL_POINTER;
-    if (backward && (!d->vc_offsets || !d->vc_items)) return MM_ERR_NULL_POINTER;
+    if (backward && !d->vc_table) return MM_ERR_NULL_POINTER;
+    if (backward && d->vc_stride <= 0) return MM_ERR_BAD_SHAPE;
     if (!d->workspace || d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_WORKSPACE;
     return MM_OK;
 }
@@ -238,6 +240,29 @@ int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces, int32
     for (int i = 0; i < 3 * F; ++i) items[offsets[faces[i]]++] = i;
     for (int v = V; v > 0; --v) offsets[v] = offsets[v - 1];
     offsets[0] = 0;
+    return MM_OK;
+}
+
+int mm_build_vertex_corner_table(int32_t V, int32_t F, const int32_t* faces, int32_t stride, int32_t* table) {
+    if (!faces) return MM_ERR_NULL_POINTER;
+    if (V <= 0 || F <= 0) return MM_ERR_BAD_SHAPE;
+    int32_t* cnt = (int32_t*)calloc((size_t)V, sizeof(int32_t));                 // (a host helper: the GPU path never allocates)
+    if (!cnt) return MM_ERR_WORKSPACE;
+    int32_t valence = 0;
+    for (int i = 0; i < 3 * F; ++i) {
+        if (faces[i] < 0 || faces[i] >= V) { free(cnt); return MM_ERR_BAD_SHAPE; }
+        if (++cnt[faces[i]] > valence) valence = cnt[faces[i]];
+    }
+    if (!table) { free(cnt); return valence; }
+    if (stride < valence) { free(cnt); return MM_ERR_BAD_SHAPE; }
+    for (size_t i = 0; i < (size_t)V * stride * 4; ++i) table[i] = -1;
+    for (int v = 0; v < V; ++v) cnt[v] = 0;
+    for (int i = 0; i < 3 * F; ++i) {                             // corners visited ascending: every vertex's list is ascending
+        const int v = faces[i], f = i / 3;
+        int32_t* e = table + ((size_t)v * stride + cnt[v]++) * 4;
+        e[0] = i; e[1] = faces[f * 3]; e[2] = faces[f * 3 + 1]; e[3] = faces[f * 3 + 2];
+    }
+    free(cnt);
     return MM_OK;
 }
 

@@ -110,9 +110,8 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
 struct VertexBwdArgs {
     int B, V, F;
     float proj0, proj1, proj2;
-    const int32_t* faces;
-    const int32_t* vc_offsets;
-    const int32_t* vc_items;
+    const int4* vc_table;   // (V,vc_stride) {face*3 + corner, the face's three vertex ids}, padded with -1
+    int vc_stride;
     const float* vertices;
     const float *azim, *elev, *dist, *bias;
     const float* T;         // (B,12) saved by the forward
@@ -161,18 +160,21 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         const float ipz = 1.f / pz;                               // one division per vertex, not three per corner
         const float xi = (me.x * a.proj0) * ipz, yi = (me.y * a.proj1) * ipz;
         float d[3] = {0.f, 0.f, 0.f};
-        const int beg = a.vc_offsets[v], end = a.vc_offsets[v + 1];
         MM_PP_MARK(0);
-        for (int it = beg + cl; it < end; it += 8) {
-            const int item = a.vc_items[it];
+        // The vertex's corners from the fixed-stride table: its address depends on nothing but the vertex, so it travels with T and the
+        // vertex itself, and the entry carries the face's three vertex ids -- the CSR (offsets -> items -> faces) was two trips more.
+        for (int sl8 = cl; sl8 < a.vc_stride; sl8 += 8) {
+            const int4 ent = a.vc_table[(size_t)v * a.vc_stride + sl8];
+            if (ent.x < 0) break;                                 // padding: this vertex has no further corner
+            const int item = ent.x;
             const int f = item / 3, k = item - f * 3;
             const size_t o = (size_t)b * a.F + f;
             // the face's gradients = its sweep items' partial sums, added in index order (one item for most faces)
             float gx = 0.f, gy = 0.f, g[3] = {0.f, 0.f, 0.f};
             const int2 cm = a.chunkmap[o];
-            // the face's corners (static connectivity) ride along with chunkmap, its three vertices with the partial sums: loaded whether or
-            // not the normal gradient below turns out to be zero -- inside that branch they would cost two more dependent trips to memory
-            const int i0 = a.faces[f * 3], i1 = a.faces[f * 3 + 1], i2 = a.faces[f * 3 + 2];
+            // the face's three vertices ride along with chunkmap: loaded whether or not the normal gradient below turns out to be zero
+            // -- inside that branch they would cost a dependent trip to memory of their own
+            const int i0 = ent.y, i1 = ent.z, i2 = ent.w;
             float pa[3], pb[3], pc[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
@@ -335,7 +337,7 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     VertexBwdArgs a;
     a.B = d->B; a.V = d->V; a.F = d->F;
     a.proj0 = d->proj[0]; a.proj1 = d->proj[1]; a.proj2 = d->proj[2];
-    a.faces = d->faces; a.vc_offsets = d->vc_offsets; a.vc_items = d->vc_items; a.vertices = d->vertices;
+    a.vc_table = (const int4*)d->vc_table; a.vc_stride = d->vc_stride; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.cam = w.cam; a.chunkmap = w.chunkmap; a.part = w.part; a.item_cap = w.item_cap; a.gfn = g->grad_face_normals;
     a.dTpart = w.dTpart; a.ticket = w.ticket;

@@ -222,7 +222,7 @@ class DiffRender(object):
         if torch.cuda.is_available():
             self.sign_init = self.sign_init.cuda()
         self.render_height = round(self.ratio * self.image_size)                                  # :298
-        self._vc_offsets, self._vc_items = template.vertex_corner_adjacency(self.num_vertices, self.faces)
+        self._vc_table = template.vertex_corner_table(self.num_vertices, self.faces)     # (V, stride, 4): the backward's vertex -> corner gather
         self._static_cache = {}
         self._desc_cache = {}
         self._ws_pool = {}                                       # (device, bytes) -> free render workspaces (see _PooledWorkspace)
@@ -240,8 +240,7 @@ class DiffRender(object):
         if st is None:
             st = {"faces": self.faces.to(device=device, dtype=torch.int32).contiguous(),
                   "face_uvs": self.face_uvs.to(device=device, dtype=torch.float32).reshape(-1, 3, 2).contiguous(),
-                  "vc_offsets": self._vc_offsets.to(device=device, dtype=torch.int32).contiguous(),
-                  "vc_items": self._vc_items.to(device=device, dtype=torch.int32).contiguous()}
+                  "vc_table": self._vc_table.to(device=device, dtype=torch.int32).contiguous()}
             self._static_cache[key] = st
         return st
 
@@ -275,7 +274,7 @@ class DiffRender(object):
                 d.proj[i] = float(self.cam_proj[i, 0])
             d.sigmainv, d.boxlen, d.multiplier, d.eps = self.sigmainv, self.boxlen, self.multiplier, self.eps
             d.faces, d.face_uvs = N.ptr(st["faces"]), N.ptr(st["face_uvs"])
-            d.vc_offsets, d.vc_items = N.ptr(st["vc_offsets"]), N.ptr(st["vc_items"])
+            d.vc_table, d.vc_stride = N.ptr(st["vc_table"]), int(st["vc_table"].shape[1])
             d.options = self.options
             hit = (bytes(d), N.lib().mm_query_workspace(ctypes.byref(d)))
             if len(self._desc_cache) > 32:
@@ -298,7 +297,7 @@ class DiffRender(object):
                 proto.proj[i] = float(self.cam_proj[i, 0])
             proto.sigmainv, proto.boxlen, proto.multiplier, proto.eps = self.sigmainv, self.boxlen, self.multiplier, self.eps
             proto.faces, proto.face_uvs = N.ptr(st["faces"]), N.ptr(st["face_uvs"])
-            proto.vc_offsets, proto.vc_items = N.ptr(st["vc_offsets"]), N.ptr(st["vc_items"])
+            proto.vc_table, proto.vc_stride = N.ptr(st["vc_table"]), int(st["vc_table"].shape[1])
             proto.options = self.options
             if len(self._desc_cache) > 32:
                 self._desc_cache.clear()
@@ -340,6 +339,15 @@ class DiffRender(object):
         attributes['imnormal'] = imn if self.emit_imnormal else None
         self.last_face_idx = face_idx
         return loss, rgba.permute(0, 3, 1, 2), attributes
+
+    def graphed_step(self, example_attributes, gt_data, no_mask=False):
+        """A captured (HIP-graph) render + recon_data + backward for attribute tensors of the example's shapes: returns a callable
+        ``g(gt_data, **attributes) -> (loss, rgbs, attributes)`` with the semantics of ``render_recon`` whose forward and backward are one
+        graph launch each (step.GraphedRenderRecon: static input slots ``g.inputs`` / ``g.gt``, static outputs).  The call sites it
+        serves: trainer.py:276 (render), :441 (recon_data), :509-518 (backward)."""
+        from .step import GraphedRenderRecon
+        N.require_device(*[v for k, v in example_attributes.items() if torch.is_tensor(v)], gt_data)
+        return GraphedRenderRecon(self, example_attributes, gt_data, no_mask=no_mask)
 
     # ---- networks.py:364-390 -------------------------------------------------------------------------------------
     def recon_data(self, pred_data, gt_data, no_mask=False, contour=0):

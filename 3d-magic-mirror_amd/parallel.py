@@ -190,3 +190,60 @@ def broadcast_(tensor, src=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(tensor, src=src)
     return tensor
+
+
+def ddp_step_check(net, forward_loss, device):
+    """One data-parallel step of ``net`` the way a trainer built on this path takes it, checked against its definition:
+      1. this rank's gradient of ``forward_loss(net)`` on its own shard, WITHOUT synchronisation (``no_sync``);
+      2. the same step through ``torch.nn.parallel.DistributedDataParallel`` -- bucketed all-reduce (RCCL over xGMI on GPUs, gloo in the CPU
+         tests) overlapped with the backward;
+    and returns (ddp module, max |DDP gradient - mean over ranks of the local gradients|).  With equal per-rank batches the mean of the per-rank
+    batch-mean gradients IS the global-batch gradient; the reference has nothing to compare with (trainer.py:94-95 is DataParallel)."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    ddp = DDP(net, device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=64, gradient_as_bucket_view=True) if world > 1 else net
+    params = [p for p in net.parameters() if p.requires_grad]
+    for p in params:
+        p.grad = None
+    if world > 1:
+        with ddp.no_sync():
+            forward_loss(ddp).backward()
+    else:
+        forward_loss(ddp).backward()
+    local = [p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p) for p in params]
+    allreduce_mean_(local)                                       # the definition: mean over ranks, through this module's flat buckets
+    for p in params:
+        p.grad = None
+    forward_loss(ddp).backward()                                 # DDP's own bucketed, overlapped reduction
+    err = 0.0
+    for p, ref in zip(params, local):
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        err = max(err, float((g - ref).abs().max()))
+    return ddp, err
+
+
+def ddp_gradient_buffer(dr, B, H, W, device, rank, seed=0):
+    """bench.py, N > 1: the REAL gradient message of a data-parallel trainer on this path.  Builds trainer_step.AttributeNet (two ResNet-18
+    trunks + conv stacks on stock PyTorch: the networks that PRODUCE the render path's attributes), takes one DistributedDataParallel step of
+    it through the render path on this rank's shard (ddp_step_check), and returns (flat fp32 buffer holding its gradient, info dict)."""
+    import importlib
+    ts = importlib.import_module(__package__ + ".trainer_step")
+    syn = importlib.import_module(__package__ + ".synthetic")
+    torch.manual_seed(seed)                                      # identical initial weights on every rank
+    net = ts.AttributeNet(dr.vertices_init, bg=True).to(device)
+    _, gt = syn.synthetic_batch(dr.vertices_init, B, H, W, seed=1000 + rank)     # this rank's shard of the global batch
+    x = gt.to(device)
+
+    def forward_loss(m):
+        att = m(x)
+        loss, _, _ = dr.render_recon(x, no_mask=True, **att)
+        return loss
+
+    ddp, err = ddp_step_check(net, forward_loss, device)
+    flat = torch.cat([p.grad.detach().reshape(-1).float() for p in net.parameters() if p.grad is not None]).contiguous()
+    info = {"module": "trainer_step.AttributeNet", "params": int(sum(p.numel() for p in net.parameters())),
+            "gradient_mb": round(flat.numel() * 4 / 1e6, 1), "ddp_vs_mean_of_local_max_abs_err": err,
+            "bucket_cap_mb": 64, "note": "one DistributedDataParallel step (bucketed all-reduce overlapped with the backward) checked against the mean over "
+                                          "ranks of the unsynchronised local gradients; its gradient buffer is what the timed region keeps reducing"}
+    del ddp
+    return flat, info

@@ -111,6 +111,24 @@ def vertex_corner_adjacency(num_vertices, faces):
     return torch.from_numpy(offsets), torch.from_numpy(order)
 
 
+def vertex_corner_table(num_vertices, faces):
+    """The same adjacency with a fixed stride, as MMRenderDesc.vc_table takes it: (V, stride, 4) int32, entry = [face*3 + corner, the
+    face's three vertex ids], ascending per vertex, padded with -1; stride = the template's largest valence.  One trip to memory
+    gives the vertex-stage backward a vertex's corners AND their faces' vertices (the CSR needs three)."""
+    f = faces.cpu().numpy().astype(np.int64)
+    flat = f.reshape(-1)
+    counts = np.bincount(flat, minlength=num_vertices)
+    stride = int(counts.max())
+    order = np.argsort(flat, kind="stable")
+    starts = np.zeros(num_vertices, dtype=np.int64)
+    starts[1:] = np.cumsum(counts)[:-1]
+    rank = np.arange(flat.size) - starts[flat[order]]
+    table = np.full((num_vertices, stride, 4), -1, dtype=np.int32)
+    table[flat[order], rank, 0] = order
+    table[flat[order], rank, 1:] = f[order // 3]
+    return torch.from_numpy(table)
+
+
 def fuse_template(vertices_init, laplacian, all_vertices, all_delta_vertices, em=1, smooth=0.0, clip=0.05, em_step=1.0,
                   warm_up=1.0, white=False, cross=False, topK=0.5):
     """The reference's template EM update: the statements of /root/reference/trainer.py:1019-1097, which

@@ -9,14 +9,20 @@ backward -> render backward, gradients to vertices, textures, lights, bg, distan
 resident in HBM, and every step does all of that work on a full batch.  Workload at every N: BASELINE config 2 (template
 smpl_uv_642, B=48 per GPU, 128x128, texture 256x128, no_mask).
 
-What the ONE JSON line (rank 0) reports, all on the same workload:
-  value             K steps enqueued round-robin on --streams HIP streams (default 4): successive steps are independent batches
-                    (the reference's trainer issues four renders per iteration, trainer.py:276,345,347,367) and their kernels overlap.
-                    This is the whole-job throughput of the C-ABI path when the caller keeps several batches in flight.
-  value_one_stream  the same K steps strictly one after the other on ONE stream: what a caller gets who renders one batch at a time.
-  value_api_fused   the same step through DiffRender.render_recon (autograd API, loss folded into the render kernels like in `value`)
-  value_api         DiffRender.render -> DiffRender.recon_data -> loss.backward() through the torch.autograd wrappers (the calls
-                    trainer.py makes), one stream, imnormal materialised like the reference does.
+What the ONE JSON line (rank 0) reports, all on the same workload (every timed figure is the MEDIAN of --reps repetitions of --steps
+steps, each repetition bracketed by barrier + synchronize: the driver's short --steps reproduces the long run):
+  value               K steps strictly one after the other on ONE stream, C ABI, recon_data folded into the render kernels, imnormal
+                      materialised as the reference does (networks.py:320): "one B=48 batch at a time", the metric as BASELINE.json words it.
+  value_four_streams  the same steps enqueued round-robin on --streams HIP streams (default 4): successive steps are independent batches
+                      (the reference's trainer issues four renders per iteration, trainer.py:276,345,347,367) and their kernels overlap.
+  value_without_imnormal  `value` without the visualise-only imnormal output.
+  value_api           DiffRender.render -> DiffRender.recon_data -> loss.backward() through the torch.autograd wrappers (the calls
+                      trainer.py makes, :276,441,509-518), one stream.
+  value_api_fused     the same step through DiffRender.render_recon (loss folded into the render kernels).
+  value_api_graphed   the same step through DiffRender.graphed_step: forward and backward one captured HIP graph each behind one autograd node;
+                      _slots: the caller writes its attributes into the graph's static input slots (no copies inside the call).
+  value_shim          the UN-FUSED compatibility path: the kaolin-shaped operators of the import boundary called in the order of the reference's
+                      DiffRender.render (networks.py:278-317; shim_chain.py) + recon_data + backward -- what a maintainer gets who only switches sys.path.
 Every stream rotates through --rotate distinct synthetic batches (default 8 per stream: > 256 MiB of inputs in total, more than
 the Infinity Cache holds), so inputs are not cache-resident from one step to the next.
 N > 1: the batch shards across ranks with no data-path collective (weak scaling); what crosses xGMI in a training step is the
@@ -120,7 +126,11 @@ def main():
     ap.add_argument("--mode", default="eager", choices=["hipgraph", "eager", "torch"],
                     help="what `value` times.  eager: C-ABI calls per step on --streams streams; hipgraph: the step replayed as one HIP "
                          "graph; torch: the DiffRender autograd API (same as value_api)")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps are enqueued on round-robin")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps are enqueued on round-robin (value_four_streams)")
+    ap.add_argument("--reps", type=int, default=9, help="repetitions of the timed region of --steps steps; the MEDIAN is reported")
+    ap.add_argument("--shim-steps", type=int, default=30, help="steps of the un-fused kaolin-shaped operator chain timed for value_shim (0 disables)")
+    ap.add_argument("--ddp-encoder", type=int, default=1, help="N > 1: all-reduce the REAL gradient buffer of trainer_step.AttributeNet (after one "
+                    "DistributedDataParallel step of it, checked) instead of a synthetic buffer of --grad-mb megabytes")
     ap.add_argument("--rotate", type=int, default=8, help="distinct synthetic input batches per stream, visited in turn")
     ap.add_argument("--unfused", action="store_true", help="recon_data as its own three launches instead of folded into the render kernels")
     ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed run-in before the warmup steps (clock ramp)")
@@ -153,7 +163,7 @@ def main():
     par = importlib.import_module("3d-magic-mirror_amd.parallel")
     name, B, S, ratio = CONFIGS[args.config]
     tpath = os.path.join(ROOT, "tests", "golden", "templates", name + ".npz")
-    dr = pkg.DiffRender(tpath, S, ratio=ratio, emit_imnormal=False)
+    dr = pkg.DiffRender(tpath, S, ratio=ratio, emit_imnormal=True)
     H, W = dr.render_height, dr.image_size
     nstreams = max(1, args.streams) if args.mode == "eager" else 1
     nrot = max(1, args.rotate)
@@ -189,14 +199,33 @@ def main():
         torch.cuda.synchronize(dev); barrier()
         return par.max_over_ranks(time.perf_counter() - t0, dev)
 
-    steps_ = [stepmod.RenderLossStep(dr, batches[s_][0][0], batches[s_][0][1], no_mask=True, fused=not args.unfused) for s_ in range(nstreams)]
+    def timed_median(fn, n, reps=None):
+        """The timed region repeated: median over the repetitions (every one bracketed like timed()), and all of them."""
+        ts_ = [timed(fn, n) for _ in range(max(1, reps or args.reps))]
+        return float(np.median(ts_)), ts_
+
+    steps_ = [stepmod.RenderLossStep(dr, batches[s_][0][0], batches[s_][0][1], no_mask=True, fused=not args.unfused, emit_imnormal=True)
+              for s_ in range(nstreams)]
     step = steps_[0]
+    step_noimn = stepmod.RenderLossStep(dr, batches[0][0][0], batches[0][0][1], no_mask=True, fused=not args.unfused, emit_imnormal=False)
 
     # ---- the gradient all-reduce a data-parallel trainer adds to every step (N > 1) ---------------------------------------------
     grad_mb = args.grad_mb if args.grad_mb is not None else (135.0 if world > 1 else 0.0)
     reducer = None
+    ddp_info = None
     if world > 1 and grad_mb > 0:
-        flat = torch.full((int(grad_mb * 1e6 / 4),), float(rank + 1), device=dev, dtype=torch.float32)
+        flat = None
+        if args.ddp_encoder:
+            # the REAL message: the gradient of an attribute-producing network (trainer_step.AttributeNet: two ResNet-18 trunks + conv stacks),
+            # produced by one DistributedDataParallel step on this rank's shard (bucketed all-reduce overlapped with its backward, checked
+            # against the ranks' mean) -- its flat gradient buffer is what the timed region keeps reducing
+            try:
+                flat, ddp_info = par.ddp_gradient_buffer(dr, B, H, W, dev, rank)
+            except Exception as e:                                # never lose the scaling line to the set-up of its message
+                ddp_info = {"error": "%s: %s" % (type(e).__name__, e)}
+                flat = None
+        if flat is None:
+            flat = torch.full((int(grad_mb * 1e6 / 4),), float(rank + 1), device=dev, dtype=torch.float32)
         reducer = par.GradAllReducer(flat)
 
     streams_ = [torch.cuda.current_stream(dev)]
@@ -299,29 +328,91 @@ def main():
     if reducer is not None:
         reducer.wait()
         sched.start(every_k)                                     # the first timed step launches a reduction
-    elapsed = timed(lambda: one(), args.steps)
+    elapsed, elapsed_all = timed_median(lambda: one(), args.steps)
     launched_timed = reducer.launched if reducer is not None else 0
     if reducer is not None:
         reducer.wait(); torch.cuda.synchronize(dev)
     loss_value = float(step.loss) if args.mode != "torch" else None
 
-    one_stream = api_value = api_fused_value = None
+    one_stream = api_value = api_fused_value = api_graphed_value = api_graphed_slots_value = shim_value = no_imn_value = None
+    e1, e1_all = elapsed, elapsed_all
     if args.mode == "eager":
         if reducer is not None:
             sched1.start(every_k)
         for _ in range(min(args.warmup, 20)):
             one_single()
-        e1 = timed(one_single, args.steps)
+        e1, e1_all = timed_median(one_single, args.steps)
         one_stream = round(world * B * args.steps / e1, 1)
+        if reducer is not None:
+            reducer.wait(); sched1.off()
+        ctr3 = [0]
+
+        def one_noimn():
+            k = ctr3[0]; ctr3[0] += 1
+            if nrot > 1:
+                step_noimn.set_inputs(*batches[0][k % nrot])
+            step_noimn.run()
+        for _ in range(min(args.warmup, 20)):
+            one_noimn()
+        e1n, _ = timed_median(one_noimn, args.steps, reps=3)
+        no_imn_value = round(world * B * args.steps / e1n, 1)
     if args.api_steps > 0:
         for _ in range(10):
             one_api()
-        e2 = timed(one_api, args.api_steps)
+        e2, _ = timed_median(one_api, args.api_steps, reps=3)
         api_value = round(world * B * args.api_steps / e2, 1)
         for _ in range(10):
             one_api_fused()
-        e2f = timed(one_api_fused, args.api_steps)
+        e2f, _ = timed_median(one_api_fused, args.api_steps, reps=3)
         api_fused_value = round(world * B * args.api_steps / e2f, 1)
+        # DiffRender.graphed_step: (a) attributes arrive as fresh tensors and are copied into the static slots; (b) the caller writes into the slots
+        gs = dr_api.graphed_step(batches[0][0][0], batches[0][0][1], no_mask=True)
+
+        def one_api_graphed():
+            k = ctr2[0] % nrot; ctr2[0] += 1
+            lv = leaves_rot[k]
+            for v in lv.values():
+                v.grad = None
+            a = dict(batches[0][k][0]); a.update(lv)
+            gs(batches[0][k][1], **a)[0].backward()
+        for _ in range(10):
+            one_api_graphed()
+        e2g, _ = timed_median(one_api_graphed, args.api_steps, reps=3)
+        api_graphed_value = round(world * B * args.api_steps / e2g, 1)
+        slot_leaves = {k: gs.inputs[k].requires_grad_(True) for k in stepmod.LEAVES}
+        slot_att = dict(batches[0][0][0]); slot_att.update(slot_leaves)
+
+        def one_api_graphed_slots():                              # (the networks' outputs land in the slots; here they simply stay)
+            for v in slot_leaves.values():
+                v.grad = None
+            gs(gs.gt, **slot_att)[0].backward()
+        for _ in range(10):
+            one_api_graphed_slots()
+        e2s, _ = timed_median(one_api_graphed_slots, args.api_steps, reps=3)
+        api_graphed_slots_value = round(world * B * args.api_steps / e2s, 1)
+    if args.shim_steps > 0 and rank == 0:
+        # the un-fused kaolin-shaped operator chain in the reference's order (networks.py:278-317): ~40 launches per render, float atomics
+        try:
+            chain = importlib.import_module("3d-magic-mirror_amd.shim_chain")
+
+            def one_shim():
+                k = ctr2[0] % nrot; ctr2[0] += 1
+                lv = leaves_rot[k]
+                for v in lv.values():
+                    v.grad = None
+                a = dict(batches[0][k][0]); a.update(lv)
+                rgbs, _, _ = chain.render(dr_api, no_mask=True, **a)
+                chain.recon_data(dr_api, rgbs, batches[0][k][1]).backward()
+            for _ in range(3):
+                one_shim()
+            torch.cuda.synchronize(dev)
+            c0 = time.perf_counter()
+            for _ in range(args.shim_steps):
+                one_shim()
+            torch.cuda.synchronize(dev)
+            shim_value = round(B * args.shim_steps / (time.perf_counter() - c0), 1)
+        except Exception as e:                                    # a secondary figure must not cost the line
+            shim_value = "%s: %s" % (type(e).__name__, e)
 
     # ---- per-kernel durations (HIP events recorded by the library around each launch, same stream) ------------
     roofline, kernels_us = None, {}
@@ -411,28 +502,37 @@ def main():
 
     if rank == 0:
         total_images = world * B * args.steps
+        head = e1 if args.mode == "eager" else elapsed           # eager: the one-stream leg is the headline
+        spread = lambda xs: round(100.0 * (max(xs) - min(xs)) / float(np.median(xs)), 2)
         out = {
             "metric": "render+loss+bwd images/sec at B=%d %dx%d, ~%.1fk faces" % (B, H, W, dr.num_faces / 1000.0),
-            "value": round(total_images / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(total_images / head, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(head / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "value_is_b48_one_stream": args.mode == "eager",
+            "timing": {"reps": max(1, args.reps), "statistic": "median over the repetitions of the K-step timed region",
+                       "spread_pct_of_median": spread(e1_all if args.mode == "eager" else elapsed_all)},
             "config": {"workload": "%s: template %s (V=%d,F=%d), B=%d per GPU, %dx%d, texture %dx%d, no_mask, fwd+loss+bwd to all "
                                    "8 inputs" % (args.config, name, dr.num_vertices, dr.num_faces, B, H, W, Ht, Wt),
-                       "value_is": {"eager": "%d independent steps in flight on %d HIP streams (C ABI, fused loss); one batch at a time = "
-                                             "value_one_stream; the DiffRender autograd API = value_api" % (nstreams, nstreams),
+                       "value_is": {"eager": "one B=%d batch at a time on one HIP stream (C ABI, fused loss, imnormal materialised); %d independent "
+                                             "steps in flight on %d streams = value_four_streams; the DiffRender autograd API = value_api*" % (B, nstreams, nstreams),
                                     "hipgraph": "one step replayed as a HIP graph on one stream",
                                     "torch": "the DiffRender autograd API on one stream"}[args.mode],
                        "mode": args.mode, "streams": nstreams, "fused_loss": not args.unfused,
                        "inputs": "%d distinct batches per stream visited in turn (%.0f MB of inputs in total; Infinity Cache 256 MiB)"
                                  % (nrot, nstreams * nrot * input_bytes / 1e6),
-                       "imnormal": "not materialised in value / value_one_stream (visualise-only output, networks.py:320); materialised in value_api",
+                       "imnormal": "materialised in value, value_four_streams and value_api* like the reference does (networks.py:320); value_without_imnormal leaves it out",
                        "sharding": "batch, no data-path collective",
                        "grad_allreduce": None if reducer is None else
                                          {"mb_per_reduction_per_rank": round(reducer.bytes_per_step() / 1e6, 1), "every_k_steps": every_k,
                                           "launched_in_timed_region": launched_timed, "alone_ms": allreduce_ms, "overlapped": True,
                                           "policy": "one reduction in flight at all times, back to back on a side stream, concurrent with the render "
                                                     "streams: K = ceil(1.25 x reduction alone / step alone), agreed on from max-over-ranks timings"}},
-            "value_one_stream": one_stream, "value_api": api_value, "value_api_fused": api_fused_value,
+            "value_one_stream": one_stream, "value_four_streams": round(total_images / elapsed, 1) if args.mode == "eager" else None,
+            "ms_per_step_four_streams": round(elapsed / args.steps * 1e3, 4) if args.mode == "eager" else None,
+            "value_without_imnormal": no_imn_value,
+            "value_api": api_value, "value_api_fused": api_fused_value, "value_api_graphed": api_graphed_value,
+            "value_api_graphed_slots": api_graphed_slots_value, "value_shim": shim_value, "ddp_encoder": ddp_info,
             "value_config3": None if not config3 else config3.get("images_per_s"), "config3": config3,
             "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},
             "loss": loss_value,

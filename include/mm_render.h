@@ -59,8 +59,9 @@ typedef struct MMRenderDesc {
     /* static template data (device) */
     const int32_t* faces;       /* (F,3) vertex ids */
     const float* face_uvs;      /* (F,3,2) raw OBJ uv of every corner (networks.py:196-202) */
-    const int32_t* vc_offsets;  /* (V+1) CSR: vertex -> incident corners ...        (backward only; may be NULL forward) */
-    const int32_t* vc_items;    /* (3F)  ... each item = face*3 + corner, ascending (backward only) */
+    const int32_t* vc_table;    /* (V,vc_stride,4) vertex -> incident corners, fixed stride (mm_build_vertex_corner_table): entry = {face*3 + corner,
+                                 * the face's three vertex ids}, ascending, padded with {-1,..}   (backward only; may be NULL forward) */
+    int32_t vc_stride;          /* entries per vertex (>= the largest valence of the template) */
     /* per-sample attributes (device), the 'attributes' dict of networks.py:259-270 */
     const float* vertices;      /* (B,V,3) */
     const float* textures;      /* (B,3,Ht,Wt) */
@@ -403,6 +404,10 @@ int mm_mask_iou_backward(const MMMaskIouDesc* desc, const float* grad_loss, floa
  * ------------------------------------------------------------------------------------------------------------------ */
 /* Build the vertex -> corner CSR from HOST faces (F,3).  offsets: (V+1), items: (3F).  Returns MM_OK or an error. */
 int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces_host, int32_t* offsets_host, int32_t* items_host);
+/* The same adjacency with a fixed stride, as MMRenderDesc.vc_table wants it (one trip to memory for a vertex's corners AND their faces'
+ * vertex ids, where the CSR needs three).  Returns the stride (the template's largest valence) if table_host is NULL; otherwise fills
+ * table_host (V, stride, 4) for the given stride (>= that valence) and returns MM_OK, or an MMStatus error. */
+int mm_build_vertex_corner_table(int32_t V, int32_t F, const int32_t* faces_host, int32_t stride, int32_t* table_host);
 const char* mm_status_string(int status);
 /* After MM_ERR_LAUNCH on this host thread: "<kernel>: <hipGetErrorString> (hipError n)"; "" if none was recorded. */
 const char* mm_last_error_detail(void);
@@ -412,8 +417,9 @@ const char* mm_last_error_detail(void);
  * 12 MMDibrGrads, 13 MMTexMapDesc, 14 MMTexMapGrads, 15 MMShDesc, 16 MMShGrads, 17 MMMaskIouDesc. */
 size_t mm_struct_size(int which);
 /* Bumped whenever a struct or the meaning of a field changes (2: op boundary added, reserved uv-tile fields and profiling slot
- * MM_PROF_BIN removed, options bits defined).  Bindings must refuse a library whose version differs from what they mirror. */
-#define MM_ABI_VERSION 2
+ * MM_PROF_BIN removed, options bits defined; 3: MMRenderDesc takes the fixed-stride vertex -> corner table instead of the CSR,
+ * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN).  Bindings must refuse a library whose version differs from what they mirror. */
+#define MM_ABI_VERSION 3
 int mm_abi_version(void);
 
 #ifdef __cplusplus

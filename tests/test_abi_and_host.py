@@ -74,6 +74,25 @@ def test_host_csr_builders(pkg):
                                           items.ctypes.data_as(ctypes.c_void_p)) == 0
     ro, ri = pkg.template.vertex_corner_adjacency(V, dr.faces)
     np.testing.assert_array_equal(off, ro.numpy()); np.testing.assert_array_equal(items, ri.numpy())
+    # the fixed-stride form MMRenderDesc.vc_table takes: the library's helper and the host class build the same table, which lists, per
+    # vertex, exactly the CSR's corners (ascending) together with their faces' vertex ids
+    for name in ("sphere", "smpl_uv_642", "smpl_uv"):
+        d2 = pkg.DiffRender(os.path.join(TEMPLATES, name + ".npz"), 32)
+        f2 = d2.faces.numpy().astype(np.int32)
+        V2, F2 = d2.num_vertices, d2.num_faces
+        stride = lib.mm_build_vertex_corner_table(V2, F2, f2.ctypes.data_as(ctypes.c_void_p), 0, None)
+        tab = np.zeros((V2, stride, 4), np.int32)
+        assert stride == int(np.bincount(f2.reshape(-1), minlength=V2).max())
+        assert lib.mm_build_vertex_corner_table(V2, F2, f2.ctypes.data_as(ctypes.c_void_p), stride, tab.ctypes.data_as(ctypes.c_void_p)) == 0
+        np.testing.assert_array_equal(tab, d2._vc_table.numpy())
+        o2, i2 = pkg.template.vertex_corner_adjacency(V2, d2.faces)
+        o2, i2 = o2.numpy(), i2.numpy()
+        for v in (0, 1, V2 // 2, V2 - 1):
+            n = o2[v + 1] - o2[v]
+            np.testing.assert_array_equal(tab[v, :n, 0], i2[o2[v]:o2[v + 1]])
+            assert (tab[v, n:] == -1).all() and (f2[tab[v, :n, 0] // 3] == tab[v, :n, 1:]).all()
+            assert (f2.reshape(-1)[tab[v, :n, 0]] == v).all()
+        assert lib.mm_build_vertex_corner_table(V2, F2, f2.ctypes.data_as(ctypes.c_void_p), stride - 1, tab.ctypes.data_as(ctypes.c_void_p)) == -2
 
 
 def test_render_without_gpu_fails_loudly(pkg):

@@ -301,6 +301,68 @@ def test_fused_backward_does_not_read_the_forward_image_back(pkg):
         assert float(grads[0][k].abs().max()) > 0
 
 
+def test_graphed_step_replays_the_eager_path_bit_for_bit(pkg):
+    """DiffRender.graphed_step: render + recon_data + backward captured as HIP graphs behind one autograd node (the call sites of
+    trainer.py:276,441,509-518).  Replays -- on new inputs copied into the static slots, on inputs written into the slots directly, with an
+    upstream gradient through face_normals, and with the loss unused -- give the bits of the eager render_recon path."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 6, 96, seed=51)
+    gs = dr.graphed_step(datt, gt.to(dev), no_mask=True)
+    for it, seed in enumerate((52, 53, 54)):
+        _, att2, d2, gt2, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", 6, 96, seed=seed)
+        w = torch.linspace(-1.0, 1.0, 6 * dr.num_faces * 3, device=dev).reshape(6, dr.num_faces, 3) * 1e-3
+        # eager reference
+        loss_e, rgbs_e, out_e = dr.render_recon(gt2.to(dev), no_mask=True, **d2)
+        tot_e = 1.7 * loss_e + (out_e["face_normals"] * w).sum() if it != 2 else (out_e["face_normals"] * w).sum()
+        tot_e.backward()
+        ref = (loss_e.detach().clone(), rgbs_e.detach().clone(), dr.last_face_idx.clone(), {k: d2[k].grad.clone() for k in LEAVES})
+        # graphed: iteration 1 writes the inputs straight into the static slots (no copy inside the call)
+        leaves = {k: d2[k].detach().clone().requires_grad_(True) for k in LEAVES}
+        if it == 1:
+            with torch.no_grad():
+                for k in LEAVES:
+                    gs.inputs[k].copy_(leaves[k])
+                gs.gt.copy_(gt2.to(dev))
+            leaves = {k: gs.inputs[k].requires_grad_(True) for k in LEAVES}
+            for v in leaves.values():
+                v.grad = None
+            a = dict(d2); a.update(leaves)
+            loss_g, rgbs_g, out_g = gs(gs.gt, **a)
+        else:
+            a = dict(d2); a.update(leaves)
+            loss_g, rgbs_g, out_g = gs(gt2.to(dev), **a)
+        tot_g = 1.7 * loss_g + (out_g["face_normals"] * w).sum() if it != 2 else (out_g["face_normals"] * w).sum()
+        tot_g.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(loss_g.detach(), ref[0]) and torch.equal(rgbs_g.detach(), ref[1]) and torch.equal(dr.last_face_idx, ref[2]), it
+        for k in LEAVES:
+            assert torch.equal(leaves[k].grad, ref[3][k]), (it, k)
+        for v in gs.inputs.values():
+            v.requires_grad_(False)
+    # accumulation over steps: a .grad that is kept (not reset to None) aliases the static buffer of the last step; the next step copies it
+    # out before the replay overwrites it -- two steps on the same inputs leave exactly twice the gradient
+    _, _, d4, gt4, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", 6, 96, seed=56)
+    lv = {k: d4[k].detach().clone().requires_grad_(True) for k in LEAVES}
+    a4 = dict(d4); a4.update(lv)
+    gs(gt4.to(dev), **a4)[0].backward()
+    once = {k: lv[k].grad.clone() for k in LEAVES}
+    gs(gt4.to(dev), **a4)[0].backward()
+    for k in LEAVES:
+        assert torch.equal(lv[k].grad, once[k] + once[k]), k
+    # without autograd: forward + backward replayed on what the slots hold, dL/dloss = 1
+    _, att3, d3, gt3, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", 6, 96, seed=55)
+    loss_e, _, _ = dr.render_recon(gt3.to(dev), no_mask=True, **d3)
+    loss_e.backward()
+    with torch.no_grad():
+        for k in LEAVES:
+            gs.inputs[k].copy_(d3[k])
+        gs.gt.copy_(gt3.to(dev)); gs.g_loss.fill_(1.0); gs.g_fn.zero_()
+    loss_r = gs.run()
+    torch.cuda.synchronize()
+    assert torch.equal(loss_r, loss_e.detach())
+    for k in LEAVES:
+        assert torch.equal(gs.grads[k], d3[k].grad), k
+
+
 def test_lane_exchange_primitives_on_this_gpu():
     """mm_device.h builds its 64x64 bit transposes and prefix scans from DPP lane selects and gfx950's v_permlane16/32_swap (no LDS-crossbar
     shuffles); profiles/tools/xchg_test.hip checks every stride, the transpose and the scan against their definitions on the device."""

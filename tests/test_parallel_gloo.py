@@ -78,9 +78,17 @@ def _worker(rank, world, port, out):
     par.allreduce_mean_([local_mean], local_weight=hi5 - lo5)
     tmax = par.max_over_ranks(0.5 + rank)
     v = torch.full((2,), float(rank)); par.broadcast_(v, src=1)
+    # a real module under DistributedDataParallel (bench.py's N > 1 message, parallel.ddp_step_check): DDP's bucketed, overlapped reduction of
+    # a shard-specific loss equals the mean over ranks of the unsynchronised local gradients -- and equals the single-process gradient of
+    # the mean of the two shards' losses (checked by the parent)
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 16), torch.nn.Tanh(), torch.nn.Linear(16, 9))
+    xs = torch.randn(2, 6, 5, generator=torch.Generator().manual_seed(11))
+    ddp, ddp_err = par.ddp_step_check(net, lambda m: (m(xs[rank]) ** 2).mean(), dev)
+    ddp_grads = [p.grad.clone() for p in net.parameters()]
     par.barrier()
     if rank == 0:
-        torch.save({"gW": gW, "loss": lt, "extra": extra, "tmax": tmax, "bc": v, "step1": step1, "step2": flat, "launched": red.launched,
+        torch.save({"ddp_err": ddp_err, "ddp_grads": ddp_grads, "gW": gW, "loss": lt, "extra": extra, "tmax": tmax, "bc": v, "step1": step1, "step2": flat, "launched": red.launched,
                     "bytes": red.bytes_per_step(), "wmean": local_mean, "umean": unweighted, "fired": fired, "launched2": red2.launched, "flat2": flat2}, out)
     torch.distributed.destroy_process_group()
 
@@ -112,6 +120,14 @@ def test_two_rank_sharding_matches_single_process(oracle, tmp_path):
     torch.testing.assert_close(got["flat2"], torch.full((64,), 1.5))              # mean of 1 and 2, a fixed point of further means
     assert abs(float(got["wmean"]) - 3.0) < 1e-6                               # mean of 1..5
     assert abs(float(got["umean"]) - 3.25) < 1e-6                              # (2 + 4.5) / 2: what unweighted averaging would give
+    # DistributedDataParallel on two shards == the single-process gradient of the mean of the two shard losses
+    assert got["ddp_err"] < 1e-7
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 16), torch.nn.Tanh(), torch.nn.Linear(16, 9))
+    xs = torch.randn(2, 6, 5, generator=torch.Generator().manual_seed(11))
+    (0.5 * ((net(xs[0]) ** 2).mean() + (net(xs[1]) ** 2).mean())).backward()
+    for p, g in zip(net.parameters(), got["ddp_grads"]):
+        torch.testing.assert_close(g, p.grad, rtol=1e-5, atol=1e-8)
 
 
 def test_shard_bounds_cover_everything():

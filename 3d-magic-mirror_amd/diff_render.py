@@ -327,11 +327,15 @@ class DiffRender(object):
         self.last_face_idx = face_idx                   # kaolin returns it from dibr_rasterization; the reference drops it
         return rgbs, attributes
 
-    def render_recon(self, gt_data, no_mask=False, **attributes):
+    def render_recon(self, gt_data, no_mask=False, contour=0, **attributes):
         """render(**attributes) and recon_data(rendered, gt_data, no_mask) (contour = 0) in ONE pass over the pixels: the loss terms
         are reduced while the image is shaded and its gradient is formed inside the backward kernels (no loss launches, no dL/drgba
         round trip) -- the path bench.py's `value` times, reachable from the class API.  Returns (loss, rgbs, attributes); ``rgbs``
         carries no gradient here (use render + recon_data if the image feeds anything else that is differentiated)."""
+        if contour:
+            # the fused kernels carry recon_data's L1 + IoU terms only; the contour term (networks.py:379-387) needs the rendered mask as a whole
+            raise ValueError("render_recon folds recon_data with contour = 0 into the render kernels; for contour > 0 (opt.lambda_contour) call "
+                             "render(...) and recon_data(..., contour=%r)" % (contour,))
         a = attributes
         rgba, fn, imn, face_idx, loss = self._render_node(bool(no_mask), gt_data, a['vertices'], a['textures'], a['lights'],
                                                           a['bg'] if no_mask else None, a['azimuths'], a['elevations'], a['distances'], a['biases'])

@@ -490,14 +490,14 @@ def main():
         rate_all, n_all = cpu_rate(B, args.cpu_seconds)
         single = None
         if args.cpu_single_seconds > 0:
-            nb1 = min(B, 4)
             oracle.set_threads(1)
-            rate_1, n_1 = cpu_rate(nb1, args.cpu_single_seconds)
+            rate_1, n_1 = cpu_rate(B, args.cpu_single_seconds)   # the SAME batch as the all-thread sample
             oracle.set_threads(nthreads)
-            single = {"value": round(rate_1, 3), "cores": 1, "sample": "%d steps of the first %d images" % (n_1, nb1)}
+            single = {"value": round(rate_1, 3), "cores": 1, "sample": "%d steps of the full batch of %d images" % (n_1, B)}
         cpu = {"value": round(rate_all, 2), "unit": "images/s", "cores": nthreads, "kind": "port", "cpu_model": cpu_model(),
-               "single_thread": single,
-               "sample": "%d steps of the full batch of %d images (%s, %dx%d), render+loss+backward, OpenMP over (image,row)/(image); "
+               "single_thread": single, "thread_scaling": None if not single else round(rate_all / rate_1, 1),
+               "sample": "%d steps of the full batch of %d images (%s, %dx%d), render+loss+backward; OpenMP over (image, row) in the forward and "
+                         "(image, band of rows) with band-private accumulators in the backward's scatters; "
                          "CPU restatement of the kaolin DIB-R semantics, not kaolin" % (n_all, B, name, H, W)}
 
     if rank == 0:

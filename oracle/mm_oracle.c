@@ -13,6 +13,9 @@
  * mirrored bit for bit by the HIP path.  Process-wide on purpose: this is test infrastructure, set before a call, never concurrently. */
 enum { MMO_OPT_CULL_STRICT = 1 << 4, MMO_OPT_SOFT_SKIP_CULLED = 1 << 5, MMO_OPT_BBOX_HALF_OPEN = 1 << 6, MMO_OPT_BARY_ONE_MINUS = 1 << 7,
        MMO_OPT_SH_ORDER_XYZ = 1 << 8, MMO_OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9 };
+/* scatter loops of the backward run as (image, band) tasks with private accumulators that are then added in band order (mm_oracle.inc) */
+#define MMO_BANDS 8
+#define MMO_TEX_BANDS 4
 static int mmo_options = 0;
 /* which bbox borders are open (a centre exactly on them is outside): bit 0 the min border, bit 1 the max border -- include/mm_render.h */
 static int mmo_box_mode(void) { return ((mmo_options & MMO_OPT_BBOX_HALF_OPEN) ? 3 : 0) | ((mmo_options & MMO_OPT_BBOX_MIN_CLOSED_MAX_OPEN) ? 2 : 0); }

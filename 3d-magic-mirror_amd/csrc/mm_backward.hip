@@ -450,7 +450,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H; a.sig2 = d->sigmainv / (d->multiplier * d->multiplier);
     a.geo = w.geo; a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
-    a.face_idx = d->face_idx; a.soft = w.soft; a.fflag = w.bin_shift != 3 ? w.fflag : nullptr; a.grad_rgba = g->grad_rgba;   // (face flags: only the compacting walk of the forward sets them)
+    a.face_idx = d->face_idx; a.soft = w.soft; a.fflag = walk_queue_mode(d->options, w.bin_shift) ? w.fflag : nullptr; a.grad_rgba = g->grad_rgba;   // (face flags: only the compacting walk of the forward sets them)
     a.gp = w.gp; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.ticket = w.ticket;
     a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;

@@ -51,6 +51,14 @@ struct TexSpill { TexRecord r; int tile; int pad; };
 #define MM_TREC_CAP 2048      // records per tile; further records of a full tile go to the image's spill list
 #endif
 
+// which form of the forward walk a shape gets (mm_raster_walk.h): the compacting queue (+ the face flags the backward's sweep plan reads) for
+// screen bins larger than a tile, the per-batch walk for 8-pixel bins; MM_OPT_WALK_QUEUE / MM_OPT_WALK_BATCH force one (identical results)
+inline bool walk_queue_mode(int options, int bin_shift) {
+    if (options & MM_OPT_WALK_QUEUE) return true;
+    if (options & MM_OPT_WALK_BATCH) return false;
+    return bin_shift != 3;
+}
+
 // ---- workspace carving (all offsets multiples of 256 bytes) ---------------------------------------------------------
 struct Workspace {
     float* T;              // (B,12)     camera transform [R;t], row-major (4,3)

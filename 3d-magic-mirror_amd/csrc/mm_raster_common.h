@@ -619,7 +619,7 @@ __device__ inline void walk_image_rank(int i, int B, bool spread, int& b, int& j
     if (spread) { const int g = i >> 3; b = g % B; j = (g / B) * 8 + (i & 7); }
     else { b = i % B; j = i / B; }
 }
-inline bool walk_queue_mode(const RasterArgs& a) { return a.bin_shift != 3; }
+inline bool walk_queue_mode(const RasterArgs& a) { return walk_queue_mode(a.options, a.bin_shift); }
 inline bool walk_spread(const RasterArgs& a) { return a.order != nullptr && 4 * a.blocks_per_image >= 1024; }
 inline unsigned walk_grid(const RasterArgs& a, bool block) {
     if (!a.order) return (unsigned)a.B * (unsigned)a.blocks_per_image * (block ? 1u : 4u);

@@ -108,6 +108,8 @@ enum { MM_OPT_WALK_BLOCK = 1 << 1,         /* tuning: force the 256-thread / coo
                                             * copysign'd) instead of three edge functions / copysign-padded sum          (App. C-3) */
        MM_OPT_SH_ORDER_XYZ = 1 << 8,       /* SH linear bands in x,y,z order and quadratic bands xy,yz,3z^2-1,xz,x^2-y^2 paired with
                                             * lights 1..8 in THAT order (instead of x,z,y / xy,yz,z^2,xz,x^2-y^2)          (App. C-6) */
+       MM_OPT_WALK_QUEUE = 1 << 10,        /* tuning: force the compacting-queue form of the forward walk (default: screen bins larger than a tile) ...           */
+       MM_OPT_WALK_BATCH = 1 << 11,        /* ... or the per-batch form (default: 8-pixel bins); identical results                                              */
        MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9 };  /* bbox test [min, max): reject x < min || x >= max -- the third form upstream may have,
                                             * between the closed default and MM_OPT_BBOX_HALF_OPEN (which opens both borders)  (App. C-4) */
 

@@ -22,7 +22,9 @@ struct BwdArgs {
     const float* bg;
     const int32_t* face_idx;
     const float2* soft;
-    const int* fflag;                                            // (B,F) faces that receive gradient from the pixels (raster_fwd): the others get no sweep items
+    const int* fflag;                                            // (B,F,2) {owns a pixel, is in a silhouette product} (raster_fwd): faces with neither get no sweep
+                                                                 // items, owners-only are swept over their box without the silhouette margin (sweep_box)
+    int sweep_sx, sweep_sy;                                      // that margin in whole pixels, per axis (sweep_shrink)
     const float* grad_rgba;
     float4* gp; float* gp2;
     float* dl_part;

@@ -72,10 +72,10 @@ __device__ inline FaceBox face_box(const BwdArgs& a, size_t o) {
     const float4 g2 = a.geo[o * 3 + 2];                           // z, w: the inflated pixel box, packed by the vertex stage
     fb.xmin = fminf(fminf(fb.p0.x, fb.p0.z), fb.p1.x); fb.ymin = fminf(fminf(fb.p0.y, fb.p0.w), fb.p1.y);
     fb.xmax = fmaxf(fmaxf(fb.p0.x, fb.p0.z), fb.p1.x); fb.ymax = fmaxf(fmaxf(fb.p0.y, fb.p0.w), fb.p1.y);
-    const unsigned org = __float_as_uint(g2.z), ext = __float_as_uint(g2.w);
-    fb.px0 = (int)(org & 0xFFFFu); fb.py0 = (int)(org >> 16);
-    fb.bw = (int)(ext & 0xFFFFu);
-    fb.npx = fb.bw * (int)(ext >> 16);
+    int taken = 1, bh;
+    if (a.fflag) taken = a.fflag[o * 2 + 1];                      // (the same box the sweep plan cut into this face's items)
+    sweep_box(__float_as_uint(g2.z), __float_as_uint(g2.w), taken != 0, a.sweep_sx, a.sweep_sy, a.W, a.H, fb.px0, fb.py0, fb.bw, bh);
+    fb.npx = fb.bw * bh;
     fb.inv_bw = 1.f / (float)(fb.bw > 0 ? fb.bw : 1);
     fb.nz = g2.y;
     return fb;
@@ -450,7 +450,9 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H; a.sig2 = d->sigmainv / (d->multiplier * d->multiplier);
     a.geo = w.geo; a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
-    a.face_idx = d->face_idx; a.soft = w.soft; a.fflag = walk_queue_mode(d->options, w.bin_shift) ? w.fflag : nullptr; a.grad_rgba = g->grad_rgba;   // (face flags: only the compacting walk of the forward sets them)
+    a.face_idx = d->face_idx; a.soft = w.soft; a.fflag = walk_queue_mode(d->options, w.bin_shift) ? w.fflag : nullptr;
+    a.sweep_sx = sweep_shrink(d->boxlen, d->W); a.sweep_sy = sweep_shrink(d->boxlen, d->H);
+    a.grad_rgba = g->grad_rgba;   // (face flags: only the compacting walk of the forward sets them)
     a.gp = w.gp; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.ticket = w.ticket;
     a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;

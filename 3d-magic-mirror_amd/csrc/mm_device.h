@@ -22,7 +22,9 @@
 #define MM_CHUNK_PX 128          // (256: gather_bwd +3.5 / +4.6 / +10 us at configs 2 / 3 / 5: the waves full of owned chunks are its tail)
 #endif                        // the backward sweeps every face's inflated pixel box in chunks of this many pixels, one 8-lane group each:
                               // an even load whatever the box sizes (perspective blow-ups, close-ups at high resolution)
-#define MM_GROUP_WORDS 8      // ids expanded per window of bin-mask words: 512 -> 1 KiB of uint16 ids per wave (a window never splits a word)
+#ifndef MM_GROUP_WORDS
+#define MM_GROUP_WORDS 8
+#endif                        // ids expanded per window of bin-mask words: 512 -> 1 KiB of uint16 ids per wave (a window never splits a word)
 
 namespace mm {
 
@@ -80,8 +82,9 @@ struct Workspace {
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
     int* nheavy;           // (B,2)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty
     int* bincount;         // (B,nbins)  candidates per screen bin (big screens / meshes only: bincount_kernel -> order_kernel)
-    int* fflag;            // (B,F)      1: the face won a pixel, or an uncovered pixel took it into its silhouette product -- only such faces receive
-                           //            gradient from the pixels, and only they are swept by the backward (cleared by vertex_fwd, set by raster_fwd)
+    int* fflag;            // (B,F,2)    [0] = 1: the face won a pixel; [1] = 1: an uncovered pixel took it into its silhouette product.  Only such faces
+                           //            receive gradient from the pixels, and only they are swept by the backward -- a face that only OWNS pixels over its
+                           //            own box, not over the box inflated by the silhouette margin (cleared by vertex_fwd, set by raster_fwd)
     long long* ltot;       // (B,MM_LSUB,4) fused loss: per image {sum|pi-gi|, sum p*g, sum p+g-p*g, -} in 2^-32 fixed point, spread over
                            //            MM_LSUB sub-accumulators (64-bit integer atomics of the raster waves: exact, order-free); zeroed by vertex_fwd
     int* tcnt;             // (B,ntiles)+(B)+(B,MM_GSHARD,8) records appended per texture tile, per-image spill counts, per-image maxima of the pixel
@@ -127,7 +130,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
     w.nheavy = (int*)(p + o);       o += align256((size_t)B * 2 * sizeof(int));
     w.bincount = (int*)(p + o);     o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
-    w.fflag = (int*)(p + o);        o += align256((size_t)B * F * sizeof(int));   // (ints, not bytes: a byte store may alias every later load in the compiler's eyes)
+    w.fflag = (int*)(p + o);        o += align256((size_t)B * F * 2 * sizeof(int));   // (ints, not bytes: a byte store may alias every later load in the compiler's eyes)
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
     w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + (size_t)B + (size_t)B * MM_GSHARD * 8) * sizeof(int));
     w.tspill = (TexSpill*)(p + o);  o += align256((size_t)B * 4 * H * W * sizeof(TexSpill));
@@ -559,6 +562,20 @@ __device__ inline void face_pixel_box(float ax, float ay, float bx, float by, fl
     const bool hit = bw > 0 && bh > 0;
     org = hit ? ((unsigned)bx0 | ((unsigned)by0 << 16)) : 0u;
     ext = hit ? ((unsigned)bw | ((unsigned)bh << 16)) : 0u;
+}
+
+// The pixel box the backward sweeps for a face.  The record holds the box inflated by the silhouette margin (what an uncovered pixel needs
+// to find the faces of its product, K4).  A face that is in NO silhouette product and only owns pixels (K2) is swept over that box shrunk
+// again by the margin's whole pixels minus one: lo_infl = ceil(f_tight - margin_px - 0.02) (pixel_range), so lo_infl + s <= ceil(f_tight) for
+// any s <= margin_px -- the owned pixels (centres inside the triangle, hence inside its own box) stay inside.  Sides cut off by the image
+// border are left alone (the clipped edge says nothing about where the box would have begun).  sx, sy: the shrink per axis.
+__host__ __device__ inline int sweep_shrink(float boxlen, int n) { const int s = (int)(boxlen * (float)n * 0.5f) - 1; return s > 0 ? s : 0; }
+__host__ __device__ inline void sweep_box(unsigned org, unsigned ext, bool taken, int sx, int sy, int W, int H, int& px0, int& py0, int& bw, int& bh) {
+    px0 = (int)(org & 0xFFFFu); py0 = (int)(org >> 16); bw = (int)(ext & 0xFFFFu); bh = (int)(ext >> 16);
+    if (taken || bw <= 0 || bh <= 0) return;
+    const int l = px0 > 0 ? sx : 0, r = px0 + bw < W ? sx : 0, t = py0 > 0 ? sy : 0, b = py0 + bh < H ? sy : 0;
+    if (bw - l - r <= 0 || bh - t - b <= 0) return;               // (cannot happen for a face that owns a pixel; never sweep nothing on a rounding doubt)
+    px0 += l; bw -= l + r; py0 += t; bh -= t + b;
 }
 
 // fused recon_data totals of image b: {sum|pi-gi|, sum p*g, sum p+g-p*g} (exact integer sums of the raster waves' partials)

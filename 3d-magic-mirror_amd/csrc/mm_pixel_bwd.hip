@@ -28,10 +28,14 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
     __shared__ unsigned short s_nch[MM_PLAN_LDS_FACES];
     const int tid = threadIdx.x;
     const bool staged = a.F <= MM_PLAN_LDS_FACES;                 // (more faces than that: the counts are re-read from the face records)
-    auto box_px = [&](int f) {                                   // (a face the forward did not flag owns no pixel and is in no silhouette product:
-        const unsigned ext = __float_as_uint(a.geo[((size_t)b * a.F + f) * 3 + 2].w);          //  nothing to sweep -- most faces of a fine, overlapping mesh)
-        const int live = a.fflag ? a.fflag[(size_t)b * a.F + f] : 1;
-        return live ? (int)(ext & 0xFFFFu) * (int)(ext >> 16) : 0;   // 0: the box misses the image, or no pixel refers to the face
+    auto box_px = [&](int f) {                                   // pixels of the face's sweep box; 0: the box misses the image, or no pixel refers to the face
+        const float4 q2 = a.geo[((size_t)b * a.F + f) * 3 + 2];   //  (most faces of a fine, overlapping mesh: nothing to sweep)
+        int own = 1, taken = 1;
+        if (a.fflag) { const int2 fl = reinterpret_cast<const int2*>(a.fflag)[(size_t)b * a.F + f]; own = fl.x; taken = fl.y; }
+        if (!(own | taken)) return 0;
+        int px0, py0, bw, bh;
+        sweep_box(__float_as_uint(q2.z), __float_as_uint(q2.w), taken != 0, a.sweep_sx, a.sweep_sy, a.W, a.H, px0, py0, bw, bh);
+        return bw * bh;
     };
     if (staged) {
         for (int f0 = tid; f0 < a.F; f0 += 8 * 256) {

@@ -21,7 +21,7 @@ struct RasterArgs {
     const float* lights;
     const float* bg;
     float2* soft;                           // per pixel {soft-mask product state, id of the knum-th face taken (int bits)}
-    int* fflag;                             // (B,F) set to 1 for a face that wins a pixel or is taken into an uncovered pixel's silhouette product (nullptr: not wanted)
+    int* fflag;                             // (B,F,2) [0] set for a face that wins a pixel, [1] for one taken into an uncovered pixel's silhouette product (nullptr: not wanted)
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     const int* nheavy;                      // (B,2) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty
@@ -37,7 +37,9 @@ struct RasterArgs {
     int options;                            // MM_OPT_* bits
 };
 
+#ifndef MM_PAIR_ROUND
 #define MM_PAIR_ROUND 512
+#endif
 #ifndef MM_HEAVY_CAND
 #define MM_HEAVY_CAND 192     // a tile with at least this many candidates (three batches) is walked by four waves together ...
 #endif
@@ -501,7 +503,7 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
         *(float4*)(a.rgba + pix * 4) = make_float4(out[0], out[1], out[2], out[3]);
         a.face_idx[pix] = h.f;
 #ifndef MM_NO_OWN_FLAG
-        if (h.f >= 0 && a.fflag) a.fflag[(size_t)t.b * a.F + h.f] = 1;     // (idempotent plain store: the backward sweeps this face)
+        if (h.f >= 0 && a.fflag) a.fflag[((size_t)t.b * a.F + h.f) * 2] = 1;     // "owns a pixel" (idempotent plain store: the backward sweeps this face)
 #endif
         a.soft[pix] = make_float2((h.f >= 0 || ss.zeros >= 2) ? 0.f : (ss.zeros == 1 ? -ss.qnz : ss.qnz), __int_as_float(ss.lastf));
         if (a.imnormal) { a.imnormal[pix * 3] = nx; a.imnormal[pix * 3 + 1] = ny; a.imnormal[pix * 3 + 2] = nz; }

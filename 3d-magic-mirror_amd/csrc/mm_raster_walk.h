@@ -21,12 +21,18 @@ struct __attribute__((aligned(16))) WaveStage {
     unsigned short pairs[MM_PAIR_ROUND];    // (row << 8) | column of the bit matrix being evaluated (candidate, pixel) or (pixel, candidate)
     unsigned long long key[64];             // per pixel: best (orderable z << 32 | ~face) so far; 0 = none
     long long logsum[64];                   // per pixel: sum of log2(1-p) in 2^-32 fixed point (integer adds commute)
+#ifdef MM_LDS_DIET
+    int zeros[16];
+#else
     int zeros[64];                          // per pixel: number of factors (1-p) that are exactly 0
+#endif
     unsigned long long takenw[64];          // faces of the current chunk of 4096 that some pixel took into its silhouette product: bit b of word w = face
                                             // chunk * 4096 + w * 64 + b (LDS ors; written to RasterArgs::fflag when the chunk has been walked)
     int npair[4];                           // cooperative walk: this wave's colour / silhouette pair counts of the round
 };
+#ifndef MM_NO_STAGE_ASSERT
 static_assert(sizeof(WaveStage) <= 8192, "four of them must fit 32 KiB: five workgroups per CU");
+#endif
 // cooperative walk: per pixel, inflated-box hits of this wave's batch of the current round / id of the knum-th silhouette face taken
 __device__ inline int* coop_cnt(WaveStage* st) { return reinterpret_cast<int*>(&st->qm[0][0]); }
 __device__ inline int* coop_lastf(WaveStage* st) { return reinterpret_cast<int*>(&st->qm[1][0]); }
@@ -44,7 +50,7 @@ __device__ inline void mark_taken(const RasterArgs& a, const TileCtx& t, const W
     if (!a.fflag || !(ms & openm)) return;
     const int f = __float_as_int(st->p2[t.lane].z), rel = f - cbase * 64;
     if (rel >= 0) atomicOr(&acc->takenw[rel >> 6], 1ull << (rel & 63));
-    else a.fflag[(size_t)t.b * a.F + f] = 1;
+    else a.fflag[((size_t)t.b * a.F + f) * 2 + 1] = 1;
 }
 // lane = word of the chunk: one idempotent store per noted face, then the word is cleared for the next chunk
 __device__ inline void flush_taken(const RasterArgs& a, const TileCtx& t, WaveStage* acc, int cbase) {
@@ -54,7 +60,7 @@ __device__ inline void flush_taken(const RasterArgs& a, const TileCtx& t, WaveSt
     while (w) {
         const int bit = __ffsll(w) - 1;
         w &= w - 1;
-        a.fflag[(size_t)t.b * a.F + (size_t)(cbase + t.lane) * 64 + bit] = 1;
+        a.fflag[((size_t)t.b * a.F + (size_t)(cbase + t.lane) * 64 + bit) * 2 + 1] = 1;
     }
 }
 
@@ -65,6 +71,9 @@ __device__ inline void flush_taken_last(const RasterArgs& a, const TileCtx& t, W
     flush_taken(a, t, acc, ((a.words - 1) / 64) * 64);
 }
 
+#ifndef MM_TAKEN_EXACT
+#define MM_TAKEN_EXACT 1
+#endif
 // Work of a 256-thread workgroup: FOUR tiles, one per wave (nothing shared), or ONE heavy tile walked by its four waves together
 // (tile_walk_coop).  With the plan kernel's order (tiles of an image by decreasing candidate count, the first nheavy of them heavy):
 // workgroup j of image b takes heavy tile j, or -- behind the heavy ones -- the four tiles nheavy + 4 (j - nheavy) + wave.  Launch
@@ -299,9 +308,13 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
         }
         const uint64_t openm = __ballot(open && cnt < a.knum);
         if (__ballot(ms != 0) && openm) {
-            mark_taken(a, t, st, st, ms, openm, cbase);
             const uint64_t ps = wave_transpose64(ms, t.lane);    // pixel-major: this lane's pixel, bit j = queued candidate j
             const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
+#if MM_TAKEN_EXACT
+            mark_taken(a, t, st, st, (wave_or_u64(sm) >> t.lane) & 1ull, 1ull, cbase);   // exactly the candidates some pixel took (bit 0 = this lane's)
+#else
+            mark_taken(a, t, st, st, ms, openm, cbase);          // a superset: every candidate whose inflated box holds a pixel that is still taking
+#endif
             cnt += __popcll(sm);
             if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);   // knum-th face taken
             if (__ballot(sm != 0)) soft_pairs(a, t, st, sm, s2);

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     face_pixel_box(ax, ay, bx, by, cx, cy, a.infl, a.mult, a.W, a.H, bx0, by0, bw, bh, org, ext);
     a.geo[o * 3 + 2] = make_float4(C.z, nz, __uint_as_float(org), __uint_as_float(ext));
     a.face_normals[o * 3 + 0] = nx; a.face_normals[o * 3 + 1] = ny; a.face_normals[o * 3 + 2] = nz;
-    a.fflag[o] = 0;
+    reinterpret_cast<int2*>(a.fflag)[o] = make_int2(0, 0);
     }
 
     // ---- screen binning: this wave's 64 faces are exactly mask word c (bin_wave_faces, mm_device.h) ---------------------------

@@ -19,8 +19,8 @@ fi
 for C in $CONFIGS; do
   timeout 1200 bash profiles/run_profile.sh $C > $OUT/profile_$C.log 2>&1
   python profiles/summarize_profile.py $TAG $C > $OUT/summary_$C.md 2>&1; head -40 $OUT/summary_$C.md
-  # raw CSVs are big: keep the stats + counter tables, drop the per-dispatch kernel traces of the PMC passes
-  find gpurun_out/prof_$C -name "*kernel_trace.csv" -path "*pmc*" -delete
+  # raw CSVs are big (gpurun merges at most 64 MiB back): the summaries above are what is kept
+  rm -rf gpurun_out/prof_$C
 done
 # the bench lines AFTER the counter passes, with this trip's counters installed: their roofline.traffic is then the fresh one
 cp $OUT/profiles/traffic_latest.json $OUT/profiles/valu_latest.json profiles/ 2>/dev/null

@@ -27,8 +27,10 @@ for case in range(ncase):
     mode = rng.choice(["default", "far", "near", "mixed"], p=[0.4, 0.25, 0.15, 0.2])
     dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio)
     dr.knum, dr.boxlen, dr.sigmainv = knum, boxlen, sigmainv
-    optbit = int(rng.choice([0, 0, 0, 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8, (1 << 4) | (1 << 5)]))   # Appendix-C switches, mirrored by the oracle
-    dr.options = int(os.environ.get("MM_OPTIONS", "0")) | optbit
+    optbit = int(rng.choice([0, 0, 0, 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8, 1 << 9, (1 << 4) | (1 << 5), (1 << 9) | (1 << 7)]))   # Appendix-C switches, mirrored by the oracle
+    # the four forms of the forward walk kernel (workgroup shape x per-batch / compacting queue): identical results by contract
+    walk = int(rng.choice([0, 0, 1 << 10, 1 << 11, 2, 4, (1 << 10) | 2, (1 << 10) | 4, (1 << 11) | 4, (1 << 11) | 2]))
+    dr.options = int(os.environ.get("MM_OPTIONS", "0")) | optbit | walk
     H, W = dr.render_height, dr.image_size
     att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=int(rng.integers(0, 1 << 30)))
     if mode == "far":
@@ -41,7 +43,7 @@ for case in range(ncase):
     inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att.items()}
     inp["faces"] = dr.faces.numpy().astype(np.int32); inp["face_uvs"] = dr.face_uvs.numpy()[0]
     proj = dr.cam_proj.numpy().reshape(3)
-    tag = "%s B=%d %dx%d no_mask=%d knum=%d boxlen=%g sigmainv=%g %s opt=%d" % (name, B, H, W, no_mask, knum, boxlen, sigmainv, mode, optbit)
+    tag = "%s B=%d %dx%d no_mask=%d knum=%d boxlen=%g sigmainv=%g %s opt=%d walk=%d" % (name, B, H, W, no_mask, knum, boxlen, sigmainv, mode, optbit, walk)
     if only is not None and case != int(only):
         continue
     api = str(rng.choice(["render+recon_data", "render_recon", "shim operators"], p=[0.4, 0.3, 0.3]))

@@ -275,10 +275,18 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         // the partials (independent loads), fixed butterfly order
         const int wv = tid >> 6, ln = tid & 63;
         if (wv >= 1) {
-            float sum[3] = {0.f, 0.f, 0.f};                      // the three components' loads in flight together
-            for (int k = ln; k < a.blocks_per_image; k += 64) {
-                const float* row = a.dl_part + ((size_t)b * a.blocks_per_image + k) * 12 + (wv - 1) * 3;
-                sum[0] += row[0]; sum[1] += row[1]; sum[2] += row[2];
+            float sum[3] = {0.f, 0.f, 0.f};                      // the three components' loads of four rows in flight together
+            for (int k0 = ln; k0 < a.blocks_per_image; k0 += 256) {
+                float r[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 64 * u;
+                    const float* row = a.dl_part + ((size_t)b * a.blocks_per_image + min(k, a.blocks_per_image - 1)) * 12 + (wv - 1) * 3;
+                    const bool ok = k < a.blocks_per_image;
+                    r[u][0] = ok ? row[0] : 0.f; r[u][1] = ok ? row[1] : 0.f; r[u][2] = ok ? row[2] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { sum[0] += r[u][0]; sum[1] += r[u][1]; sum[2] += r[u][2]; }
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -289,19 +297,31 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
     }
     MM_PP_MARK(4);
     if (tid >= 64 && tid < 100) reinterpret_cast<float*>(&s_cam)[tid - 64] = a.cam[b * 48 + tid - 64];   // the forward's camera (no trig here)
-    {   // dL/dT = sum of the workgroups' partials in index order.  The partials are fetched by all threads at once (one trip to memory per 21
-        // workgroups, not one per workgroup), parked in LDS and added up by twelve threads in index order: still bitwise reproducible.
+    {   // dL/dT = sum of the workgroups' partials in a FIXED order: thread (gl, comp) adds rows gl, gl + 21, gl + 42, ... of its component --
+        // all of its loads in flight together: ONE trip to memory however many workgroups the image has (6 890 vertices: 216 rows; a pass of
+        // 21 rows at a time was eleven dependent trips, ~20 us of serial tail per image) -- then twelve threads add the 21 partial sums in
+        // index order.  No float atomics, the same order every run: bitwise reproducible.
+        const int gl = tid / 12, comp = tid - gl * 12;
         float sum = 0.f;
-        const int gl = tid / 12, comp = tid - gl * 12;           // 21 partial rows per pass
-        for (unsigned g0 = 0; g0 < gridDim.x; g0 += 21) {
-            const unsigned g = g0 + gl;
-            if (gl < 21 && g < gridDim.x)
-                s_part[gl][comp] = __hip_atomic_load(a.dTpart + ((size_t)b * gridDim.x + g) * 12 + comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if (tid < 12) for (unsigned k = 0; k < 21u && g0 + k < gridDim.x; ++k) sum += s_part[k][tid];
-            __syncthreads();
+        if (gl < 21) {
+            for (unsigned g0 = gl; g0 < gridDim.x; g0 += 21 * 8) {
+                float r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned g = g0 + 21u * u;
+                    r[u] = g < gridDim.x ? __hip_atomic_load(a.dTpart + ((size_t)b * gridDim.x + g) * 12 + comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += r[u];
+            }
+            s_part[gl][comp] = sum;
         }
-        if (tid < 12) s_red[0][tid] = sum;
+        __syncthreads();
+        if (tid < 12) {
+            float tot = 0.f;
+            for (int k = 0; k < 21; ++k) tot += s_part[k][tid];
+            s_red[0][tid] = tot;
+        }
     }
     __syncthreads();
     if (tid == 0) {

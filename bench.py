@@ -107,6 +107,30 @@ def load_counters(name, config):
     return j[config], j.get("note", "")
 
 
+def usable_cpus():
+    """(threads worth running, facts): the CPUs this process may actually use -- the affinity mask cut down to the container's CPU-time
+    quota (cgroup v2 cpu.max / v1 cfs_quota): on a box whose container is capped at 16 CPUs' worth of time, 128 OpenMP threads only
+    time-slice (measured: the oracle's step 2.4x slower on 128 threads than on 16, profiles/tools/cpu_scaling.py)."""
+    facts = {"logical_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_quota_cpus": None}
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    facts["cgroup_quota_cpus"] = quota
+    n = facts["affinity"]
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, facts
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -486,7 +510,9 @@ def main():
                 n += nb
             return n / (time.perf_counter() - c0), n // nb
 
-        nthreads = oracle.num_threads()
+        nthreads, cpu_facts = usable_cpus()
+        nthreads = min(nthreads, oracle.num_threads()) if oracle.num_threads() > 1 else 1
+        oracle.set_threads(nthreads)
         rate_all, n_all = cpu_rate(B, args.cpu_seconds)
         single = None
         if args.cpu_single_seconds > 0:
@@ -495,7 +521,7 @@ def main():
             oracle.set_threads(nthreads)
             single = {"value": round(rate_1, 3), "cores": 1, "sample": "%d steps of the full batch of %d images" % (n_1, B)}
         cpu = {"value": round(rate_all, 2), "unit": "images/s", "cores": nthreads, "kind": "port", "cpu_model": cpu_model(),
-               "single_thread": single, "thread_scaling": None if not single else round(rate_all / rate_1, 1),
+               "single_thread": single, "thread_scaling": None if not single else round(rate_all / rate_1, 1), "host": cpu_facts,
                "sample": "%d steps of the full batch of %d images (%s, %dx%d), render+loss+backward; OpenMP over (image, row) in the forward and "
                          "(image, band of rows) with band-private accumulators in the backward's scatters; "
                          "CPU restatement of the kaolin DIB-R semantics, not kaolin" % (n_all, B, name, H, W)}

@@ -1,5 +1,6 @@
 // mm_abi.hip -- extern "C" entry points of libmm_render.so (declared in include/mm_render.h): argument validation,
 // workspace carving and launch sequencing.  No allocation, no host synchronisation, no global state.
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include "mm_device.h"
@@ -50,7 +51,7 @@ size_t mm_query_workspace(const MMRenderDesc* d) {
 int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
     int st = check_render(d, false);
     if (st != MM_OK) return st;
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt);
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     mm::clear_stale_error();
     st = mm::launch_vertex_fwd(d, w, s);
@@ -62,7 +63,7 @@ int mm_render_fused_loss(const MMRenderDesc* d, mm_stream_t stream) {
     int st = check_render(d, false);
     if (st != MM_OK) return st;
     if (!d->fused_gt || !d->fused_loss) return MM_ERR_NULL_POINTER;
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt);
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
     mm::clear_stale_error();
     return mm::launch_fused_loss(d, w, (hipStream_t)stream);
 }
@@ -73,7 +74,21 @@ int mm_debug_workspace_layout(const MMRenderDesc* d, size_t* out5) {
     out5[0] = (size_t)((char*)w.chunkmap - (char*)nullptr); out5[1] = (size_t)((char*)w.items - (char*)nullptr);
     out5[2] = (size_t)((char*)w.nitems - (char*)nullptr); out5[3] = (size_t)((char*)w.part - (char*)nullptr); out5[4] = (size_t)w.item_cap;
     out5[5] = (size_t)((char*)w.gp - (char*)nullptr); out5[6] = (size_t)((char*)w.gp2 - (char*)nullptr); out5[7] = (size_t)((char*)w.soft - (char*)nullptr);
+    out5[8] = (size_t)((char*)w.tcnt - (char*)nullptr); out5[9] = (size_t)w.ntiles; out5[10] = (size_t)w.trcap; out5[11] = (size_t)((char*)w.trcnt - (char*)nullptr);
     return MM_OK;
+}
+
+int mm_render_status(const MMRenderDesc* d, mm_stream_t stream, int32_t* dropped_host) {
+    if (!d) return MM_ERR_NULL_POINTER;                            // (only the shape and the workspace are looked at)
+    if (d->B <= 0 || d->V <= 0 || d->F <= 0 || d->H <= 0 || d->W <= 0 || d->Ht <= 0 || d->Wt <= 0) return MM_ERR_BAD_SHAPE;
+    if (!d->workspace || d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_BAD_SHAPE;
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
+    std::vector<int32_t> h((size_t)d->B);
+    if (hipMemcpyAsync(h.data(), w.tstatus, (size_t)d->B * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return MM_ERR_LAUNCH;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MM_ERR_LAUNCH;
+    bool any = false;
+    for (int b = 0; b < d->B; ++b) { any = any || h[b] != 0; if (dropped_host) dropped_host[b] = h[b]; }
+    return any ? MM_ERR_WORKSPACE : MM_OK;
 }
 
 int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {
@@ -83,7 +98,7 @@ int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_
         !g->grad_elevations || !g->grad_distances || !g->grad_biases)
         return MM_ERR_NULL_POINTER;
     if (d->no_mask && !g->grad_bg) return MM_ERR_NULL_POINTER;
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt);
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     mm::clear_stale_error();
     st = mm::launch_raster_bwd(d, g, w, s);

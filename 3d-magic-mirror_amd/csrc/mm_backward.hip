@@ -178,23 +178,16 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s
     int b, T;
     map_block(block, a.B, ntiles, b, T);
     const int tid = threadIdx.x;
-    // the record count and every thread's first record are requested together, before the accumulators are cleared: one trip
-    // to memory instead of two for the (usual) tile with at most 256 records.  The slot always exists; it is only USED if
-    // it lies below the count.
     const int tx0 = (T % a.ntx) * MM_TS, ty0 = (T / a.ntx) * MM_TS;
-    const TexRecord* recs = a.trec + ((size_t)b * ntiles + T) * MM_TREC_CAP;
     MM_PP_BEGIN();
-    const int nrec = a.tcnt[(size_t)b * ntiles + T];
-    const TexRecord first = recs[tid];
-    const int ncap = min(nrec, MM_TREC_CAP);
-    int nsp = 0;
-    const TexSpill* sp = a.tspill + (size_t)b * 4 * a.H * a.W;
-    if (nrec > MM_TREC_CAP) nsp = a.tcnt[(size_t)a.B * ntiles + b];   // the list was full: the tile's other records are in the image's spill list
+    const int nall = a.tcur[(size_t)b * ntiles + T], off = a.toff[(size_t)b * ntiles + T] - 1;
+    const int dropped = a.tpool[b * 2 + 1];                       // records of the image its array had no room for (pixel_bwd)
+    const int nrec = max(0, min(nall, a.trcap - off));           // (the list is cut where the array ends)
+    const TexRecord* recs = a.trec + (size_t)b * a.trcap + off;
     MM_PP_MARK(0);
     // largest contribution of the tile's records (first pass; the second one below re-reads them from L2)
-    float mx = tid < ncap ? tex_record_max(first) : 0.f;
-    for (int r = tid + 256; r < ncap; r += 256) mx = fmaxf(mx, tex_record_max(recs[r]));
-    for (int r = tid; r < nsp; r += 256) if (sp[r].tile == T) mx = fmaxf(mx, tex_record_max(sp[r].r));
+    float mx = 0.f;
+    for (int r = tid; r < nrec; r += 256) mx = fmaxf(mx, tex_record_max(recs[r]));
     mx = wave_max(mx);
     if ((tid & 63) == 0) s_max[tid >> 6] = mx;
     for (int i = tid; i < 3 * MM_TS * MM_TS / 4; i += 256) ((int4*)&s_acc[0][0])[i] = make_int4(0, 0, 0, 0);   // (16-byte LDS stores)
@@ -205,13 +198,15 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s
     if (mx > 0.f && mx < INFINITY) {                             // workgroup-uniform; nothing to add up otherwise (about half of all tiles)
         int e;
         (void)frexpf((float)nrec * mx, &e);                      // records * max < 2^e
-        const int k = min(max(30 - e, -100), 120);
-        const float scale = ldexpf(1.f, k);
-        inv = ldexpf(1.f, -k);
-        if (tid < ncap) tex_accumulate(a, s_acc, first, tx0, ty0, scale);
-        for (int r = tid + 256; r < ncap; r += 256) tex_accumulate(a, s_acc, recs[r], tx0, ty0, scale);
-        for (int r = tid; r < nsp; r += 256) if (sp[r].tile == T) tex_accumulate(a, s_acc, sp[r].r, tx0, ty0, scale);
+        const int k2 = min(max(30 - e, -100), 120);
+        const float scale = ldexpf(1.f, k2);
+        inv = ldexpf(1.f, -k2);
+        for (int r = tid; r < nrec; r += 256) tex_accumulate(a, s_acc, recs[r], tx0, ty0, scale);
         __syncthreads();
+    }
+    if (dropped != 0) {                                          // the image lost records: its texture gradient is NOT a gradient -- say so in every texel
+        inv = __builtin_nanf("");
+        if (T == 0 && tid == 0) a.tstatus[b] = dropped;
     }
     MM_PP_MARK(2);
     MM_PP_COUNT(nrec, 0);
@@ -455,8 +450,8 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.grad_rgba = g->grad_rgba;   // (face flags: only the compacting walk of the forward sets them)
     a.gp = w.gp; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.ticket = w.ticket;
-    a.tcnt = w.tcnt; a.trec = w.trec; a.tspill = w.tspill; a.ntiles_ = w.ntiles;
-    a.gmax = (unsigned*)(w.tcnt + (size_t)d->B * w.ntiles + d->B);    // (B, MM_GSHARD, 8): two maxima per 32-byte sector
+    a.tcur = w.tcur; a.tpool = w.tpool; a.trcnt = w.trcnt; a.toff = w.toff; a.tstatus = w.tstatus; a.trec = w.trec; a.ntiles_ = w.ntiles; a.trcap = w.trcap;
+    a.gmax = w.gmax;                                             // (B, MM_GSHARD, 8): two maxima per 32-byte sector
     a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
     a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
     a.items = w.items; a.nitems = w.nitems; a.part = w.part; a.item_cap = w.item_cap;

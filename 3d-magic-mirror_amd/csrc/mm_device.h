@@ -48,11 +48,10 @@ __host__ __device__ inline int bin_shift_for(int H, int W, int F) {
 // One covered pixel's contribution to the texture gradient, appended by the pixel backward to the list of every texture
 // tile its bilinear footprint touches; the tile's workgroup streams its list (no search, no atomics on HBM).
 struct TexRecord { unsigned xy; float tx, ty, d0, d1, d2; };       // xy = x0 | y0 << 16 (top-left texel)
-struct TexSpill { TexRecord r; int tile; int pad; };
-#ifndef MM_TREC_CAP
-#define MM_TREC_CAP 2048      // records per tile; further records of a full tile go to the image's spill list
-#endif
-
+// The lists of an image are PACKED into one array: the forward counts, per tile, the covered pixels whose footprint touches it (raster_fwd's
+// epilogue: an upper bound of the records, exact when no texture gradient is zero), every workgroup of the pixel backward turns the counts
+// into the tiles' offsets (the plan workgroup of the image: mm_pixel_bwd.hip), and a tile's records go to [offset, offset + count).  Nothing is sized per tile -- the visible
+// surface lands in a few tiles of the texture (a close-up puts four fifths of an image's records into one of 128).
 // which form of the forward walk a shape gets (mm_raster_walk.h): the compacting queue (+ the face flags the backward's sweep plan reads) for
 // screen bins larger than a tile, the per-batch walk for 8-pixel bins; MM_OPT_WALK_QUEUE / MM_OPT_WALK_BATCH force one (identical results)
 inline bool walk_queue_mode(int options, int bin_shift) {
@@ -87,11 +86,18 @@ struct Workspace {
                            //            own box, not over the box inflated by the silhouette margin (cleared by vertex_fwd, set by raster_fwd)
     long long* ltot;       // (B,MM_LSUB,4) fused loss: per image {sum|pi-gi|, sum p*g, sum p+g-p*g, -} in 2^-32 fixed point, spread over
                            //            MM_LSUB sub-accumulators (64-bit integer atomics of the raster waves: exact, order-free); zeroed by vertex_fwd
-    int* tcnt;             // (B,ntiles)+(B)+(B,MM_GSHARD,8) records appended per texture tile, per-image spill counts, per-image maxima of the pixel
-                           //            backward (float bits: max |K2 number|, max |dL/dalpha|); zeroed by the vertex stage of the forward and by every
-                           //            vertex backward for the next one
-    TexRecord* trec;       // (B,ntiles,MM_TREC_CAP)
-    TexSpill* tspill;      // (B,4*H*W)   records of tiles whose list is full (worst case: every pixel, 2x2 tiles)
+    int* tcnt;             // the counters of the backward, ntcnt ints in all, zeroed by the vertex stage of the forward and by every vertex backward for the
+    int ntcnt;             //            next one: tcur, toff, tpool, gmax (below), in this order
+    int* tcur;             // (B,ntiles) records appended to a texture tile's list so far (pixel_bwd)
+    int* tpool;            // (B,2)      per image {-, records dropped: the packed array was full}
+    unsigned* gmax;        // (B,MM_GSHARD,8) per-image maxima of the pixel backward (float bits: max |K2 number|, max |dL/dalpha|)
+    int* tstatus;          // (B)        records dropped by the last backward: zeroed by vertex_fwd, set by the texture gather, which also poisons the
+                           //            image's texture gradient with NaN (mm_render_status reads it)
+    int* trcnt;            // (B,ntiles) covered pixels whose bilinear footprint touches the tile: zeroed by vertex_fwd, counted by raster_fwd
+    int* toff;             // (B,ntiles) 1 + offset of the tile's list in the image's record array (pixel_bwd's plan workgroup of the image; 0 = not yet)
+    TexRecord* trec;       // (B,trcap)  the images' record arrays.  trcap = 9/8 H W by default -- every pixel covered and one footprint in eight across
+                           //            a tile border; a larger workspace_bytes enlarges it
+    int trcap;
     int2* chunkmap;        // (B,F)      {first sweep item, number of items} of every face (plan kernel, every forward)
     int2* items;           // (B,item_cap) sweep items {face, chunk of its box}
     int2* nitems;          // (B)        {items listed, pixels per chunk in this image (MM_CHUNK_PX << k)}
@@ -106,7 +112,8 @@ struct Workspace {
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-__host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, int F, int H, int W, int Ht, int Wt) {
+// avail: bytes the caller really has (0 = the minimum, what mm_query_workspace reports): what is beyond the minimum goes to the record pool
+__host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, int F, int H, int W, int Ht, int Wt, size_t avail = 0) {
     Workspace w;
     char* p = (char*)base;
     size_t o = 0;
@@ -132,14 +139,27 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.bincount = (int*)(p + o);     o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
     w.fflag = (int*)(p + o);        o += align256((size_t)B * F * 2 * sizeof(int));   // (ints, not bytes: a byte store may alias every later load in the compiler's eyes)
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
-    w.tcnt = (int*)(p + o);         o += align256(((size_t)B * w.ntiles + (size_t)B + (size_t)B * MM_GSHARD * 8) * sizeof(int));
-    w.tspill = (TexSpill*)(p + o);  o += align256((size_t)B * 4 * H * W * sizeof(TexSpill));
-    w.trec = (TexRecord*)(p + o);   o += align256((size_t)B * w.ntiles * MM_TREC_CAP * sizeof(TexRecord));
+    w.ntcnt = (int)((size_t)B * w.ntiles * 2 + (size_t)B * 2 + (size_t)B * MM_GSHARD * 8);
+    w.tcnt = (int*)(p + o);         o += align256(((size_t)w.ntcnt + B + (size_t)B * w.ntiles) * sizeof(int));
+    w.tcur = w.tcnt;
+    w.toff = w.tcur + (size_t)B * w.ntiles;
+    w.tpool = w.toff + (size_t)B * w.ntiles;
+    w.gmax = (unsigned*)(w.tpool + (size_t)B * 2);
+    w.tstatus = w.tcnt + w.ntcnt;
+    w.trcnt = w.tstatus + B;
     w.item_cap = F + (int)(((size_t)16 * H * W + MM_CHUNK_PX - 1) / MM_CHUNK_PX);
     w.chunkmap = (int2*)(p + o);    o += align256((size_t)B * F * sizeof(int2));
     w.items = (int2*)(p + o);       o += align256((size_t)B * w.item_cap * sizeof(int2));
     w.nitems = (int2*)(p + o);      o += align256((size_t)B * sizeof(int2));
     w.part = (float*)(p + o);       o += align256((size_t)B * w.item_cap * 12 * sizeof(float));
+    w.trec = (TexRecord*)(p + o);                                 // (last: the record arrays take what the caller gives beyond the minimum)
+    const size_t rc_min = ((size_t)H * W * 9 / 8 + 255) & ~(size_t)255;
+    size_t rc = rc_min;
+    const size_t need = o + align256((size_t)B * rc_min * sizeof(TexRecord));
+    if (avail > need) rc += (avail - need) / ((size_t)B * sizeof(TexRecord));
+    if (rc > ((size_t)1 << 30)) rc = (size_t)1 << 30;
+    w.trcap = (int)rc;
+    o += align256((size_t)B * rc_min * sizeof(TexRecord));
     w.bytes = o;
     return w;
 }
@@ -524,15 +544,16 @@ __device__ inline int wave_prefix_excl(int v, int lane, int& total) {
 // transpose turns the 64 faces' coverage words into the 64 bins' mask words, stored plainly -- every word of every bin is
 // written (blocks no face touches skip the transpose): no atomics, no zero-fill, no second pass over the face records.
 // The raster kernel re-tests every (pixel, face) pair exactly, so a conservative mask changes no result.
+//   s_part / s_parts: this call handles block  s  iff  s % s_parts == s_part  (the blocks of a big screen are dealt to several workgroups)
 __device__ inline void bin_wave_faces(uint64_t* mask, int b, int nbx, int nby, int words, int bin_shift, int c, int lane,
-                                      int bx0, int by0, int bw, int bh) {
+                                      int bx0, int by0, int bw, int bh, int s_part = 0, int s_parts = 1) {
     int c0 = 0, c1 = -1, r0 = 0, r1 = -1;                         // bin columns / rows the box touches (none)
     if (bw > 0 && bh > 0) {
         c0 = bx0 >> bin_shift; c1 = (bx0 + bw - 1) >> bin_shift;
         r0 = by0 >> bin_shift; r1 = (by0 + bh - 1) >> bin_shift;
     }
     const int sbx = (nbx + 7) >> 3, sby = (nby + 7) >> 3;
-    for (int s = 0; s < sbx * sby; ++s) {
+    for (int s = s_part; s < sbx * sby; s += s_parts) {
         const int kx0 = (s % sbx) * 8, ky0 = (s / sbx) * 8;
         const int clo = max(c0 - kx0, 0), chi = min(c1 - kx0, 7), rlo = max(r0 - ky0, 0), rhi = min(r1 - ky0, 7);
         const unsigned col = chi >= clo ? ((2u << chi) - (1u << clo)) : 0u;       // bits clo..chi

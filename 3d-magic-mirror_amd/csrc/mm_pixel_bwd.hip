@@ -27,6 +27,27 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
     // ceil(ceil(n / c) / 2^k) = ceil(n / (c 2^k)): the doubled chunk sizes need nothing else.
     __shared__ unsigned short s_nch[MM_PLAN_LDS_FACES];
     const int tid = threadIdx.x;
+    // First (the pixel workgroups behind this one in the grid want it two trips to memory into their lives): where each texture tile's record list
+    // starts in the image's packed array = exclusive scan of the forward's per-tile counts.  Stored + 1: the words are zero until now (cleared with
+    // the backward's counters), which is how a pixel lane that got there first knows to ask again.
+    if (q == 0) {
+        const int nt = a.ntiles_, per4 = (nt + 255) >> 8, t0 = tid * per4;
+        const int* cnt = a.trcnt + (size_t)b * nt;
+        int mine = 0;
+        for (int i = 0; i < per4; ++i) mine += t0 + i < nt ? cnt[t0 + i] : 0;
+        int tot;
+        int run = wave_prefix_excl(mine, tid & 63, tot);
+        if ((tid & 63) == 0) s_wave[0][tid >> 6] = tot;
+        __syncthreads();
+        for (int w2 = 0; w2 < (tid >> 6); ++w2) run += s_wave[0][w2];
+        for (int i = 0; i < per4; ++i) {
+            if (t0 + i < nt) {
+                __hip_atomic_store(a.toff + (size_t)b * nt + t0 + i, run + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                run += cnt[t0 + i];
+            }
+        }
+        __syncthreads();                                         // (s_wave is used again below)
+    }
     const bool staged = a.F <= MM_PLAN_LDS_FACES;                 // (more faces than that: the counts are re-read from the face records)
     auto box_px = [&](int f) {                                   // pixels of the face's sweep box; 0: the box misses the image, or no pixel refers to the face
         const float4 q2 = a.geo[((size_t)b * a.F + f) * 3 + 2];   //  (most faces of a fine, overlapping mesh: nothing to sweep)
@@ -114,7 +135,6 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     const size_t hw = (size_t)a.H * a.W, pin = (size_t)py * a.W + px;
     const size_t pix = (size_t)b * hw + pin;
     if (blk == 0 && threadIdx.x == 0) a.ticket[b] = 0u;           // arrival counter of the vertex backward, used after this kernel
-
     // The pass is a chain of dependent trips to memory; it is written so that four remain: (1) everything addressed by the pixel
     // alone -- face_idx, prediction, ground truth, background; (2) what the winner's id addresses -- geometry, normal, corner uvs;
     // (3) the twelve texels, unconditionally from clamped addresses; (4) the record-slot atomics.  (Loads left inside per-lane
@@ -310,13 +330,15 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
             }
         }
     }
-    // append the records: one returning atomic per (wave, distinct tile), lanes of the same tile take consecutive slots.
-    // The grouping is pure lane arithmetic; all leaders then issue their atomics in ONE instruction per footprint corner
-    // (and the four corners' atomics are in flight together), so a wave pays one fabric round trip, not one per tile.
-    int leader[4], rank[4], base[4];
+    // append the records: one returning atomic per (wave, distinct tile), lanes of the same tile take consecutive slots of the tile's list, which
+    // starts at the tile's offset in the image's packed record array -- read by the group's leader in the same trip as its atomic (written by the
+    // image's plan workgroup at the top of its life, + 1: a zero means "not yet", the first microseconds of the launch, and is asked for again).
+    // The grouping is pure lane arithmetic; all leaders then issue their atomics in ONE instruction per footprint corner (and the four corners'
+    // atomics are in flight together), so a wave pays one fabric round trip, not one per tile.
+    int leader[4], rank[4], base[4], toff[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        leader[c] = -1; rank[c] = 0; base[c] = 0;
+        leader[c] = -1; rank[c] = 0; base[c] = 0; toff[c] = 1;
         if (!any_covered) continue;                              // wave-uniform: nothing to append
         int size = 0;
         unsigned long long pending = __ballot(rtile[c] >= 0);
@@ -327,22 +349,32 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
             if (rtile[c] == tile) { leader[c] = ld; rank[c] = ballot_rank(m); size = __popcll(m); }
             pending &= ~m;
         }
-        if (leader[c] == lane) base[c] = atomicAdd(a.tcnt + (size_t)b * a.ntiles_ + rtile[c], size);
+        if (leader[c] == lane) {
+            toff[c] = __hip_atomic_load(a.toff + (size_t)b * a.ntiles_ + rtile[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base[c] = atomicAdd(a.tcur + (size_t)b * a.ntiles_ + rtile[c], size);
+        }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (!any_covered) break;
+        while (__builtin_expect(leader[c] == lane && toff[c] == 0, 0)) {
+            __builtin_amdgcn_s_sleep(2);
+            toff[c] = __hip_atomic_load(a.toff + (size_t)b * a.ntiles_ + rtile[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        base[c] += toff[c] - 1;
+    }
+    int ndrop = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (!any_covered) break;
         const int bs = __shfl(base[c], leader[c] < 0 ? lane : leader[c], 64);
         if (rtile[c] >= 0) {
-            const int slot = bs + rank[c];
-            if (slot < MM_TREC_CAP) a.trec[((size_t)b * a.ntiles_ + rtile[c]) * MM_TREC_CAP + slot] = rec;
-            else {                                               // full tile (rare): the image's spill list
-                const int os = atomicAdd(a.tcnt + (size_t)a.B * a.ntiles_ + b, 1);
-                TexSpill sp; sp.r = rec; sp.tile = rtile[c]; sp.pad = 0;
-                a.tspill[(size_t)b * 4 * a.H * a.W + os] = sp;
-            }
+            const int pos = bs + rank[c];
+            if (pos < a.trcap) a.trec[(size_t)b * a.trcap + pos] = rec;
+            else ++ndrop;                                        // the image's array is full: counted, and the texture gather poisons the image's gradient
         }
     }
+    if (__builtin_expect(__ballot(ndrop != 0) != 0ull, 0)) { if (ndrop) atomicAdd(a.tpool + b * 2 + 1, ndrop); }
 
     // d lights: wave butterfly -> one LDS row per wave -> fixed-order partial of this workgroup (summed by vertex_bwd)
     float dl[9];

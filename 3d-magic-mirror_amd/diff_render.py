@@ -85,7 +85,7 @@ class _RenderFn(torch.autograd.Function):
                 raise RuntimeError("gt_data must be (B,4,%d,%d), got %s" % (H, W, tuple(gt.shape)))
             loss = torch.empty((), device=dev, dtype=torch.float32)
             d.fused_gt, d.fused_image_weight, d.fused_loss = N.ptr(gt), float(dr.image_weight), N.ptr(loss)
-        nbytes = N.lib().mm_query_workspace(ctypes.byref(d))
+        nbytes = dr.workspace_bytes(d)
         holder = _PooledWorkspace(dr._ws_pool, (str(dev), nbytes), nbytes, dev)
         ws = holder.buf
         d.workspace, d.workspace_bytes = N.ptr(ws), ws.numel()
@@ -134,6 +134,8 @@ class _RenderFn(torch.autograd.Function):
         g = N.MMRenderGrads(None if ctx.fused else N.ptr(g_rgba), N.ptr(g_fn), N.ptr(gv), N.ptr(gt_), N.ptr(gl), N.ptr(gbg), N.ptr(ga), N.ptr(ge), N.ptr(gd), N.ptr(gb))
         with torch.cuda.device(dev):
             N.check(N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), N.current_stream(dev)), "mm_render_backward")
+            if ctx.dr.check_texture_records:                     # (synchronises: a diagnostic switch)
+                ctx.dr.check_records(d, N.current_stream(dev))
         return None, None, None, None, gv, gt_, gl, gbg, ga, ge, gd, gb
 
 
@@ -206,6 +208,11 @@ class DiffRender(object):
         self.ratio = ratio
         self.emit_imnormal = emit_imnormal
         self.options = 0                                # MMRenderDesc.options: MM_OPT_* bits (SURVEY Appendix C switches); 0 = defaults
+        # The render workspace is the library's minimum (mm_query_workspace) plus room for this many MORE texture-gradient records per pixel
+        # than the 9/8 the minimum holds (include/mm_render.h); an image that runs out gets NaN texture gradients, and with
+        # check_texture_records every backward of the class API asks the library (a stream synchronisation) and raises instead.
+        self.extra_texture_records_per_pixel = 0.0
+        self.check_texture_records = False
         camera_fovy = np.arctan(1.0 / 2.5) * 2
         self.cam_proj = template.generate_perspective_projection(camera_fovy, ratio=1 / ratio)     # networks.py:172-174
         mesh = obj_io.load_template(mesh_name)                                                   # :176
@@ -261,9 +268,26 @@ class DiffRender(object):
                           vertices, textures, lights, bg, azimuths, elevations, distances, biases, gt, bool(self.emit_imnormal),
                           float(self.image_weight), torch._C._cuda_getCurrentRawStream(dev.index))
 
+    def workspace_bytes(self, d):
+        """Bytes of the render workspace for the shape in MMRenderDesc `d`: the library's minimum + the extra record pool asked for."""
+        extra = int(np.ceil(max(0.0, float(self.extra_texture_records_per_pixel)) * d.H * d.W)) * 24 * d.B
+        return int(N.lib().mm_query_workspace(ctypes.byref(d))) + extra
+
+    @staticmethod
+    def check_records(d, stream):
+        """Raise if the last mm_render_backward on MMRenderDesc `d` dropped texture-gradient records (synchronises `stream`)."""
+        dropped = (ctypes.c_int32 * d.B)()
+        st = N.lib().mm_render_status(ctypes.byref(d), stream, dropped)
+        if st != 0 and not any(dropped):
+            N.check(st, "mm_render_status")
+        if st != 0:
+            raise RuntimeError("mm_render_backward: the texture-record pool overflowed (records dropped per image: %s); the texture gradients of those "
+                               "images are NaN. Raise DiffRender.extra_texture_records_per_pixel." % (list(dropped),))
+
     def _proto(self, st, B, no_mask, Ht, Wt):
         """(bytes of the MMRenderDesc prototype of this shape, its workspace size) for the C++ host path; cached like _desc's prototypes."""
-        key = ("bytes", id(st), B, int(bool(no_mask)), Ht, Wt, self.knum, self.sigmainv, self.boxlen, self.multiplier, self.eps, self.options)
+        key = ("bytes", id(st), B, int(bool(no_mask)), Ht, Wt, self.knum, self.sigmainv, self.boxlen, self.multiplier, self.eps, self.options,
+               float(self.extra_texture_records_per_pixel))
         hit = self._desc_cache.get(key)
         if hit is None:
             d = N.MMRenderDesc()
@@ -276,7 +300,7 @@ class DiffRender(object):
             d.faces, d.face_uvs = N.ptr(st["faces"]), N.ptr(st["face_uvs"])
             d.vc_table, d.vc_stride = N.ptr(st["vc_table"]), int(st["vc_table"].shape[1])
             d.options = self.options
-            hit = (bytes(d), N.lib().mm_query_workspace(ctypes.byref(d)))
+            hit = (bytes(d), self.workspace_bytes(d))
             if len(self._desc_cache) > 32:
                 self._desc_cache.clear()
             self._desc_cache[key] = hit

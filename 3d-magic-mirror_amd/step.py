@@ -60,7 +60,7 @@ class RenderLossStep:
         i = self.inp
         self.d = dr._desc(st, B, no_mask, i["vertices"], i["textures"], i["lights"], i["bg"] if no_mask else None, i["azimuths"],
                           i["elevations"], i["distances"], i["biases"], self.rgba, self.face_idx, self.face_normals, self.imnormal)
-        self.ws = torch.empty(N.lib().mm_query_workspace(ctypes.byref(self.d)), device=dev, dtype=torch.uint8)
+        self.ws = torch.empty(dr.workspace_bytes(self.d), device=dev, dtype=torch.uint8)
         self.d.workspace, self.d.workspace_bytes = N.ptr(self.ws), self.ws.numel()
         self.grad_rgba = torch.empty_like(self.rgba)
         self.grads = {k: (torch.empty_like(v) if v is not None and (k != "bg" or no_mask) else None) for k, v in self.inp.items()}
@@ -138,6 +138,12 @@ class RenderLossStep:
         if not self.fused:
             N.check(L.mm_recon_data_backward(ctypes.byref(self.r), s), "mm_recon_data_backward")
         N.check(L.mm_render_backward(ctypes.byref(self.d), ctypes.byref(self.g), s), "mm_render_backward")
+
+    def dropped_records(self, stream=None):
+        """Per-image counts of texture-gradient records the last backward had no room for (mm_render_status; synchronises)."""
+        out = (ctypes.c_int32 * self.d.B)()
+        N.lib().mm_render_status(ctypes.byref(self.d), ctypes.c_void_p((stream or torch.cuda.current_stream(self.dev)).cuda_stream), out)
+        return list(out)
 
     def capture(self):
         """Capture run() into a HIP graph (torch.cuda.CUDAGraph is only the capture/replay plumbing)."""

@@ -132,16 +132,28 @@ typedef struct MMRenderGrads {
     float* grad_biases;              /* (B,2) */
 } MMRenderGrads;
 
+/* The MINIMUM workspace for the shape.  Everything in it is sized for the worst case except the pool of texture-gradient records
+ * (one per covered pixel and texture tile under its bilinear footprint), which holds 9/8 records per pixel: a fully covered image
+ * with one footprint in eight across a tile border.  A workspace_bytes above the minimum is used: the excess enlarges the images'
+ * record arrays (24 bytes per record and image).  An image that still runs out (texture coordinates that put most pixels on the
+ * corners of 32x32-texel tiles) gets NaN in ALL of its grad_textures texels -- never a silently short sum -- and mm_render_status
+ * says how many records were dropped. */
 size_t mm_query_workspace(const MMRenderDesc* desc);
 int mm_render_forward(const MMRenderDesc* desc, mm_stream_t stream);
 int mm_render_backward(const MMRenderDesc* desc, const MMRenderGrads* grads, mm_stream_t stream);
+/* After mm_render_backward and before the next mm_render_forward on the same workspace: copies the per-image counts of dropped
+ * texture-gradient records to dropped_host (B ints, may be NULL) and returns MM_OK if all are zero, MM_ERR_WORKSPACE otherwise.
+ * The one entry point that SYNCHRONISES the stream (a diagnostic, not part of a step). */
+int mm_render_status(const MMRenderDesc* desc, mm_stream_t stream, int32_t* dropped_host);
 /* Fused mode only (desc->fused_gt and desc->fused_loss set), after mm_render_forward: writes the recon_data value of the batch
  * (networks.py:364-390, contour = 0) to desc->fused_loss from the sums the forward left in the workspace -- for callers that need
  * the loss before they run the backward (the autograd API DiffRender.render_recon).  mm_render_backward writes the same value. */
 int mm_render_fused_loss(const MMRenderDesc* desc, mm_stream_t stream);
 /* Tools only (profiles/tools): byte offsets inside the render workspace of out[0] = chunkmap (B,F) int2, out[1] = sweep items (B,item_cap)
  * int2, out[2] = nitems (B) int2, out[3] = per-item partial sums (B,item_cap,12) float; out[4] = item_cap; out[5] = gp (B,H,W,2) float4,
- * out[6] = gp2 (B,H,W) float, out[7] = soft (B,H,W) float2.  Returns 0, or MM_ERR_*. */
+ * out[6] = gp2 (B,H,W) float, out[7] = soft (B,H,W) float2, out[8] = per-texture-tile record counts of the last backward (B,ntiles) int
+ * followed by the list offsets + 1 (B,ntiles) and {-, records dropped} (B,2); out[9] = ntiles; out[10] = records an image's array holds;
+ * out[11] = the forward's per-tile footprint counts (B,ntiles) int.  `out` has room for 16 values.  Returns 0, or MM_ERR_*. */
 int mm_debug_workspace_layout(const MMRenderDesc* desc, size_t* out8);
 
 /* --------------------------------------------------------------------------------------------------------------------

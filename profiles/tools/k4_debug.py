@@ -97,7 +97,7 @@ N = pkg._native
 A3 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}
 st = stepmod.RenderLossStep(dr, A3, gt.to(dev), no_mask=no_mask, fused=True)
 st.run(); torch.cuda.synchronize()
-lay = (ctypes.c_size_t * 8)()
+lay = (ctypes.c_size_t * 16)()
 N.lib().mm_debug_workspace_layout.argtypes = [ctypes.POINTER(N.MMRenderDesc), ctypes.POINTER(ctypes.c_size_t)]
 assert N.lib().mm_debug_workspace_layout(ctypes.byref(st.d), lay) == 0
 ws = st.ws.cpu().numpy()

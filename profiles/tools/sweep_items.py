@@ -15,7 +15,7 @@ for cfg in (sys.argv[1:] or ["config5"]):
         att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=0)
         st = stepmod.RenderLossStep(dr, {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}, gt.to(dev), fused=True)
         st.run(); torch.cuda.synchronize()
-        out = (ctypes.c_size_t * 8)()
+        out = (ctypes.c_size_t * 16)()
         assert N.lib().mm_debug_workspace_layout(ctypes.byref(st.d), out) == 0
         ni = st.ws[out[2]:out[2] + B * 8].view(torch.int32).reshape(B, 2).cpu().numpy()
         cm = st.ws[out[0]:out[0] + B * dr.num_faces * 8].view(torch.int32).reshape(B, dr.num_faces, 2).cpu().numpy()

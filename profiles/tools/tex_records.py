@@ -1,0 +1,33 @@
+"""Texture-gradient records per image and per 32x32-texel tile (what sizes Workspace::trec / tspill): one step per config with a library
+variant that leaves the counters in place (-DMM_DBG_KEEP_TCNT):   python profiles/tools/tex_records.py config2 config3 config5 market"""
+import sys, importlib, os, ctypes, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+bn = importlib.import_module("3d-magic-mirror_amd.build_native")
+var = os.path.join(os.path.dirname(bn.LIB), "libmm_keep.so")
+bn.build(out=var, extra_flags=["-DMM_DBG_KEEP_TCNT"])
+pkg = importlib.import_module("3d-magic-mirror_amd"); stepmod = importlib.import_module("3d-magic-mirror_amd.step"); N = pkg._native
+N.LIB_PATH = var
+bn.needs_build = lambda: False
+dev = torch.device("cuda:0")
+for cfg in (sys.argv[1:] or ["config2"]):
+    name, B, S, ratio = bench.CONFIGS[cfg]
+    dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio, emit_imnormal=False)
+    H, W = dr.render_height, dr.image_size
+    for seed in (0, 1):
+        att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=seed)
+        if seed == 1:                                             # a close-up: the object fills the frame
+            att["distances"] = att["distances"] * 0.55
+        st = stepmod.RenderLossStep(dr, {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}, gt.to(dev), fused=True)
+        st.run(); torch.cuda.synchronize()
+        out = (ctypes.c_size_t * 16)()
+        assert N.lib().mm_debug_workspace_layout(ctypes.byref(st.d), out) == 0
+        nt = int(out[9])
+        tc = st.ws[out[8]:out[8] + (2 * B * nt + 2 * B) * 4].view(torch.int32).cpu().numpy()
+        per = tc[:B * nt].reshape(B, nt); pool = tc[2 * B * nt:].reshape(B, 2)      # (counts | offsets + 1 | {-, dropped})
+        tot = per.sum(1)
+        print("%s seed %d | HW %d, %d tiles | records per image: mean %.0f max %d = %.2f of HW | per tile: mean of non-empty %.0f, p99 %d, max %d = %.2f of HW/ntiles | "
+              "tiles over 256: %.2f %%, over 1024: %.2f %% | array capacity %d; records dropped: %d" % (
+                  cfg, seed, H * W, nt, tot.mean(), tot.max(), tot.max() / (H * W), per[per > 0].mean(), np.percentile(per[per > 0], 99), per.max(),
+                  per.max() / (H * W / nt), 100.0 * (per > 256).mean(), 100.0 * (per > 1024).mean(), int(out[10]), pool[:, 1].sum()), flush=True)

@@ -354,6 +354,24 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
             base[c] = atomicAdd(a.tcur + (size_t)b * a.ntiles_ + rtile[c], size);
         }
     }
+    // (the slots are on their way: the wave's light-gradient sums are formed meanwhile, the records stored after them)
+    // d lights: wave butterfly -> one LDS row per wave -> fixed-order partial of this workgroup (summed by vertex_bwd)
+    float dl[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dl[i] = 0.f;
+    if (any_covered) {
+        float bnd9[9];
+        sh_bands(snx, sny, snz, bnd9);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dl[i] = wave_sum(dcs * bnd9[i]);
+    } else { dl[0] = wave_sum(dcs * MM_SH_C0); dl[6] = wave_sum(dcs * (0.f - MM_SH_C6B)); }     // the other seven are zero
+    m2 = wave_max(m2); m4 = wave_max(m4);
+    if (lane == 0) {
+        if (a.options & MM_OPT_SH_ORDER_XYZ) { const float tmp = dl[2]; dl[2] = dl[3]; dl[3] = tmp; }   // back to the user's light order
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s_dl[wave][i] = dl[i];
+        s_gm[wave][0] = m2; s_gm[wave][1] = m4;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (!any_covered) break;
@@ -376,23 +394,6 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     }
     if (__builtin_expect(__ballot(ndrop != 0) != 0ull, 0)) { if (ndrop) atomicAdd(a.tpool + b * 2 + 1, ndrop); }
 
-    // d lights: wave butterfly -> one LDS row per wave -> fixed-order partial of this workgroup (summed by vertex_bwd)
-    float dl[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) dl[i] = 0.f;
-    if (any_covered) {
-        float bnd9[9];
-        sh_bands(snx, sny, snz, bnd9);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) dl[i] = wave_sum(dcs * bnd9[i]);
-    } else { dl[0] = wave_sum(dcs * MM_SH_C0); dl[6] = wave_sum(dcs * (0.f - MM_SH_C6B)); }     // the other seven are zero
-    m2 = wave_max(m2); m4 = wave_max(m4);
-    if (lane == 0) {
-        if (a.options & MM_OPT_SH_ORDER_XYZ) { const float tmp = dl[2]; dl[2] = dl[3]; dl[3] = tmp; }   // back to the user's light order
-#pragma unroll
-        for (int i = 0; i < 9; ++i) s_dl[wave][i] = dl[i];
-        s_gm[wave][0] = m2; s_gm[wave][1] = m4;
-    }
     __syncthreads();
     if (threadIdx.x >= 64 && threadIdx.x < 66) {                 // non-negative floats order like their bit patterns: integer max, one atomic per
         const int k = threadIdx.x - 64;                          // workgroup and kind (NaN / inf gradients end up as an inf scale = zero sums)

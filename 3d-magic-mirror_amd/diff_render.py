@@ -254,7 +254,7 @@ class DiffRender(object):
     def _render_node(self, no_mask, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases):
         """One autograd node for the render (+ the fused loss if gt is given).  With lib/mm_torch_ext.so built, the node is C++
         (csrc/mm_torch_ext.cpp: no Python in the backward); otherwise the torch.autograd.Function above issues the same ABI calls."""
-        ext = N.torch_ext()
+        ext = None if self.check_texture_records else N.torch_ext()   # (the diagnostic switch lives in the Python nodes)
         if ext is None:
             return _RenderFn.apply(self, no_mask, self.emit_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases)
         N.require_device(azimuths)

@@ -176,11 +176,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         sys.stderr.write("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE\n" % (world, args.gpus))
+    # MM_BENCH_SHARE_GPU=1 + MM_BENCH_DIST_BACKEND=gloo: every rank on cuda:0 with a host-staged backend -- how tests/test_gpu_bench_ranks.py runs the
+    # N > 1 leg on a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    if os.environ.get("MM_BENCH_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("MM_BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("3d-magic-mirror_amd")
     stepmod = importlib.import_module("3d-magic-mirror_amd.step")

@@ -206,9 +206,16 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             for (int c = 0; c < 4; ++c) {
                 if (c < cm.y) { gx += pk[c][0]; gy += pk[c][1]; g[0] += pk[c][2]; g[1] += pk[c][3]; g[2] += pk[c][4]; }
             }
-            for (int c = 4; c < cm.y; ++c) {
-                gx += part[c * 12 + k * 2]; gy += part[c * 12 + k * 2 + 1];
-                g[0] += part[c * 12 + 6]; g[1] += part[c * 12 + 7]; g[2] += part[c * 12 + 8];
+            for (int c0 = 4; c0 < cm.y; c0 += 4) {                // (big faces -- a close-up, a crumpled fine mesh: four rows per trip here too)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float* pc4 = part + (size_t)min(c0 + c, cm.y - 1) * 12;
+                    pk[c][0] = pc4[k * 2]; pk[c][1] = pc4[k * 2 + 1]; pk[c][2] = pc4[6]; pk[c][3] = pc4[7]; pk[c][4] = pc4[8];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c0 + c < cm.y) { gx += pk[c][0]; gy += pk[c][1]; g[0] += pk[c][2]; g[1] += pk[c][3]; g[2] += pk[c][4]; }
+                }
             }
             // through face_vertices_image
             d[0] += gx * a.proj0 * ipz;
@@ -273,20 +280,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         __hip_atomic_store(a.dTpart + ((size_t)b * gridDim.x + blockIdx.x) * 12 + tid,
                            ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- publish, take a ticket; the last workgroup of this image finishes the camera chain
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the storing wave drains its stores before the ticket is drawn
-    __syncthreads();
-    MM_PP_MARK(2);
-    if (tid == 0) {
-        // No agent-scope fences here: a release fence writes back the XCD's whole L2 and an acquire invalidates it, once per
-        // workgroup (removing them took this kernel from 213 to 53 us at B=384).
-        const unsigned prev = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (prev == gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    MM_PP_MARK(3);
-    if (!s_last) { MM_PP_FLUSH(vertex_bwd, (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6)); return; }
-    {   // dL/dlights: sum of the pixel-backward workgroup partials; waves 1..3 take 3 components each, lanes stride over
+    if (blockIdx.x == 0) {   // dL/dlights (needs nothing of this kernel: the image's FIRST workgroup adds it up, off the last one's tail): sum of the pixel-backward workgroup partials; waves 1..3 take 3 components each, lanes stride over
         // the partials (independent loads), fixed butterfly order
         const int wv = tid >> 6, ln = tid & 63;
         if (wv >= 1) {
@@ -310,6 +304,19 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             }
         }
     }
+    // ---- publish, take a ticket; the last workgroup of this image finishes the camera chain
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the storing wave drains its stores before the ticket is drawn
+    __syncthreads();
+    MM_PP_MARK(2);
+    if (tid == 0) {
+        // No agent-scope fences here: a release fence writes back the XCD's whole L2 and an acquire invalidates it, once per
+        // workgroup (removing them took this kernel from 213 to 53 us at B=384).
+        const unsigned prev = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (prev == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    MM_PP_MARK(3);
+    if (!s_last) { MM_PP_FLUSH(vertex_bwd, (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6)); return; }
     MM_PP_MARK(4);
     if (tid >= 64 && tid < 100) reinterpret_cast<float*>(&s_cam)[tid - 64] = a.cam[b * 48 + tid - 64];   // the forward's camera (no trig here)
     {   // dL/dT = sum of the workgroups' partials in a FIXED order: thread (gl, comp) adds rows gl, gl + 21, gl + 42, ... of its component --

@@ -81,7 +81,8 @@ int mm_debug_workspace_layout(const MMRenderDesc* d, size_t* out5) {
 int mm_render_status(const MMRenderDesc* d, mm_stream_t stream, int32_t* dropped_host) {
     if (!d) return MM_ERR_NULL_POINTER;                            // (only the shape and the workspace are looked at)
     if (d->B <= 0 || d->V <= 0 || d->F <= 0 || d->H <= 0 || d->W <= 0 || d->Ht <= 0 || d->Wt <= 0) return MM_ERR_BAD_SHAPE;
-    if (!d->workspace || d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_BAD_SHAPE;
+    if (!d->workspace) return MM_ERR_NULL_POINTER;
+    if (d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_BAD_SHAPE;   // (MM_ERR_WORKSPACE is this call's "records were dropped")
     const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
     std::vector<int32_t> h((size_t)d->B);
     if (hipMemcpyAsync(h.data(), w.tstatus, (size_t)d->B * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return MM_ERR_LAUNCH;

@@ -544,16 +544,15 @@ __device__ inline int wave_prefix_excl(int v, int lane, int& total) {
 // transpose turns the 64 faces' coverage words into the 64 bins' mask words, stored plainly -- every word of every bin is
 // written (blocks no face touches skip the transpose): no atomics, no zero-fill, no second pass over the face records.
 // The raster kernel re-tests every (pixel, face) pair exactly, so a conservative mask changes no result.
-//   s_part / s_parts: this call handles block  s  iff  s % s_parts == s_part  (the blocks of a big screen are dealt to several workgroups)
 __device__ inline void bin_wave_faces(uint64_t* mask, int b, int nbx, int nby, int words, int bin_shift, int c, int lane,
-                                      int bx0, int by0, int bw, int bh, int s_part = 0, int s_parts = 1) {
+                                      int bx0, int by0, int bw, int bh) {
     int c0 = 0, c1 = -1, r0 = 0, r1 = -1;                         // bin columns / rows the box touches (none)
     if (bw > 0 && bh > 0) {
         c0 = bx0 >> bin_shift; c1 = (bx0 + bw - 1) >> bin_shift;
         r0 = by0 >> bin_shift; r1 = (by0 + bh - 1) >> bin_shift;
     }
     const int sbx = (nbx + 7) >> 3, sby = (nby + 7) >> 3;
-    for (int s = s_part; s < sbx * sby; s += s_parts) {
+    for (int s = 0; s < sbx * sby; ++s) {
         const int kx0 = (s % sbx) * 8, ky0 = (s / sbx) * 8;
         const int clo = max(c0 - kx0, 0), chi = min(c1 - kx0, 7), rlo = max(r0 - ky0, 0), rhi = min(r1 - ky0, 7);
         const unsigned col = chi >= clo ? ((2u << chi) - (1u << clo)) : 0u;       // bits clo..chi

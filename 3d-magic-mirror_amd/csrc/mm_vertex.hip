@@ -12,10 +12,6 @@
 MM_PP_STORAGE(vertex_fwd)       // 0 counters cleared, 1 camera (fp64 trig + look-at), 2 face records, 3 binning
 MM_PP_STORAGE(vertex_bwd)       // 0 loads of T + vertex, 1 corner gather, 2 group / wave reductions + partial store, 3 ticket, 4 last workgroup: lights, 5 camera chain
 
-#ifndef MM_VFWD_SPLIT_MIN
-#define MM_VFWD_SPLIT_MIN 8           // mask blocks per wave from which vertex_fwd's binning is dealt to 2 / 4 workgroups
-#endif
-
 namespace mm {
 
 struct VertexFwdArgs {
@@ -52,14 +48,9 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     __shared__ float s_trig[4];
     __shared__ Camera s_cam;
     const int b = blockIdx.y, tid = threadIdx.x;
-    // blockIdx.z: on big screens the 8x8-bin blocks of the candidate mask are dealt to several workgroups per 256 faces (each re-derives the
-    // faces' boxes: a hundred instructions against sixteen wave transposes); only z == 0 writes the face records
-    const bool writer = blockIdx.z == 0;
     MM_PP_BEGIN();
-    if (writer) {
-        for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
-        for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nltot; i += gridDim.x * gridDim.y * 256) a.ltot[i] = 0;
-    }
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nltot; i += gridDim.x * gridDim.y * 256) a.ltot[i] = 0;
     MM_PP_MARK(0);
     // this lane's face: its corner ids and their raw positions depend on nothing the camera produces -- both trips to memory are in
     // flight while four lanes do the fp64 trigonometry and one builds the look-at
@@ -73,8 +64,8 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     }
     block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
     MM_PP_MARK(1);
-    if (writer && blockIdx.x == 0 && tid < 12) a.T[b * 12 + tid] = s_cam.T[tid];
-    if (writer && blockIdx.x == 0 && tid >= 64 && tid < 100) a.cam[b * 48 + tid - 64] = reinterpret_cast<const float*>(&s_cam)[tid - 64];
+    if (blockIdx.x == 0 && tid < 12) a.T[b * 12 + tid] = s_cam.T[tid];
+    if (blockIdx.x == 0 && tid >= 64 && tid < 100) a.cam[b * 48 + tid - 64] = reinterpret_cast<const float*>(&s_cam)[tid - 64];
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = s_cam.T[i];
@@ -97,25 +88,21 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     const float den = len + 1e-10f;
     const float nx = n[0] / den, ny = n[1] / den, nz = n[2] / den;
     const size_t o = (size_t)b * a.F + f;
-    if (writer) {
     a.geo[o * 3 + 0] = make_float4(ax, ay, bx, by);
     a.geo[o * 3 + 1] = make_float4(cx, cy, A.z, Bv.z);
-    }
     // the pixel box of the face inflated by the soft-mask margin (conservative, see pixel_range), packed for the backward's
     // face sweep: x = px0 | py0 << 16, y = width | height << 16 (0 x 0 if it misses the image)
     unsigned org, ext;
     face_pixel_box(ax, ay, bx, by, cx, cy, a.infl, a.mult, a.W, a.H, bx0, by0, bw, bh, org, ext);
-    if (writer) {
     a.geo[o * 3 + 2] = make_float4(C.z, nz, __uint_as_float(org), __uint_as_float(ext));
     a.face_normals[o * 3 + 0] = nx; a.face_normals[o * 3 + 1] = ny; a.face_normals[o * 3 + 2] = nz;
     reinterpret_cast<int2*>(a.fflag)[o] = make_int2(0, 0);
-    }
     }
 
     // ---- screen binning: this wave's 64 faces are exactly mask word c (bin_wave_faces, mm_device.h) ---------------------------
     MM_PP_MARK(2);
     const int c = blockIdx.x * 4 + (tid >> 6);
-    if (a.mask != nullptr && c < a.words) bin_wave_faces(a.mask, b, a.nbx, a.nby, a.words, a.bin_shift, c, tid & 63, bx0, by0, bw, bh, (int)blockIdx.z, (int)gridDim.z);
+    if (a.mask != nullptr && c < a.words) bin_wave_faces(a.mask, b, a.nbx, a.nby, a.words, a.bin_shift, c, tid & 63, bx0, by0, bw, bh);
     MM_PP_MARK(3);
     MM_PP_FLUSH(vertex_fwd, (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6));
 }
@@ -369,9 +356,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.ltot = w.ltot; a.nltot = d->B * MM_LSUB * 4;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mask = w.binmask; a.fflag = w.fflag;
-    const int nblk = ((w.nbx + 7) / 8) * ((w.nby + 7) / 8);           // 8x8-bin blocks of the mask per wave
-    const int zsplit = nblk >= MM_VFWD_SPLIT_MIN ? (nblk >= 16 ? 4 : 2) : 1;
-    dim3 grid((d->F + 255) / 256, d->B, zsplit);
+    dim3 grid((d->F + 255) / 256, d->B);
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
       hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }
     return launch_ok("vertex_fwd");

@@ -142,7 +142,8 @@ size_t mm_query_workspace(const MMRenderDesc* desc);
 int mm_render_forward(const MMRenderDesc* desc, mm_stream_t stream);
 int mm_render_backward(const MMRenderDesc* desc, const MMRenderGrads* grads, mm_stream_t stream);
 /* After mm_render_backward and before the next mm_render_forward on the same workspace: copies the per-image counts of dropped
- * texture-gradient records to dropped_host (B ints, may be NULL) and returns MM_OK if all are zero, MM_ERR_WORKSPACE otherwise.
+ * texture-gradient records to dropped_host (B ints, may be NULL) and returns MM_OK if all are zero, MM_ERR_WORKSPACE otherwise
+ * (a NULL desc / workspace: MM_ERR_NULL_POINTER; a bad shape, a workspace below the minimum or misaligned: MM_ERR_BAD_SHAPE).
  * The one entry point that SYNCHRONISES the stream (a diagnostic, not part of a step). */
 int mm_render_status(const MMRenderDesc* desc, mm_stream_t stream, int32_t* dropped_host);
 /* Fused mode only (desc->fused_gt and desc->fused_loss set), after mm_render_forward: writes the recon_data value of the batch

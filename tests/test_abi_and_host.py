@@ -241,3 +241,26 @@ def test_next_row_entry_points_validate_before_any_gpu_work(pkg):
     assert L.mm_texture_flow_forward(ctypes.byref(t), None) == -1
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pkg.sample_texture(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+
+
+def test_workspace_query_and_status_validation(pkg):
+    """The render workspace is right-sized (round 3: the texture-gradient records are packed per image, no per-tile capacities) and
+    mm_render_status validates its arguments on the host before it touches the device."""
+    N = pkg._native
+    L = N.lib()
+    d = N.MMRenderDesc()
+    assert L.mm_query_workspace(ctypes.byref(d)) == 0
+    assert L.mm_render_status(None, None, None) == -1                                # MM_ERR_NULL_POINTER
+    assert L.mm_render_status(ctypes.byref(d), None, None) == -2                     # MM_ERR_BAD_SHAPE
+    d.B, d.H, d.W, d.V, d.F, d.Ht, d.Wt = 48, 128, 128, 642, 1280, 256, 128          # BASELINE config 2
+    n2 = L.mm_query_workspace(ctypes.byref(d))
+    assert n2 % 256 == 0 and 40e6 < n2 < 80e6                                        # 301 MB in round 2
+    assert L.mm_render_status(ctypes.byref(d), None, None) == -1                     # no workspace
+    d.B, d.H, d.W, d.V, d.F, d.Ht, d.Wt = 16, 512, 512, 6890, 13776, 1024, 512       # config 5
+    n5 = L.mm_query_workspace(ctypes.byref(d))
+    assert 300e6 < n5 < 400e6                                                        # 1 007 MB in round 2
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "sphere.npz"), 64)
+    d.B, d.H, d.W, d.V, d.F, d.Ht, d.Wt = 2, 64, 64, dr.num_vertices, dr.num_faces, 64, 64
+    base = dr.workspace_bytes(d)
+    dr.extra_texture_records_per_pixel = 1.5
+    assert dr.workspace_bytes(d) == base + 2 * int(1.5 * 64 * 64) * 24                 # 24-byte records, per image

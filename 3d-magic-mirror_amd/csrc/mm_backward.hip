@@ -181,7 +181,7 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s
     const int tx0 = (T % a.ntx) * MM_TS, ty0 = (T / a.ntx) * MM_TS;
     MM_PP_BEGIN();
     const int nall = a.tcur[(size_t)b * ntiles + T], off = a.toff[(size_t)b * ntiles + T] - 1;
-    const int dropped = a.tpool[b * 2 + 1];                       // records of the image its array had no room for (pixel_bwd)
+    const int dropped = a.tdrop[b];                            // records of the image its array had no room for (pixel_bwd)
     const int nrec = max(0, min(nall, a.trcap - off));           // (the list is cut where the array ends)
     const TexRecord* recs = a.trec + (size_t)b * a.trcap + off;
     MM_PP_MARK(0);
@@ -450,7 +450,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.grad_rgba = g->grad_rgba;   // (face flags: only the compacting walk of the forward sets them)
     a.gp = w.gp; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.ticket = w.ticket;
-    a.tcur = w.tcur; a.tpool = w.tpool; a.trcnt = w.trcnt; a.toff = w.toff; a.tstatus = w.tstatus; a.trec = w.trec; a.ntiles_ = w.ntiles; a.trcap = w.trcap;
+    a.tcur = w.tcur; a.tdrop = w.tdrop; a.trcnt = w.trcnt; a.toff = w.toff; a.tstatus = w.tstatus; a.trec = w.trec; a.ntiles_ = w.ntiles; a.trcap = w.trcap;
     a.gmax = w.gmax;                                             // (B, MM_GSHARD, 8): two maxima per 32-byte sector
     a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
     a.image_weight = d->fused_image_weight; a.ltot = w.ltot;

@@ -87,9 +87,9 @@ struct Workspace {
     long long* ltot;       // (B,MM_LSUB,4) fused loss: per image {sum|pi-gi|, sum p*g, sum p+g-p*g, -} in 2^-32 fixed point, spread over
                            //            MM_LSUB sub-accumulators (64-bit integer atomics of the raster waves: exact, order-free); zeroed by vertex_fwd
     int* tcnt;             // the counters of the backward, ntcnt ints in all, zeroed by the vertex stage of the forward and by every vertex backward for the
-    int ntcnt;             //            next one: tcur, toff, tpool, gmax (below), in this order
+    int ntcnt;             //            next one: tcur, toff, tdrop, gmax (below), in this order
     int* tcur;             // (B,ntiles) records appended to a texture tile's list so far (pixel_bwd)
-    int* tpool;            // (B,2)      per image {-, records dropped: the packed array was full}
+    int* tdrop;            // (B)        records an image's array had no room for (pixel_bwd counts; the texture gather poisons the image and sets tstatus)
     unsigned* gmax;        // (B,MM_GSHARD,8) per-image maxima of the pixel backward (float bits: max |K2 number|, max |dL/dalpha|)
     int* tstatus;          // (B)        records dropped by the last backward: zeroed by vertex_fwd, set by the texture gather, which also poisons the
                            //            image's texture gradient with NaN (mm_render_status reads it)
@@ -112,7 +112,7 @@ struct Workspace {
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// avail: bytes the caller really has (0 = the minimum, what mm_query_workspace reports): what is beyond the minimum goes to the record pool
+// avail: bytes the caller really has (0 = the minimum, what mm_query_workspace reports): what is beyond the minimum goes to the images' record arrays
 __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, int F, int H, int W, int Ht, int Wt, size_t avail = 0) {
     Workspace w;
     char* p = (char*)base;
@@ -139,12 +139,13 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.bincount = (int*)(p + o);     o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
     w.fflag = (int*)(p + o);        o += align256((size_t)B * F * 2 * sizeof(int));   // (ints, not bytes: a byte store may alias every later load in the compiler's eyes)
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
-    w.ntcnt = (int)((size_t)B * w.ntiles * 2 + (size_t)B * 2 + (size_t)B * MM_GSHARD * 8);
+    const size_t ndrop = ((size_t)B * w.ntiles * 2 + B + 7) / 8 * 8 - (size_t)B * w.ntiles * 2;   // (gmax starts on a 32-byte sector)
+    w.ntcnt = (int)((size_t)B * w.ntiles * 2 + ndrop + (size_t)B * MM_GSHARD * 8);
     w.tcnt = (int*)(p + o);         o += align256(((size_t)w.ntcnt + B + (size_t)B * w.ntiles) * sizeof(int));
     w.tcur = w.tcnt;
     w.toff = w.tcur + (size_t)B * w.ntiles;
-    w.tpool = w.toff + (size_t)B * w.ntiles;
-    w.gmax = (unsigned*)(w.tpool + (size_t)B * 2);
+    w.tdrop = w.toff + (size_t)B * w.ntiles;
+    w.gmax = (unsigned*)(w.tdrop + ndrop);
     w.tstatus = w.tcnt + w.ntcnt;
     w.trcnt = w.tstatus + B;
     w.item_cap = F + (int)(((size_t)16 * H * W + MM_CHUNK_PX - 1) / MM_CHUNK_PX);

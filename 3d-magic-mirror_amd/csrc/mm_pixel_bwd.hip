@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
             else ++ndrop;                                        // the image's array is full: counted, and the texture gather poisons the image's gradient
         }
     }
-    if (__builtin_expect(__ballot(ndrop != 0) != 0ull, 0)) { if (ndrop) atomicAdd(a.tpool + b * 2 + 1, ndrop); }
+    if (__builtin_expect(__ballot(ndrop != 0) != 0ull, 0)) { if (ndrop) atomicAdd(a.tdrop + b, ndrop); }
 
     __syncthreads();
     if (threadIdx.x >= 64 && threadIdx.x < 66) {                 // non-negative floats order like their bit patterns: integer max, one atomic per

@@ -153,7 +153,7 @@ int mm_render_fused_loss(const MMRenderDesc* desc, mm_stream_t stream);
 /* Tools only (profiles/tools): byte offsets inside the render workspace of out[0] = chunkmap (B,F) int2, out[1] = sweep items (B,item_cap)
  * int2, out[2] = nitems (B) int2, out[3] = per-item partial sums (B,item_cap,12) float; out[4] = item_cap; out[5] = gp (B,H,W,2) float4,
  * out[6] = gp2 (B,H,W) float, out[7] = soft (B,H,W) float2, out[8] = per-texture-tile record counts of the last backward (B,ntiles) int
- * followed by the list offsets + 1 (B,ntiles) and {-, records dropped} (B,2); out[9] = ntiles; out[10] = records an image's array holds;
+ * followed by the list offsets + 1 (B,ntiles) and the records dropped (B); out[9] = ntiles; out[10] = records an image's array holds;
  * out[11] = the forward's per-tile footprint counts (B,ntiles) int.  `out` has room for 16 values.  Returns 0, or MM_ERR_*. */
 int mm_debug_workspace_layout(const MMRenderDesc* desc, size_t* out8);
 

@@ -1,4 +1,4 @@
-"""Texture-gradient records per image and per 32x32-texel tile (what sizes Workspace::trec / tspill): one step per config with a library
+"""Texture-gradient records per image and per 32x32-texel tile (what sizes Workspace::trec): one step per config with a library
 variant that leaves the counters in place (-DMM_DBG_KEEP_TCNT):   python profiles/tools/tex_records.py config2 config3 config5 market"""
 import sys, importlib, os, ctypes, torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,10 +24,10 @@ for cfg in (sys.argv[1:] or ["config2"]):
         out = (ctypes.c_size_t * 16)()
         assert N.lib().mm_debug_workspace_layout(ctypes.byref(st.d), out) == 0
         nt = int(out[9])
-        tc = st.ws[out[8]:out[8] + (2 * B * nt + 2 * B) * 4].view(torch.int32).cpu().numpy()
-        per = tc[:B * nt].reshape(B, nt); pool = tc[2 * B * nt:].reshape(B, 2)      # (counts | offsets + 1 | {-, dropped})
+        tc = st.ws[out[8]:out[8] + (2 * B * nt + B) * 4].view(torch.int32).cpu().numpy()
+        per = tc[:B * nt].reshape(B, nt); dropped = tc[2 * B * nt:]                  # (counts | offsets + 1 | records dropped)
         tot = per.sum(1)
         print("%s seed %d | HW %d, %d tiles | records per image: mean %.0f max %d = %.2f of HW | per tile: mean of non-empty %.0f, p99 %d, max %d = %.2f of HW/ntiles | "
               "tiles over 256: %.2f %%, over 1024: %.2f %% | array capacity %d; records dropped: %d" % (
                   cfg, seed, H * W, nt, tot.mean(), tot.max(), tot.max() / (H * W), per[per > 0].mean(), np.percentile(per[per > 0], 99), per.max(),
-                  per.max() / (H * W / nt), 100.0 * (per > 256).mean(), 100.0 * (per > 1024).mean(), int(out[10]), pool[:, 1].sum()), flush=True)
+                  per.max() / (H * W / nt), 100.0 * (per > 256).mean(), 100.0 * (per > 1024).mean(), int(out[10]), dropped.sum()), flush=True)

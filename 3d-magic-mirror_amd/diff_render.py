@@ -377,6 +377,14 @@ class DiffRender(object):
         N.require_device(*[v for k, v in example_attributes.items() if torch.is_tensor(v)], gt_data)
         return GraphedRenderRecon(self, example_attributes, gt_data, no_mask=no_mask)
 
+    def graphed_render(self, example_attributes, no_mask=False):
+        """A captured (HIP-graph) ``render`` + backward for attribute tensors of the example's shapes: a callable ``g(**attributes) -> (rgbs,
+        attributes)`` like ``render`` (step.GraphedRender).  For the renders of an iteration whose images feed a loss outside this class
+        (trainer.py:345-367); one object per such render -- its outputs are static memory."""
+        from .step import GraphedRender
+        N.require_device(*[v for k, v in example_attributes.items() if torch.is_tensor(v)])
+        return GraphedRender(self, example_attributes, no_mask=no_mask)
+
     # ---- networks.py:364-390 -------------------------------------------------------------------------------------
     def recon_data(self, pred_data, gt_data, no_mask=False, contour=0):
         ext = N.torch_ext()

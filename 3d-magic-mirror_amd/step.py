@@ -300,3 +300,97 @@ class GraphedRenderRecon:
     @property
     def grads(self):
         return self.step.grads
+
+
+class _GraphedRenderFn(torch.autograd.Function):
+    """rgba (B,H,W,4), face_normals = graphed render(leaves...): forward and backward are one captured graph each."""
+
+    @staticmethod
+    def forward(ctx, gr, *leaves):
+        gr._load_inputs(leaves)
+        gr.fwd_graph.replay()
+        ctx.gr = gr
+        ctx.leaf_inputs = [t if (t is not None and t.is_leaf and t.requires_grad) else None for t in leaves]
+        ctx.set_materialize_grads(False)
+        return gr.step.rgba, gr.step.face_normals
+
+    @staticmethod
+    def backward(ctx, g_rgba, g_fn):
+        gr = ctx.gr
+        g = gr.step.grads
+        for k, leaf in zip(LEAVES, ctx.leaf_inputs):             # (see _GraphedFn.backward: a kept .grad that aliases the static buffer is copied out first)
+            if leaf is not None and leaf.grad is not None and g[k] is not None and leaf.grad.data_ptr() == g[k].data_ptr():
+                leaf.grad = leaf.grad.clone()
+        if g_rgba is None:
+            if not gr._g_rgba_zero:
+                gr.step.grad_rgba.zero_(); gr._g_rgba_zero = True
+        else:
+            gr.step.grad_rgba.copy_(g_rgba.detach(), non_blocking=True); gr._g_rgba_zero = False   # (any strides: the image reaches the caller as a permuted view)
+        if g_fn is not None:
+            gr.g_fn.copy_(g_fn.detach(), non_blocking=True); gr._g_fn_zero = False
+        elif not gr._g_fn_zero:
+            gr.g_fn.zero_(); gr._g_fn_zero = True
+        gr.bwd_graph.replay()
+        out = []
+        for k, leaf in zip(LEAVES, ctx.leaf_inputs):
+            if leaf is None or g[k] is None:
+                out.append(g[k])
+            else:
+                if leaf.grad is None:
+                    leaf.grad = g[k]
+                else:
+                    leaf.grad.add_(g[k])
+                out.append(None)
+        return (None,) + tuple(out)
+
+
+class GraphedRender:
+    """``DiffRender.render`` alone (no loss folded in) and its backward as two captured HIP graphs behind one autograd node: the render calls of
+    a trainer iteration whose images feed something other than ``recon_data`` -- trainer.py:345-367 renders three more views per iteration for the
+    discriminator and the cycle losses.  Same contract as GraphedRenderRecon: static input slots (``inputs``), static outputs (the image, the
+    face normals, face_idx and imnormal are overwritten by the next call of THIS object: use one object per render of an iteration), leaves get
+    the static gradient buffers as ``.grad``.  The upstream gradient of the image is copied into a static slot (50 MB at B=48, 256x256: the one
+    copy this path cannot avoid -- the loss lives outside).  Bit-identical to the eager render."""
+
+    def __init__(self, dr, example_attributes, no_mask=True):
+        dev = example_attributes["azimuths"].device
+        f32 = lambda t: t.detach().to(torch.float32).contiguous().clone()
+        self.dr, self.dev, self.no_mask = dr, dev, bool(no_mask)
+        self.inputs = {k: (f32(example_attributes[k]) if example_attributes.get(k) is not None and (k != "bg" or no_mask) else None) for k in LEAVES}
+        B, H, W = self.inputs["azimuths"].shape[0], dr.render_height, dr.image_size
+        self.step = RenderLossStep(dr, self.inputs, torch.zeros((B, 4, H, W), device=dev), no_mask=no_mask, emit_imnormal=dr.emit_imnormal, fused=False)
+        self.g_fn = torch.zeros_like(self.step.face_normals)
+        self.step.g.grad_face_normals = N.ptr(self.g_fn)
+        self.step.grad_rgba.zero_()
+        self._g_fn_zero = self._g_rgba_zero = True
+        L = N.lib()
+        fwd = lambda s: N.check(L.mm_render_forward(ctypes.byref(self.step.d), ctypes.c_void_p(s.cuda_stream)), "mm_render_forward")
+        bwd = lambda s: N.check(L.mm_render_backward(ctypes.byref(self.step.d), ctypes.byref(self.step.g), ctypes.c_void_p(s.cuda_stream)), "mm_render_backward")
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            fwd(side); bwd(side)                                 # warm-up outside capture (module load, first touch)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph, stream=side):
+            fwd(side)
+        with torch.cuda.graph(self.bwd_graph, stream=side):
+            bwd(side)
+
+    def _load_inputs(self, leaves):
+        for k, t in zip(LEAVES, leaves):
+            slot = self.inputs[k]
+            if slot is None or t is None:
+                continue
+            if t.data_ptr() != slot.data_ptr():
+                slot.copy_(t.detach().reshape(slot.shape), non_blocking=True)
+
+    def __call__(self, **attributes):
+        """(rgbs, attributes) = render(no_mask, **attributes) through the captured graphs."""
+        leaves = tuple(attributes.get(k) if (k != "bg" or self.no_mask) else None for k in LEAVES)
+        rgba, fn = _GraphedRenderFn.apply(self, *leaves)
+        attributes["face_normals"] = fn
+        attributes["imnormal"] = self.step.imnormal
+        self.dr.last_face_idx = self.step.face_idx
+        return rgba.permute(0, 3, 1, 2), attributes

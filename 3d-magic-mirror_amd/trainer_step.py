@@ -133,9 +133,12 @@ def default_opt():
 
 
 class TrainerStep:
-    def __init__(self, template, image_size, batch, device, ratio=1, opt=None, seed=0):
+    def __init__(self, template, image_size, batch, device, ratio=1, opt=None, seed=0, graphed=False):
+        """graphed: the four renders go through DiffRender.graphed_render (one captured forward / backward graph pair per render of the iteration:
+        their outputs are static memory) instead of the eager autograd nodes -- same bits, less host time."""
         self.opt = opt or default_opt()
         self.dev, self.B = device, batch
+        self.graphed, self._gr = bool(graphed), {}
         self.dr = DiffRender(template, image_size, ratio=ratio)
         torch.manual_seed(seed)
         self.netE = AttributeNet(self.dr.vertices_init, bg=self.opt.bg).to(device)
@@ -154,6 +157,15 @@ class TrainerStep:
         self.gen = torch.Generator(device=device).manual_seed(seed + 2)
         self.last = {}
 
+    def _render(self, slot, A):
+        """render #slot of the iteration: eager, or through that slot's captured graphs."""
+        if not self.graphed:
+            return self.dr.render(**A, no_mask=self.opt.bg)
+        g = self._gr.get(slot)
+        if g is None:
+            g = self._gr[slot] = self.dr.graphed_render(A, no_mask=self.opt.bg)
+        return g(**A)
+
     def _u(self, *shape, lo=0.0, hi=1.0):
         return torch.rand(*shape, device=self.dev, generator=self.gen) * (hi - lo) + lo
 
@@ -161,7 +173,7 @@ class TrainerStep:
         o, dr, Bn = self.opt, self.dr, self.B
         self.optimizerE.zero_grad(set_to_none=True)
         Ae = self.netE(self.Xa)
-        Xer, Ae = dr.render(**Ae, no_mask=o.bg)                                            # render #1
+        Xer, Ae = self._render(0, Ae)                                                      # render #1
         Ae90 = deep_copy(Ae)
         sign = torch.where(self._u(Bn) < 0.5, -1.0, 1.0)
         Ae90["azimuths"] = -self._u(Bn, lo=o.hard_range, hi=180.0 - o.hard_range) * sign
@@ -177,10 +189,10 @@ class TrainerStep:
               "textures": a_t * Aa["textures"] + (1 - a_t) * Ab["textures"],
               "bg": (a_t * Aa["bg"] + (1 - a_t) * Ab["bg"]) if o.bg else None,
               "lights": a_l * Aa["lights"] + (1 - a_l) * Ab["lights"]}
-        Xir, Ai = dr.render(**Ai, no_mask=o.bg)                                            # render #2
-        Xer90, Ae90 = dr.render(**Ae90, no_mask=o.bg) if o.hard else (Xer, Ae)             # render #3
+        Xir, Ai = self._render(1, Ai)                                                      # render #2
+        Xer90, Ae90 = self._render(2, Ae90) if o.hard else (Xer, Ae)                       # render #3
         Aire = self.netE(Xir.detach().clone())
-        _, Aire = dr.render(**Aire, no_mask=o.bg)                                          # render #4 (face_normals only)
+        _, Aire = self._render(3, Aire)                                                    # render #4 (face_normals only)
         outs = self.critic(torch.cat((Xer90[:, :3], Xir[:, :3]), 0))
         o1, o2 = torch.split(outs, Bn, 0)
         lossR_fake = o.lambda_gan * (-o1.mean() - o.ganw * o2.mean()) / (1.0 + o.ganw)
@@ -209,10 +221,10 @@ class TrainerStep:
                     if torch.is_tensor(v):
                         v.grad = None
             Ae, Ai, A9, Ar = (dict(A) for A in sets)
-            Xer, Ae = dr.render(**Ae, no_mask=o.bg)
-            Xir, Ai = dr.render(**Ai, no_mask=o.bg)
-            Xer90, A9 = dr.render(**A9, no_mask=o.bg)
-            _, Ar = dr.render(**Ar, no_mask=o.bg)
+            Xer, Ae = self._render(0, Ae)
+            Xir, Ai = self._render(1, Ai)
+            Xer90, A9 = self._render(2, A9)
+            _, Ar = self._render(3, Ar)
             l = dr.recon_data(Xer, self.Xa, no_mask=o.bg) + 1e-4 * (Xer90[:, :3].mean() + Xir[:, :3].mean())
             r1, r2, r3 = dr.regularization(Ae, Ai, Ar, o)
             (l + r1 + r2 + r3).backward()
@@ -242,11 +254,23 @@ def bench(device, steps=8, warmup=3, template=None, image_size=256, batch=48):
     for _ in range(2):
         rp()
     t_rp = timed(rp, steps)
+    # the same step and the same render path with the four renders through DiffRender.graphed_render (same weights, same random stream)
+    tg = TrainerStep(template, image_size, batch, device, graphed=True)
+    for _ in range(warmup):
+        tg.step()
+    t_step_g = timed(tg.step, steps)
+    rpg = tg.render_path_only()
+    for _ in range(2):
+        rpg()
+    t_rp_g = timed(rpg, steps)
     nparam = sum(p.numel() for p in ts.netE.parameters())
     return {"workload": "config3: template ellipsoid (V=%d,F=%d), B=%d, %dx%d, texture %dx%d; ResNet-18 x2 + conv stacks (%.1f M params) -> "
                         "4 renders (trainer.py order) -> recon_data -> regularisers (chamfer IC) -> one backward -> Adam"
                         % (ts.dr.num_vertices, ts.dr.num_faces, batch, ts.dr.render_height, ts.dr.image_size, 2 * ts.dr.render_height,
                            ts.dr.image_size, nparam / 1e6),
             "images_per_s": round(batch / t_step, 1), "ms_per_step": round(t_step * 1e3, 3),
-            "render_path_ms": round(t_rp * 1e3, 3), "render_path_share": round(t_rp / t_step, 3), "steps": steps, "loss": loss,
+            "render_path_ms": round(t_rp * 1e3, 3), "render_path_share": round(t_rp / t_step, 3),
+            "graphed_renders": {"images_per_s": round(batch / t_step_g, 1), "ms_per_step": round(t_step_g * 1e3, 3), "render_path_ms": round(t_rp_g * 1e3, 3),
+                                "loss": float(tg.last["loss"])},
+            "steps": steps, "loss": loss,
             "encoder_params": nparam}

@@ -1,5 +1,9 @@
-import sys, importlib, os, torch, time
-sys.path.insert(0, "/root/repo")
+"""The trainer-shaped config-3 step (trainer_step.bench): whole step and render path (four renders + recon_data + regularisers + backward on
+detached attributes), eager class API against DiffRender.graphed_render.   python profiles/tools/render_path.py"""
+import sys, importlib, os, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 ts_mod = importlib.import_module("3d-magic-mirror_amd.trainer_step")
-r = ts_mod.bench(torch.device("cuda:0"), steps=8, warmup=3)
-print({k: r[k] for k in ("images_per_s", "ms_per_step", "render_path_ms", "render_path_share")})
+for rep in range(2):
+    r = ts_mod.bench(torch.device("cuda:0"), steps=8, warmup=3)
+    print({k: r[k] for k in ("images_per_s", "ms_per_step", "render_path_ms", "render_path_share", "graphed_renders")}, flush=True)

@@ -406,6 +406,47 @@ def test_graphed_step_replays_the_eager_path_bit_for_bit(pkg):
         assert torch.equal(gs.grads[k], d3[k].grad), k
 
 
+def test_graphed_render_replays_the_eager_render_bit_for_bit(pkg):
+    """DiffRender.graphed_render: render alone + its backward as two HIP graphs behind one autograd node, for images whose loss lives outside
+    the class (trainer.py:345-367).  Leaves and non-leaf attributes (the gradient goes on through the engine into whatever produced them),
+    an upstream gradient that reaches the image as a permuted view, a step where only face_normals is differentiated: the eager bits."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 5, 80, seed=61)
+    gr = dr.graphed_render(datt, no_mask=True)
+    B = 5
+    for it, seed in enumerate((62, 63, 64)):
+        _, _, d2, _, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", B, 80, seed=seed)
+        wi = torch.linspace(-1.0, 1.0, B * 4 * H * W, device=dev).reshape(B, 4, H, W) * 1e-2
+        wf = torch.linspace(1.0, -1.0, B * dr.num_faces * 3, device=dev).reshape(B, dr.num_faces, 3) * 1e-3
+        scale = torch.full((), 1.5, device=dev, requires_grad=True)
+
+        def total(rgbs, out, it=it, wi=wi, wf=wf):
+            t = (out["face_normals"] * wf).sum()
+            return t if it == 2 else t + (rgbs * wi).sum()
+
+        def inputs(src):
+            lv = {k: src[k].detach().clone().requires_grad_(True) for k in LEAVES}
+            a = dict(src); a.update(lv)
+            if it == 1:                                          # non-leaf attributes: vertices and lights are products of something upstream
+                a["vertices"] = lv["vertices"] * scale
+                a["lights"] = lv["lights"] + 0.0
+            return lv, a
+        lv_e, a_e = inputs(d2)
+        rgbs_e, out_e = dr.render(no_mask=True, **a_e)
+        total(rgbs_e, out_e).backward()
+        ref = (rgbs_e.detach().clone(), dr.last_face_idx.clone(), {k: lv_e[k].grad.clone() for k in LEAVES}, scale.grad.clone() if it == 1 else None)
+        scale.grad = None
+        lv_g, a_g = inputs(d2)
+        rgbs_g, out_g = gr(**a_g)
+        total(rgbs_g, out_g).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(rgbs_g.detach(), ref[0]) and torch.equal(dr.last_face_idx, ref[1]), it
+        for k in LEAVES:
+            assert torch.equal(lv_g[k].grad, ref[2][k]), (it, k)
+        if it == 1:
+            assert torch.equal(scale.grad, ref[3])
+            scale.grad = None
+
+
 def test_lane_exchange_primitives_on_this_gpu():
     """mm_device.h builds its 64x64 bit transposes and prefix scans from DPP lane selects and gfx950's v_permlane16/32_swap (no LDS-crossbar
     shuffles); profiles/tools/xchg_test.hip checks every stride, the transpose and the scan against their definitions on the device."""

@@ -573,6 +573,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                                           # (rank 0's extra legs are done: nobody tears the communicator down under it)
         dist.destroy_process_group()
 
 

@@ -23,7 +23,7 @@ EXACT = ["-ffp-contract=off"]
 RELAXED = ["-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
 SOURCES = {"mm_abi.hip": EXACT, "mm_reg.hip": EXACT, "mm_texflow.hip": EXACT, "mm_attloss.hip": EXACT, "mm_vertex.hip": EXACT, "mm_raster.hip": EXACT,
            "mm_backward.hip": RELAXED, "mm_pixel_bwd.hip": EXACT, "mm_loss.hip": EXACT, "mm_nn.hip": EXACT, "mm_dibr.hip": EXACT, "mm_ops.hip": EXACT}
-HEADERS = ["mm_device.h", "mm_raster_common.h", "mm_raster_walk.h", "mm_backward.h", os.path.join("..", "..", "include", "mm_render.h")]
+HEADERS = ["mm_device.h", "mm_raster_common.h", "mm_raster_walk.h", "mm_backward.h", "mm_order.h", os.path.join("..", "..", "include", "mm_render.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

@@ -15,6 +15,7 @@ size_t recon_workspace_bytes(const MMReconDesc*);
 int launch_recon_fwd(const MMReconDesc*, hipStream_t);
 int launch_recon_bwd(const MMReconDesc*, hipStream_t);
 int launch_nn(int, int, int, const float*, const float*, float*, int32_t*, hipStream_t);
+int launch_nn_both(int, int, int, const float*, const float*, float*, int32_t*, float*, int32_t*, hipStream_t);
 size_t reg_workspace_bytes(const MMMeshRegDesc*);
 int launch_reg_fwd(const MMMeshRegDesc*, hipStream_t);
 int launch_reg_bwd(const MMMeshRegDesc*, const MMMeshRegGrads*, hipStream_t);
@@ -30,11 +31,15 @@ static int check_render(const MMRenderDesc* d, bool backward) {
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->V <= 0 || d->F <= 0 || d->Ht <= 0 || d->Wt <= 0) return MM_ERR_BAD_SHAPE;
     if (d->knum <= 0) return MM_ERR_UNSUPPORTED;
     if (d->H > 65535 || d->W > 65535) return MM_ERR_UNSUPPORTED;                 // pixel boxes are packed in 16 + 16 bits
-    if (!d->faces || !d->face_uvs || !d->vertices || !d->textures || !d->lights || !d->azimuths || !d->elevations ||
-        !d->distances || !d->biases || !d->face_idx || !d->face_normals)
-        return MM_ERR_NULL_POINTER;
-    if (!backward && !d->rgba) return MM_ERR_NULL_POINTER;                        // (the backward never reads the image: rgba may be NULL there)
-    if (d->no_mask && !d->bg) return MM_ERR_NULL_POINTER;
+    if (d->geometry_only) {                                                       // vertex stage only: what it reads and writes
+        if (!d->faces || !d->vertices || !d->azimuths || !d->elevations || !d->distances || !d->biases || !d->face_normals) return MM_ERR_NULL_POINTER;
+    } else {
+        if (!d->faces || !d->face_uvs || !d->vertices || !d->textures || !d->lights || !d->azimuths || !d->elevations ||
+            !d->distances || !d->biases || !d->face_idx || !d->face_normals)
+            return MM_ERR_NULL_POINTER;
+        if (!backward && !d->rgba) return MM_ERR_NULL_POINTER;                    // (the backward never reads the image: rgba may be NULL there)
+        if (d->no_mask && !d->bg) return MM_ERR_NULL_POINTER;
+    }
     if (backward && !d->vc_table) return MM_ERR_NULL_POINTER;
     if (backward && d->vc_stride <= 0) return MM_ERR_BAD_SHAPE;
     if (!d->workspace || d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_WORKSPACE;
@@ -55,7 +60,7 @@ int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     mm::clear_stale_error();
     st = mm::launch_vertex_fwd(d, w, s);
-    if (st != MM_OK) return st;
+    if (st != MM_OK || d->geometry_only) return st;
     return mm::launch_raster_fwd(d, w, s);      // tile order + raster
 }
 
@@ -95,12 +100,16 @@ int mm_render_status(const MMRenderDesc* d, mm_stream_t stream, int32_t* dropped
 int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {
     int st = check_render(d, true);
     if (st != MM_OK) return st;
-    if (!g || (!g->grad_rgba && !d->fused_gt) || !g->grad_vertices || !g->grad_textures || !g->grad_lights || !g->grad_azimuths ||
-        !g->grad_elevations || !g->grad_distances || !g->grad_biases)
-        return MM_ERR_NULL_POINTER;
-    if (d->no_mask && !g->grad_bg) return MM_ERR_NULL_POINTER;
+    if (!g || !g->grad_vertices || !g->grad_azimuths || !g->grad_elevations || !g->grad_distances || !g->grad_biases) return MM_ERR_NULL_POINTER;
     const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
+    if (d->geometry_only) {                                       // nothing was rasterised: the gradient arrives through face_normals alone
+        if (!g->grad_face_normals) return MM_ERR_NULL_POINTER;
+        mm::clear_stale_error();
+        return mm::launch_vertex_bwd(d, g, w, s);
+    }
+    if ((!g->grad_rgba && !d->fused_gt) || !g->grad_textures || !g->grad_lights) return MM_ERR_NULL_POINTER;
+    if (d->no_mask && !g->grad_bg) return MM_ERR_NULL_POINTER;
     mm::clear_stale_error();
     st = mm::launch_raster_bwd(d, g, w, s);
     if (st != MM_OK) return st;
@@ -143,6 +152,15 @@ int mm_nearest_neighbour(int32_t B, int32_t N, int32_t M, const float* x, const 
     if (B <= 0 || N <= 0 || M <= 0) return MM_ERR_BAD_SHAPE;
     mm::clear_stale_error();
     return mm::launch_nn(B, N, M, x, y, dist, idx, (hipStream_t)stream);
+}
+
+int mm_chamfer_nearest(int32_t B, int32_t N, int32_t M, const float* x, const float* y, float* dist_x, int32_t* idx_x,
+                       float* dist_y, int32_t* idx_y, mm_stream_t stream) {
+    if (!x || !y || !dist_x || !idx_x || !dist_y || !idx_y) return MM_ERR_NULL_POINTER;
+    if (B <= 0 || N <= 0 || M <= 0) return MM_ERR_BAD_SHAPE;
+    if (B > 65535) return MM_ERR_UNSUPPORTED;
+    mm::clear_stale_error();
+    return mm::launch_nn_both(B, N, M, x, y, dist_x, idx_x, dist_y, idx_y, (hipStream_t)stream);
 }
 
 static int check_reg(const MMMeshRegDesc* d, bool backward) {

@@ -31,6 +31,7 @@ struct BwdArgs {
     float* grad_bg;
     unsigned* ticket;
     int* tcur; int* tdrop; const int* trcnt; int* toff; int* tstatus; TexRecord* trec; int ntiles_, trcap;   // texture records (Workspace)
+    int* status_flag;                                            // MMRenderDesc.status_flag (may be pinned host memory) or nullptr
     // fused recon_data (gt == nullptr: off)
     const float* gt; const float* rgba; const float* grad_loss; float* loss; float image_weight;
     const long long* ltot;                                       // (B,MM_LSUB,4) fused loss sums of the raster waves (fixed point)

@@ -206,7 +206,10 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s
     }
     if (dropped != 0) {                                          // the image lost records: its texture gradient is NOT a gradient -- say so in every texel
         inv = __builtin_nanf("");
-        if (T == 0 && tid == 0) a.tstatus[b] = dropped;
+        if (T == 0 && tid == 0) {
+            a.tstatus[b] = dropped;
+            if (a.status_flag) __hip_atomic_fetch_add(a.status_flag, dropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the host may be polling it)
+        }
     }
     MM_PP_MARK(2);
     MM_PP_COUNT(nrec, 0);
@@ -452,6 +455,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.ticket = w.ticket;
     a.tcur = w.tcur; a.tdrop = w.tdrop; a.trcnt = w.trcnt; a.toff = w.toff; a.tstatus = w.tstatus; a.trec = w.trec; a.ntiles_ = w.ntiles; a.trcap = w.trcap;
     a.gmax = w.gmax;                                             // (B, MM_GSHARD, 8): two maxima per 32-byte sector
+    a.status_flag = d->status_flag;
     a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
     a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
     a.items = w.items; a.nitems = w.nitems; a.part = w.part; a.item_cap = w.item_cap;

@@ -29,6 +29,9 @@
 namespace mm {
 
 struct Float3 { float x, y, z; };
+// three consecutive 4-byte values at a 4-byte-aligned address, as ONE 12-byte load (global_load_dwordx3)
+struct __attribute__((packed, aligned(4))) Packed3 { float x, y, z; };
+struct __attribute__((packed, aligned(4))) PackedI3 { int x, y, z; };
 
 // ---- screen bins ------------------------------------------------------------------------------------------------------
 // The vertex stage records, per screen bin, which faces' boxes (inflated by the soft-mask margin) may touch it, as one
@@ -111,6 +114,19 @@ struct Workspace {
 };
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Small templates in LARGE batches: the vertex backward as one workgroup per image, face-major then vertex-major through LDS
+// (vertex_image_bwd_kernel: no ticket, no partial-row round trip).  One workgroup = one CU's load / store pipeline per image: with
+// fewer images than a fraction of the chip's 256 CUs the 8-lanes-per-vertex grid of vertex_bwd_kernel (21 workgroups per image) is as
+// fast or faster (B=48: 16.2 vs 16.1 us at 128x128, 28.5 vs 18.0 at 256x256 where faces have several sweep items); at B=384 it is 29.6
+// against 52.5 us (profiles/r04_per_image_stages_ab.md).
+#define MM_VIMG_BWD_MAX_FACES 1700
+#ifndef MM_VIMG_BWD_MIN_B
+#define MM_VIMG_BWD_MIN_B 128
+#endif
+inline bool vertex_bwd_per_image(int B, int F, int vc_stride) {
+    return B >= MM_VIMG_BWD_MIN_B && F <= MM_VIMG_BWD_MAX_FACES && vc_stride <= 64;
+}
 
 // avail: bytes the caller really has (0 = the minimum, what mm_query_workspace reports): what is beyond the minimum goes to the images' record arrays
 __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, int F, int H, int W, int Ht, int Wt, size_t avail = 0) {

@@ -116,6 +116,9 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. pixel-major pass
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef MM_TOFF_SPIN_MAX
+#define MM_TOFF_SPIN_MAX (1 << 17)   // polls of a tile's list offset before the group gives up (each a trip to memory: ~0.1 s in all)
+#endif
 #ifndef MM_PIXEL_LB
 #define MM_PIXEL_LB 5             // waves per SIMD the register allocation is held to: 96 VGPRs without spills (the light gradients are carried as scalar + normal, not
 #endif                            // as nine products); 5 workgroups of 28.9 KB LDS (the plan workgroups' staging) fit a CU as well
@@ -335,10 +338,10 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     // image's plan workgroup at the top of its life, + 1: a zero means "not yet", the first microseconds of the launch, and is asked for again).
     // The grouping is pure lane arithmetic; all leaders then issue their atomics in ONE instruction per footprint corner (and the four corners'
     // atomics are in flight together), so a wave pays one fabric round trip, not one per tile.
-    int leader[4], rank[4], base[4], toff[4];
+    int leader[4], rank[4], base[4], toff[4], room[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        leader[c] = -1; rank[c] = 0; base[c] = 0; toff[c] = 1;
+        leader[c] = -1; rank[c] = 0; base[c] = 0; toff[c] = 1; room[c] = 0;
         if (!any_covered) continue;                              // wave-uniform: nothing to append
         int size = 0;
         unsigned long long pending = __ballot(rtile[c] >= 0);
@@ -351,6 +354,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
         }
         if (leader[c] == lane) {
             toff[c] = __hip_atomic_load(a.toff + (size_t)b * a.ntiles_ + rtile[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            room[c] = a.trcnt[(size_t)b * a.ntiles_ + rtile[c]];    // what the forward counted for this tile: the length of its list
             base[c] = atomicAdd(a.tcur + (size_t)b * a.ntiles_ + rtile[c], size);
         }
     }
@@ -375,21 +379,30 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (!any_covered) break;
+        // (the image's plan workgroup has a LOWER workgroup index and writes the offsets first thing: it is in flight before this wave exists,
+        //  and the wait below is the first microseconds of a launch.  It is nevertheless BOUNDED: should the offsets never arrive -- a
+        //  dispatcher that does not start workgroups in index order -- the group's records are counted as dropped, the image's texture
+        //  gradient is poisoned and mm_render_status reports it, instead of a hang.)
+        int spins = 0;
         while (__builtin_expect(leader[c] == lane && toff[c] == 0, 0)) {
+            if (++spins > MM_TOFF_SPIN_MAX) break;
             __builtin_amdgcn_s_sleep(2);
             toff[c] = __hip_atomic_load(a.toff + (size_t)b * a.ntiles_ + rtile[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        room[c] = toff[c] == 0 ? 0 : room[c] - base[c];           // places left in the tile's list from this group's first one (<= 0: none)
         base[c] += toff[c] - 1;
     }
     int ndrop = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (!any_covered) break;
-        const int bs = __shfl(base[c], leader[c] < 0 ? lane : leader[c], 64);
+        const int bs = __shfl(base[c], leader[c] < 0 ? lane : leader[c], 64), rm = __shfl(room[c], leader[c] < 0 ? lane : leader[c], 64);
         if (rtile[c] >= 0) {
             const int pos = bs + rank[c];
-            if (pos < a.trcap) a.trec[(size_t)b * a.trcap + pos] = rec;
-            else ++ndrop;                                        // the image's array is full: counted, and the texture gather poisons the image's gradient
+            // inside the image's array AND inside the tile's own list (the forward's count is an upper bound of what this pass appends as
+            // long as both recompute the same footprints; a record beyond it would land in the NEXT tile's list: dropped and reported instead)
+            if (pos < a.trcap && rank[c] < rm) a.trec[(size_t)b * a.trcap + pos] = rec;
+            else ++ndrop;                                        // counted, and the texture gather poisons the image's gradient
         }
     }
     if (__builtin_expect(__ballot(ndrop != 0) != 0ull, 0)) { if (ndrop) atomicAdd(a.tdrop + b, ndrop); }

@@ -23,6 +23,7 @@
 //     critical path is pairs/64 evaluations, not its busiest pixel, and results do not depend on evaluation order.
 //   * the epilogue (winner -> uv -> texels -> shade -> store) is written as TWO dependent trips to memory (mm_raster_common.h: shade_store).
 #include "mm_raster_walk.h"
+#include "mm_order.h"
 
 MM_TIMELINE_STORAGE(raster_fwd)
 MM_PP_STORAGE(raster_fwd)       // 0 tile setup, 1 mask -> id list, 2 fetch + stage + box tests + transposes, 3 colour pairs, 4 silhouette pairs, 5 shade + store
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_
         // workgroups of image b, in launch order: heavy tiles (one each), the other non-empty tiles (four each, or one), then the empty
         // tiles four per WAVE (shade_empty_tiles); the grid is sized for "no tile is empty", workgroups behind the last one exit
         int b, j;
-        walk_image_rank((int)blockIdx.x, a.B, a.spread != 0, b, j);
+        walk_image_rank((int)blockIdx.x, a.B, a.spread, b, j);
         const int nh = kBlock ? a.nheavy[2 * b] : 0, nne = a.nheavy[2 * b + 1];
         const int W1 = kBlock ? nh + (max(nne - nh, 0) + 3) / 4 : nne;       // workgroups that walk: heavy tiles one each, the others four each (or one)
         const int per = kBlock ? 16 : 4, W2 = (4 * a.blocks_per_image - nne + per - 1) / per;   // workgroups that shade empty tiles
@@ -135,26 +136,22 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
         }
         c = min(c, 1023);
         s_key[slot] = (unsigned short)c;
-        atomicAdd(&s_start[c], 1);
+        if (!a.block_sort) atomicAdd(&s_start[c], 1);
     }
-    __syncthreads();
-    // exclusive prefix over the keys in DESCENDING order: thread t owns keys 1023 - 4t .. 1020 - 4t
-    int h[4], mine = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { h[j] = s_start[1023 - (4 * tid + j)]; mine += h[j]; }
-    int wtot;
-    int before = wave_prefix_excl(mine, tid & 63, wtot);
-    if ((tid & 63) == 63) s_wave[tid >> 6] = wtot;
-    __syncthreads();
-    for (int w = 0; w < (tid >> 6); ++w) before += s_wave[w];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { s_start[1023 - (4 * tid + j)] = before; before += h[j]; }
-    __syncthreads();
-    // tiles with at least MM_HEAVY_CAND candidates come first: the slots in front of key MM_HEAVY_CAND - 1
-    if (tid == 0) { nheavy[2 * b] = min(s_start[MM_HEAVY_CAND - 1], MM_HEAVY_MAX); nheavy[2 * b + 1] = s_start[0]; }   // slots in front of key 0: not empty
-    __syncthreads();
-    for (int slot = tid; slot < nslot; slot += 256)
-        order[(size_t)b * nslot + atomicAdd(&s_start[s_key[slot]], 1)] = (unsigned short)(slot | (s_key[slot] == 0 ? 0x8000 : 0));
+    if (a.block_sort) {
+        // Screen bins of 16 pixels or more: the four tiles of a 16x16 block lie in ONE bin and walk the same candidate list.  The BLOCKS are
+        // sorted (key = the bin's count) and a block's four tiles stay together in the order, so that raster_fwd can hand them to four
+        // workgroups of one XCD at the same time (walk_image_rank, spread == 2): the bin's mask row and its candidates' records are then
+        // fetched from memory once and found in that XCD's L2 by the other three.
+        __syncthreads();
+        for (int blk = tid; blk < a.blocks_per_image; blk += 256) {
+            const int c = max(max(s_key[4 * blk], s_key[4 * blk + 1]), max(s_key[4 * blk + 2], s_key[4 * blk + 3]));
+            s_key[4 * blk] = s_key[4 * blk + 1] = s_key[4 * blk + 2] = s_key[4 * blk + 3] = (unsigned short)c;
+            atomicAdd(&s_start[c], 4);
+        }
+        tile_sort_scatter<256, 4>(nslot, s_key, s_start, s_wave, order + (size_t)b * nslot, nheavy + 2 * b);
+    } else
+        tile_sort_scatter<256, 1>(nslot, s_key, s_start, s_wave, order + (size_t)b * nslot, nheavy + 2 * b);
 }
 
 RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
@@ -172,6 +169,7 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     a.order = nullptr;
     a.nheavy = nullptr;
+    a.block_sort = 0;
     a.feats = nullptr; a.D = 0; a.interp = nullptr; a.soft_out = nullptr; a.face_idx64 = nullptr; a.options = d->options;
     return a;
 }
@@ -179,6 +177,7 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
 const unsigned short* launch_order(RasterArgs& a, unsigned short* order, int* nheavy, int* bincount, int B, void** prof_events, hipStream_t s) {
     const int nslot = 4 * a.blocks_per_image;
     a.order = nullptr; a.bincount = nullptr;
+    a.block_sort = walk_block_sort(a) ? 1 : 0;
     if (nslot > MM_ORDER_MAX_SLOTS || nslot > 0x7FFF) return nullptr;          // (entries are 15 bits + the empty flag)
     ProfScope po(prof_events, MM_PROF_ORDER, s);
     if (nslot > 1024 || a.words > 64) {                          // big screen / mesh: the bins' candidate counts by a parallel kernel first

@@ -26,7 +26,8 @@ struct RasterArgs {
     int* trcnt; int ntx_tex, ntiles_tex;     // (B,ntiles) covered pixels per 32x32-texel tile under their bilinear footprint: sizes the backward's record lists
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     const int* nheavy;                      // (B,2) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty
-    int spread;                             // sorted order: eight consecutive workgroups = eight ranks of one image (walk_image_rank)
+    int spread;                             // sorted order: eight consecutive workgroups = eight ranks of one image (walk_image_rank); 2: the four tiles of a block on one XCD
+    int block_sort;                         // the order kernel sorts 16x16 blocks, a block's four tiles stay together (bins of 16 pixels or more)
     const int* bincount;                    // (B,nbins) candidates per screen bin, or nullptr (small screens: the order kernel counts the mask bits itself)
     // outputs
     float* rgba;
@@ -642,16 +643,31 @@ inline bool walk_block_mode(const RasterArgs& a) {
 // others idle (13 776 faces at 512x512: half of all wave slots empty over the second half of the launch).  With RasterArgs::spread
 // eight consecutive workgroups are eight consecutive ranks of the SAME image instead: every XCD takes an eighth of every image, heavy
 // tiles first everywhere (512x512: 361 -> 261 us; 256x256: 105 -> 96).
-__device__ inline void walk_image_rank(int i, int B, bool spread, int& b, int& j) {
-    if (spread) { const int g = i >> 3; b = g % B; j = (g / B) * 8 + (i & 7); }
+// spread == 2 (block-sorted order, one tile per workgroup): 32 consecutive workgroups = 32 consecutive ranks of one image, dealt so that
+// ranks 4k .. 4k+3 -- the four tiles of one block, which walk the same bin's candidates -- are the four workgroups of the 32 that land on
+// the SAME XCD (i, i + 8, i + 16, i + 24): dispatched within a microsecond of each other, they share that XCD's L2.
+__device__ inline void walk_image_rank(int i, int B, int spread, int& b, int& j) {
+    if (spread == 2) { const int g = i >> 5; b = g % B; j = (g / B) * 32 + (i & 7) * 4 + ((i >> 3) & 3); }
+    else if (spread) { const int g = i >> 3; b = g % B; j = (g / B) * 8 + (i & 7); }
     else { b = i % B; j = i / B; }
 }
 inline bool walk_queue_mode(const RasterArgs& a) { return walk_queue_mode(a.options, a.bin_shift); }
-inline bool walk_spread(const RasterArgs& a) { return a.order != nullptr && 4 * a.blocks_per_image >= 1024; }
+// blocks instead of tiles are sorted where a block's four tiles share a bin (bins of 16 pixels or more) and tiles are walked one per workgroup
+inline bool walk_block_sort(const RasterArgs& a) {
+#ifdef MM_NO_BLOCK_SORT
+    return false;
+#else
+    return a.bin_shift >= 4 && !(a.options & MM_OPT_WALK_BLOCK);
+#endif
+}
+inline int walk_spread(const RasterArgs& a) {
+    if (a.order == nullptr || 4 * a.blocks_per_image < 1024) return 0;
+    return a.block_sort ? 2 : 1;
+}
 inline unsigned walk_grid(const RasterArgs& a, bool block) {
     if (!a.order) return (unsigned)a.B * (unsigned)a.blocks_per_image * (block ? 1u : 4u);
     const unsigned per_image = block ? (unsigned)(MM_HEAVY_MAX + (4 * a.blocks_per_image + 3) / 4) : (unsigned)a.blocks_per_image * 4u;
-    return (unsigned)a.B * ((per_image + 7u) & ~7u);             // (ranks beyond an image's last workgroup exit at once)
+    return (unsigned)a.B * ((per_image + 31u) & ~31u);           // (ranks beyond an image's last workgroup exit at once)
 }
 
 }  // namespace mm

@@ -93,7 +93,7 @@ __device__ inline TileCtx make_tile(const RasterArgs& a, int wv, int rank, bool&
     if (a.order) {
         const int nslot = 4 * a.blocks_per_image;
         int j;
-        walk_image_rank((int)blockIdx.x, a.B, a.spread != 0, t.b, j);
+        walk_image_rank((int)blockIdx.x, a.B, a.spread, t.b, j);
         if (rank >= 0) j = rank;
         const int nh = kBlock ? a.nheavy[2 * t.b] : 0;
         int idx;

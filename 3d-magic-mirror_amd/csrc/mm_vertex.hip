@@ -29,6 +29,7 @@ struct VertexFwdArgs {
     int bin_shift, nbx, nby, words;
     uint64_t* mask;          // (B,nbins,words) screen-bin candidate mask, written here (nullptr: not wanted)
     int* fflag;              // (B,F) "this face receives gradient from the pixels": cleared here, set by raster_fwd
+    unsigned* ticket;        // (B) arrival counter of the vertex backward's workgroups: cleared here (and by its last workgroup after use)
 };
 
 __device__ inline void block_camera(const float* azim, const float* elev, const float* dist, const float* bias, int b,
@@ -44,34 +45,10 @@ __device__ inline void block_camera(const float* azim, const float* elev, const 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
-    __shared__ float s_trig[4];
-    __shared__ Camera s_cam;
-    const int b = blockIdx.y, tid = threadIdx.x;
-    MM_PP_BEGIN();
-    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
-    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nltot; i += gridDim.x * gridDim.y * 256) a.ltot[i] = 0;
-    MM_PP_MARK(0);
-    // this lane's face: its corner ids and their raw positions depend on nothing the camera produces -- both trips to memory are in
-    // flight while four lanes do the fp64 trigonometry and one builds the look-at
-    const int f = blockIdx.x * 256 + tid;
-    float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f}, pc[3] = {0.f, 0.f, 0.f};
-    if (f < a.F) {
-        const int i0 = a.faces[f * 3 + 0], i1 = a.faces[f * 3 + 1], i2 = a.faces[f * 3 + 2];
-        const float* vb = a.vertices + (size_t)b * a.V * 3;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
-    }
-    block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
-    MM_PP_MARK(1);
-    if (blockIdx.x == 0 && tid < 12) a.T[b * 12 + tid] = s_cam.T[tid];
-    if (blockIdx.x == 0 && tid >= 64 && tid < 100) a.cam[b * 48 + tid - 64] = reinterpret_cast<const float*>(&s_cam)[tid - 64];
-    float T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = s_cam.T[i];
-
-    int bx0 = 0, by0 = 0, bw = 0, bh = 0;                         // inflated pixel box of this lane's face (none)
-    if (f < a.F) {
+// one face: camera transform of its three vertices, perspective divide, x multiplier, unit normal, inflated pixel box -> the packed
+// record the pixel stage streams (geo), attributes['face_normals'], cleared face flags.  The expressions of SURVEY 8(a)-a5, in their order.
+__device__ inline void face_record(const VertexFwdArgs& a, int b, int f, const float* pa, const float* pb, const float* pc, const float* T,
+                                   int& bx0, int& by0, int& bw, int& bh) {
     const Float3 A = to_camera(pa, T);
     const Float3 Bv = to_camera(pb, T);
     const Float3 C = to_camera(pc, T);
@@ -97,7 +74,37 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
     a.geo[o * 3 + 2] = make_float4(C.z, nz, __uint_as_float(org), __uint_as_float(ext));
     a.face_normals[o * 3 + 0] = nx; a.face_normals[o * 3 + 1] = ny; a.face_normals[o * 3 + 2] = nz;
     reinterpret_cast<int2*>(a.fflag)[o] = make_int2(0, 0);
+}
+
+__global__ __launch_bounds__(256) void vertex_fwd_kernel(VertexFwdArgs a) {
+    __shared__ float s_trig[4];
+    __shared__ Camera s_cam;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    MM_PP_BEGIN();
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.ntcnt; i += gridDim.x * gridDim.y * 256) a.tcnt[i] = 0;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nltot; i += gridDim.x * gridDim.y * 256) a.ltot[i] = 0;
+    MM_PP_MARK(0);
+    // this lane's face: its corner ids and their raw positions depend on nothing the camera produces -- both trips to memory are in
+    // flight while four lanes do the fp64 trigonometry and one builds the look-at
+    const int f = blockIdx.x * 256 + tid;
+    float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f}, pc[3] = {0.f, 0.f, 0.f};
+    if (f < a.F) {
+        const int i0 = a.faces[f * 3 + 0], i1 = a.faces[f * 3 + 1], i2 = a.faces[f * 3 + 2];
+        const float* vb = a.vertices + (size_t)b * a.V * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
     }
+    block_camera(a.azim, a.elev, a.dist, a.bias, b, s_trig, &s_cam);
+    MM_PP_MARK(1);
+    if (blockIdx.x == 0 && tid < 12) a.T[b * 12 + tid] = s_cam.T[tid];
+    if (blockIdx.x == 0 && tid == 12) a.ticket[b] = 0u;
+    if (blockIdx.x == 0 && tid >= 64 && tid < 100) a.cam[b * 48 + tid - 64] = reinterpret_cast<const float*>(&s_cam)[tid - 64];
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = s_cam.T[i];
+
+    int bx0 = 0, by0 = 0, bw = 0, bh = 0;                         // inflated pixel box of this lane's face (none)
+    if (f < a.F) face_record(a, b, f, pa, pb, pc, T, bx0, by0, bw, bh);
 
     // ---- screen binning: this wave's 64 faces are exactly mask word c (bin_wave_faces, mm_device.h) ---------------------------
     MM_PP_MARK(2);
@@ -112,6 +119,7 @@ struct VertexBwdArgs {
     float proj0, proj1, proj2;
     const int4* vc_table;   // (V,vc_stride) {face*3 + corner, the face's three vertex ids}, padded with -1
     int vc_stride;
+    const int32_t* faces;   // (F,3) vertex ids (the per-image form walks the faces)
     const float* vertices;
     const float *azim, *elev, *dist, *bias;
     const float* T;         // (B,12) saved by the forward
@@ -124,6 +132,7 @@ struct VertexBwdArgs {
     unsigned* ticket;       // (B) zeroed arrival counter
     int* tcnt; int ntcnt;   // texture-record counters, consumed by the gather before this kernel: cleared for the next backward
     const float* dl_part;   // (B,blocks,12) partial dL/dlights of the pixel backward
+    int geometry_only;      // nothing was rasterised (MMRenderDesc.geometry_only): no face has sweep items, no light gradient is written
     int blocks_per_image;
     float* grad_lights;
     float* grad_vertices;
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             const size_t o = (size_t)b * a.F + f;
             // the face's gradients = its sweep items' partial sums, added in index order (one item for most faces)
             float gx = 0.f, gy = 0.f, g[3] = {0.f, 0.f, 0.f};
-            const int2 cm = a.chunkmap[o];
+            const int2 cm = a.geometry_only ? make_int2(0, 0) : a.chunkmap[o];
             // the face's three vertices ride along with chunkmap: loaded whether or not the normal gradient below turns out to be zero
             // -- inside that branch they would cost a dependent trip to memory of their own
             const int i0 = ent.y, i1 = ent.z, i2 = ent.w;
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         __hip_atomic_store(a.dTpart + ((size_t)b * gridDim.x + blockIdx.x) * 12 + tid,
                            ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (blockIdx.x == 0) {   // dL/dlights (needs nothing of this kernel: the image's FIRST workgroup adds it up, off the last one's tail): sum of the pixel-backward workgroup partials; waves 1..3 take 3 components each, lanes stride over
+    if (blockIdx.x == 0 && !a.geometry_only) {   // dL/dlights (needs nothing of this kernel: the image's FIRST workgroup adds it up, off the last one's tail): sum of the pixel-backward workgroup partials; waves 1..3 take 3 components each, lanes stride over
         // the partials (independent loads), fixed butterfly order
         const int wv = tid >> 6, ln = tid & 63;
         if (wv >= 1) {
@@ -340,9 +349,198 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
         camera_backward(a.dist[b], s_cam, dT, &dd, &de, &da, db);
         a.grad_dist[b] = dd; a.grad_elev[b] = de; a.grad_azim[b] = da;
         a.grad_bias[2 * b] = db[0]; a.grad_bias[2 * b + 1] = db[1];
+        a.ticket[b] = 0u;                                        // every workgroup of the image has drawn: ready for the next backward on this workspace
     }
     MM_PP_MARK(5);
     MM_PP_FLUSH(vertex_bwd, (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The vertex backward PER IMAGE, for small templates (at most MM_VIMG_BWD_MAX_FACES faces): ONE workgroup of 1024 threads per image, two
+// phases through LDS instead of the ticket / partial-row round trip of vertex_bwd_kernel:
+//   A. face-major   a thread per face adds up the face's sweep-item sums (one item for most faces: the first two rows travel with the face's
+//                   vertices) and turns them ONCE per face -- not once per corner -- into dL/d(camera-space position) of its three corners:
+//                   the screen-space part through the perspective divide, the normal part through the cross product.  Nine floats per face
+//                   into LDS.
+//   B. vertex-major a thread per vertex adds its corners up in the static table's (ascending) order, writes dL/dvertex and its twelve terms
+//                   of dL/dT; one fixed-order workgroup reduction; thread 0 runs the camera chain from the forward's saved record.
+// No atomics, no ticket, no write-through partials, no second trip for the image's last workgroup: the chain is {ids, chunk map} ->
+// {vertices, item sums} -> LDS -> outputs.  Bitwise reproducible (fixed orders throughout).
+// ---------------------------------------------------------------------------------------------------------------------
+// (MM_VIMG_BWD_MAX_FACES = 1700, mm_device.h)   36 bytes of LDS per face: 61 KB of dynamic LDS at most, below the 64 KB a launch gets without opting in
+__global__ __launch_bounds__(1024) void vertex_image_bwd_kernel(VertexBwdArgs a) {
+    extern __shared__ float s_d[];                                // (F, 3 corners, 3)
+    __shared__ Camera s_cam;
+    __shared__ float s_red[16][12];
+    const int b = blockIdx.x, tid = threadIdx.x;
+#ifndef MM_DBG_KEEP_TCNT
+    for (int i = b * 1024 + tid; i < a.ntcnt; i += gridDim.x * 1024) a.tcnt[i] = 0;
+#endif
+    const float* vb = a.vertices + (size_t)b * a.V * 3;
+    // ---- trip 1: what depends on nothing (T, the camera record, this thread's faces' ids and chunk maps, its vertex and its corner list)
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = a.T[b * 12 + i];
+    if (tid >= 64 && tid < 100) reinterpret_cast<float*>(&s_cam)[tid - 64] = a.cam[b * 48 + tid - 64];
+    int fid[2][3]; int2 cm[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int f = tid + 1024 * k;
+        fid[k][0] = fid[k][1] = fid[k][2] = 0; cm[k] = make_int2(0, 0);
+        if (f < a.F) {
+            const PackedI3 i3 = *(const PackedI3*)(a.faces + f * 3);
+            fid[k][0] = i3.x; fid[k][1] = i3.y; fid[k][2] = i3.z;
+            if (!a.geometry_only) cm[k] = a.chunkmap[(size_t)b * a.F + f];
+        }
+    }
+    int it0[8]; float p0[3] = {0.f, 0.f, 0.f};                    // phase B's first vertex: its corner list and position ride along with trip 1
+#pragma unroll
+    for (int u = 0; u < 8; ++u) it0[u] = (tid < a.V && u < a.vc_stride) ? a.vc_table[(size_t)tid * a.vc_stride + u].x : -1;
+    if (tid < a.V) { const Packed3 v3 = *(const Packed3*)(vb + tid * 3); p0[0] = v3.x; p0[1] = v3.y; p0[2] = v3.z; }
+    // ---- phase A
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int f = tid + 1024 * k;
+        if (f >= a.F) continue;
+        const size_t o = (size_t)b * a.F + f;
+        float P[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const Packed3 v3 = *(const Packed3*)(vb + (size_t)fid[k][c] * 3); P[c][0] = v3.x; P[c][1] = v3.y; P[c][2] = v3.z; }
+        // the face's gradients = its sweep items' partial sums, added in index order: the first two rows in this trip (clamped addresses,
+        // selected afterwards; rows are 48 bytes, 16-byte aligned: three wide loads each), the rare rest one by one
+        float r[2][9];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4* row = (const float4*)(a.part + ((size_t)b * a.item_cap + min(cm[k].x + min(c, max(cm[k].y - 1, 0)), a.item_cap - 1)) * 12);
+            const float4 r0 = row[0], r1 = row[1]; const float r2 = a.part[((size_t)b * a.item_cap + min(cm[k].x + min(c, max(cm[k].y - 1, 0)), a.item_cap - 1)) * 12 + 8];
+            r[c][0] = r0.x; r[c][1] = r0.y; r[c][2] = r0.z; r[c][3] = r0.w; r[c][4] = r1.x; r[c][5] = r1.y; r[c][6] = r1.z; r[c][7] = r1.w; r[c][8] = r2;
+        }
+        float gn[3] = {0.f, 0.f, 0.f};
+        if (a.gfn) { const Packed3 g3 = *(const Packed3*)(a.gfn + o * 3); gn[0] = g3.x; gn[1] = g3.y; gn[2] = g3.z; }
+        float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c < cm[k].y) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) s[j] += r[c][j];
+            }
+        for (int c = 2; c < cm[k].y; ++c) {                       // (a close-up: faces of many 128-pixel chunks)
+            const float* row = a.part + ((size_t)b * a.item_cap + cm[k].x + c) * 12;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) s[j] += row[j];
+        }
+        const float g[3] = {s[6] + gn[0], s[7] + gn[1], s[8] + gn[2]};
+        Float3 cam3[3];
+        float d[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            cam3[c] = to_camera(P[c], T);
+            const float pz = cam3[c].z * a.proj2;
+            const float ipz = 1.f / pz;
+            const float xi = (cam3[c].x * a.proj0) * ipz, yi = (cam3[c].y * a.proj1) * ipz;
+            const float gx = s[c * 2], gy = s[c * 2 + 1];
+            d[c][0] = gx * a.proj0 * ipz;
+            d[c][1] = gy * a.proj1 * ipz;
+            d[c][2] = -(gx * xi + gy * yi) * a.proj2 * ipz;
+        }
+        if (g[0] != 0.f || g[1] != 0.f || g[2] != 0.f) {          // through the unit face normal
+            const float e0[3] = {cam3[1].x - cam3[0].x, cam3[1].y - cam3[0].y, cam3[1].z - cam3[0].z};
+            const float e1[3] = {cam3[2].x - cam3[0].x, cam3[2].y - cam3[0].y, cam3[2].z - cam3[0].z};
+            float n[3];
+            cross3(e0, e1, n);
+            const float len = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+            const float den = len + 1e-10f;
+            const float ng = (n[0] * g[0] + n[1] * g[1]) + n[2] * g[2];
+            const float iden = 1.f / den, cc = (len > 0.f) ? (ng * iden * iden) / len : 0.f;
+            float dn[3], de0[3], de1[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dn[j] = g[j] * iden - cc * n[j];
+            cross3(e1, dn, de0);
+            cross3(dn, e0, de1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { d[0][j] -= de0[j] + de1[j]; d[1][j] += de0[j]; d[2][j] += de1[j]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s_d[(f * 3 + c) * 3 + j] = d[c][j];
+    }
+    __syncthreads();
+    // ---- phase B
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int v = tid; v < a.V; v += 1024) {
+        const bool first = v == tid;
+        float p[3] = {p0[0], p0[1], p0[2]};
+        if (!first) { p[0] = vb[v * 3]; p[1] = vb[v * 3 + 1]; p[2] = vb[v * 3 + 2]; }
+        float d[3] = {0.f, 0.f, 0.f};
+        for (int sl0 = 0; sl0 < a.vc_stride; sl0 += 8) {          // eight entries per trip (valence is ~6)
+            int it[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) it[u] = it0[u];
+            if (!first || sl0 != 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) it[u] = sl0 + u < a.vc_stride ? a.vc_table[(size_t)v * a.vc_stride + sl0 + u].x : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (it[u] >= 0) { d[0] += s_d[it[u] * 3]; d[1] += s_d[it[u] * 3 + 1]; d[2] += s_d[it[u] * 3 + 2]; }
+        }
+        float* gv = a.grad_vertices + ((size_t)b * a.V + v) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            gv[i] = (T[i * 3 + 0] * d[0] + T[i * 3 + 1] * d[1]) + T[i * 3 + 2] * d[2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i * 3 + j] += p[i] * d[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[9 + j] += d[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = wave_sum(acc[i]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s_red[tid >> 6][i] = acc[i];
+    }
+    // dL/dlights: the pixel backward's per-workgroup partials, added by waves 13..15 (three components each; the last waves hold the fewest
+    // faces and vertices), lanes stride over the rows, fixed butterfly order
+    {
+        const int wv = tid >> 6, ln = tid & 63;
+        if (wv >= 13 && !a.geometry_only) {
+            float sum[3] = {0.f, 0.f, 0.f};
+            for (int k0 = ln; k0 < a.blocks_per_image; k0 += 256) {
+                float r4[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = k0 + 64 * u;
+                    const float* row = a.dl_part + ((size_t)b * a.blocks_per_image + min(kk, a.blocks_per_image - 1)) * 12 + (wv - 13) * 3;
+                    const bool ok = kk < a.blocks_per_image;
+                    r4[u][0] = ok ? row[0] : 0.f; r4[u][1] = ok ? row[1] : 0.f; r4[u][2] = ok ? row[2] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { sum[0] += r4[u][0]; sum[1] += r4[u][1]; sum[2] += r4[u][2]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sum[i] = wave_sum(sum[i]);
+                if (ln == 0) a.grad_lights[b * 9 + (wv - 13) * 3 + i] = sum[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float dT[12];
+        for (int i = 0; i < 12; ++i) {
+            float tot = 0.f;
+            for (int w = 0; w < 16; ++w) tot += s_red[w][i];
+            dT[i] = tot;
+        }
+        float dd, de, da, db[2];
+        camera_backward(a.dist[b], s_cam, dT, &dd, &de, &da, db);
+        a.grad_dist[b] = dd; a.grad_elev[b] = de; a.grad_azim[b] = da;
+        a.grad_bias[2 * b] = db[0]; a.grad_bias[2 * b + 1] = db[1];
+    }
 }
 
 int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
@@ -355,7 +553,8 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.tcnt = w.tcnt; a.ntcnt = w.ntcnt + d->B + d->B * w.ntiles;   // (+ the status words and the forward's per-tile counts: cleared by the forward only)
     a.ltot = w.ltot; a.nltot = d->B * MM_LSUB * 4;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
-    a.mask = w.binmask; a.fflag = w.fflag;
+    a.mask = d->geometry_only ? nullptr : w.binmask; a.fflag = w.fflag;      // (geometry only: nothing walks the screen bins)
+    a.ticket = w.ticket;
     dim3 grid((d->F + 255) / 256, d->B);
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_FWD, s);
       hipLaunchKernelGGL(vertex_fwd_kernel, grid, dim3(256), 0, s, a); }
@@ -374,6 +573,12 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.dl_part = w.dl_part; a.blocks_per_image = w.blocks_per_image; a.grad_lights = g->grad_lights;
     a.grad_vertices = g->grad_vertices;
     a.grad_azim = g->grad_azimuths; a.grad_elev = g->grad_elevations; a.grad_dist = g->grad_distances; a.grad_bias = g->grad_biases;
+    a.faces = d->faces; a.geometry_only = d->geometry_only;
+    if (vertex_bwd_per_image(d->B, d->F, d->vc_stride)) {
+        ProfScope ps(d->prof_events, MM_PROF_VERTEX_BWD, s);
+        hipLaunchKernelGGL(vertex_image_bwd_kernel, dim3(d->B), dim3(1024), (size_t)d->F * 9 * sizeof(float), s, a);
+        return launch_ok("vertex_image_bwd");
+    }
     { ProfScope ps(d->prof_events, MM_PROF_VERTEX_BWD, s);
       hipLaunchKernelGGL(vertex_bwd_kernel, dim3((d->V + 31) / 32, d->B), dim3(256), 0, s, a); }
     return launch_ok("vertex_bwd");

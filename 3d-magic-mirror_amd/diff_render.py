@@ -72,6 +72,20 @@ class _RenderFn(torch.autograd.Function):
         dev, B, H, W, vertices, textures, lights, bg, azimuths, elevations, distances, biases = _render_inputs(
             dr, no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases)
         st = dr._static(dev)
+        if want_imnormal == "geometry":                          # render_geometry: the vertex stage alone (MMRenderDesc.geometry_only)
+            fn = torch.empty((B, dr.num_faces, 3), device=dev, dtype=torch.float32)
+            d = dr._desc(st, B, False, vertices, textures, lights, None, azimuths, elevations, distances, biases, None, None, fn, None)
+            d.geometry_only = 1
+            nbytes = dr.workspace_bytes(d)
+            holder = _PooledWorkspace(dr._ws_pool, (str(dev), nbytes), nbytes, dev)
+            d.workspace, d.workspace_bytes = N.ptr(holder.buf), holder.buf.numel()
+            with torch.cuda.device(dev):
+                N.check(N.lib().mm_render_forward(ctypes.byref(d), N.current_stream(dev)), "mm_render_forward")
+            ctx.dr, ctx.geometry, ctx.ws_holder = dr, True, holder
+            ctx.save_for_backward(vertices, textures, azimuths, elevations, distances, biases)
+            ctx.set_materialize_grads(False)
+            return fn
+        ctx.geometry = False
         rgba = torch.empty((B, H, W, 4), device=dev, dtype=torch.float32)
         face_idx = torch.empty((B, H, W), device=dev, dtype=torch.int32)
         fn = torch.empty((B, dr.num_faces, 3), device=dev, dtype=torch.float32)
@@ -108,7 +122,24 @@ class _RenderFn(torch.autograd.Function):
         return rgba, fn, imn, face_idx, loss
 
     @staticmethod
-    def backward(ctx, g_rgba, g_fn, _g_imn, _g_idx, g_loss=None):
+    def backward(ctx, g_rgba, g_fn=None, _g_imn=None, _g_idx=None, g_loss=None):
+        if ctx.geometry:                                         # (g_rgba is dL/dface_normals here: the node's only output)
+            vertices, textures, azimuths, elevations, distances, biases = ctx.saved_tensors
+            if g_rgba is None:
+                return (None,) * 12
+            dr, dev, B = ctx.dr, azimuths.device, azimuths.shape[0]
+            g_fn = g_rgba.to(torch.float32).contiguous()
+            d = dr._desc(dr._static(dev), B, False, vertices, textures, None, None, azimuths, elevations, distances, biases, None, None, None, None)
+            d.geometry_only = 1
+            d.face_normals = g_fn.data_ptr()                     # (a valid pointer for the argument check; the backward does not read the normals)
+            ws = ctx.ws_holder.buf
+            d.workspace, d.workspace_bytes = N.ptr(ws), ws.numel()
+            gv = torch.empty_like(vertices)
+            ga, ge, gd, gb = torch.empty_like(azimuths), torch.empty_like(elevations), torch.empty_like(distances), torch.empty_like(biases)
+            g = N.MMRenderGrads(None, N.ptr(g_fn), N.ptr(gv), None, None, None, N.ptr(ga), N.ptr(ge), N.ptr(gd), N.ptr(gb))
+            with torch.cuda.device(dev):
+                N.check(N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), N.current_stream(dev)), "mm_render_backward")
+            return None, None, None, None, gv, None, None, None, ga, ge, gd, gb
         vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt = ctx.saved_tensors
         ws = ctx.ws_holder.buf
         dr, dev = ctx.dr, azimuths.device
@@ -233,6 +264,7 @@ class DiffRender(object):
         self._static_cache = {}
         self._desc_cache = {}
         self._ws_pool = {}                                       # (device, bytes) -> free render workspaces (see _PooledWorkspace)
+        self._status = None                                      # one pinned int32 the backward kernels add dropped-record counts to (MMRenderDesc.status_flag)
         # dibr_rasterization defaults (kaolin v0.12.0): sigmainv=7000, boxlen=0.02, knum=30, multiplier=1000, eps=1e-8
         self.sigmainv, self.boxlen, self.knum, self.multiplier, self.eps = 7000.0, 0.02, 30, 1000.0, 1e-8
         if verbose:
@@ -254,6 +286,7 @@ class DiffRender(object):
     def _render_node(self, no_mask, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases):
         """One autograd node for the render (+ the fused loss if gt is given).  With lib/mm_torch_ext.so built, the node is C++
         (csrc/mm_torch_ext.cpp: no Python in the backward); otherwise the torch.autograd.Function above issues the same ABI calls."""
+        self._raise_if_records_were_dropped()                    # (an overflow of an EARLIER step's backward: a host read of pinned memory, no sync)
         ext = None if self.check_texture_records else N.torch_ext()   # (the diagnostic switch lives in the Python nodes)
         if ext is None:
             return _RenderFn.apply(self, no_mask, self.emit_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases)
@@ -267,6 +300,28 @@ class DiffRender(object):
         return ext.render(N.fn_addr("mm_render_forward"), N.fn_addr("mm_render_fused_loss"), N.fn_addr("mm_render_backward"), proto, nbytes,
                           vertices, textures, lights, bg, azimuths, elevations, distances, biases, gt, bool(self.emit_imnormal),
                           float(self.image_weight), torch._C._cuda_getCurrentRawStream(dev.index))
+
+    def _status_ptr(self):
+        """Address of this object's pinned status word (device-writable host memory): every descriptor built here carries it, so that a
+        backward that drops texture-gradient records -- eager, C++ node or captured graph -- is noticed WITHOUT a synchronisation."""
+        if self._status is None:
+            self._status = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._status.data_ptr()
+
+    def poll_dropped_records(self, reset=True):
+        """Texture-gradient records dropped by backward passes that have COMPLETED since the last poll (no synchronisation: a host read)."""
+        if self._status is None:
+            return 0
+        n = int(self._status[0])
+        if n and reset:
+            self._status[0] = 0
+        return n
+
+    def _raise_if_records_were_dropped(self):
+        n = self.poll_dropped_records()
+        if n:
+            raise RuntimeError("an earlier mm_render_backward of this DiffRender dropped %d texture-gradient records (record pool overflow): the texture "
+                               "gradients of the affected images were NaN. Raise DiffRender.extra_texture_records_per_pixel." % n)
 
     def workspace_bytes(self, d):
         """Bytes of the render workspace for the shape in MMRenderDesc `d`: the library's minimum + the extra record pool asked for."""
@@ -300,6 +355,7 @@ class DiffRender(object):
             d.faces, d.face_uvs = N.ptr(st["faces"]), N.ptr(st["face_uvs"])
             d.vc_table, d.vc_stride = N.ptr(st["vc_table"]), int(st["vc_table"].shape[1])
             d.options = self.options
+            d.status_flag = self._status_ptr()
             hit = (bytes(d), self.workspace_bytes(d))
             if len(self._desc_cache) > 32:
                 self._desc_cache.clear()
@@ -323,6 +379,7 @@ class DiffRender(object):
             proto.faces, proto.face_uvs = N.ptr(st["faces"]), N.ptr(st["face_uvs"])
             proto.vc_table, proto.vc_stride = N.ptr(st["vc_table"]), int(st["vc_table"].shape[1])
             proto.options = self.options
+            proto.status_flag = self._status_ptr()
             if len(self._desc_cache) > 32:
                 self._desc_cache.clear()
             self._desc_cache[key] = proto
@@ -351,6 +408,43 @@ class DiffRender(object):
         self.last_face_idx = face_idx                   # kaolin returns it from dibr_rasterization; the reference drops it
         return rgbs, attributes
 
+    def render_many(self, attribute_sets, no_mask=False):
+        """Several INDEPENDENT ``render`` calls as one: the attribute sets (same shapes) are concatenated along the batch and rendered by ONE pass
+        of the kernels over sum(B) images -- the renders of trainer.py:276, :345 and :347 all exist as attributes before any of them runs, and
+        three launches-bound passes of 48 images cost more than one of 144.  Returns [(rgbs, attributes), ...] like the separate calls would:
+        per-set views of the batched outputs; gradients flow back through the concatenation into every set's own tensors.
+        Results per image are those of the separate calls bit for bit (an image's render does not depend on its batch)."""
+        sets = list(attribute_sets)
+        if not sets:
+            return []
+        keys = ('vertices', 'textures', 'lights', 'azimuths', 'elevations', 'distances', 'biases') + (('bg',) if no_mask else ())
+        sizes = [int(a['azimuths'].reshape(-1).shape[0]) for a in sets]
+        cat = {k: (sets[0][k] if len(sets) == 1 else torch.cat([a[k].reshape((n,) + tuple(a[k].shape[1:]) if a[k].dim() > 1 else (n,)) for a, n in zip(sets, sizes)], 0))
+               for k in keys}
+        rgba, fn, imn, face_idx = self._render_node(bool(no_mask), None, cat['vertices'], cat['textures'], cat['lights'], cat.get('bg'),
+                                                    cat['azimuths'], cat['elevations'], cat['distances'], cat['biases'])
+        self.last_face_idx = face_idx
+        out, o = [], 0
+        for a, n in zip(sets, sizes):
+            a['face_normals'] = fn[o:o + n]
+            a['imnormal'] = imn[o:o + n] if self.emit_imnormal else None
+            out.append((rgba[o:o + n].permute(0, 3, 1, 2), a))
+            o += n
+        return out
+
+    def render_geometry(self, **attributes):
+        """``render`` for the call site that throws the image away (trainer.py:367: ``_, Aire = diffRender.render(**Aire)`` keeps only
+        ``attributes['face_normals']``): the vertex stage alone -- camera, prepare_vertices, face normals -- with its backward to vertices and
+        camera; nothing is rasterised, shaded or stored.  Returns the attributes with 'face_normals' set (bit-identical to render's) and
+        'imnormal' None."""
+        a = attributes
+        self._raise_if_records_were_dropped()
+        N.require_device(a['azimuths'])
+        attributes['face_normals'] = _RenderFn.apply(self, False, "geometry", None, a['vertices'], a['textures'], a['lights'], None,
+                                                     a['azimuths'], a['elevations'], a['distances'], a['biases'])
+        attributes['imnormal'] = None
+        return attributes
+
     def render_recon(self, gt_data, no_mask=False, contour=0, **attributes):
         """render(**attributes) and recon_data(rendered, gt_data, no_mask) (contour = 0) in ONE pass over the pixels: the loss terms
         are reduced while the image is shaded and its gradient is formed inside the backward kernels (no loss launches, no dL/drgba
@@ -368,22 +462,23 @@ class DiffRender(object):
         self.last_face_idx = face_idx
         return loss, rgba.permute(0, 3, 1, 2), attributes
 
-    def graphed_step(self, example_attributes, gt_data, no_mask=False):
+    def graphed_step(self, example_attributes, gt_data, no_mask=False, fast_leaf_grads=False):
         """A captured (HIP-graph) render + recon_data + backward for attribute tensors of the example's shapes: returns a callable
         ``g(gt_data, **attributes) -> (loss, rgbs, attributes)`` with the semantics of ``render_recon`` whose forward and backward are one
         graph launch each (step.GraphedRenderRecon: static input slots ``g.inputs`` / ``g.gt``, static outputs).  The call sites it
-        serves: trainer.py:276 (render), :441 (recon_data), :509-518 (backward)."""
+        serves: trainer.py:276 (render), :441 (recon_data), :509-518 (backward).  ``fast_leaf_grads``: opt-in, leaf attributes get the
+        static gradient buffers as ``.grad`` without going through the engine (step._graphed_input_grads)."""
         from .step import GraphedRenderRecon
         N.require_device(*[v for k, v in example_attributes.items() if torch.is_tensor(v)], gt_data)
-        return GraphedRenderRecon(self, example_attributes, gt_data, no_mask=no_mask)
+        return GraphedRenderRecon(self, example_attributes, gt_data, no_mask=no_mask, fast_leaf_grads=fast_leaf_grads)
 
-    def graphed_render(self, example_attributes, no_mask=False):
+    def graphed_render(self, example_attributes, no_mask=False, fast_leaf_grads=False):
         """A captured (HIP-graph) ``render`` + backward for attribute tensors of the example's shapes: a callable ``g(**attributes) -> (rgbs,
         attributes)`` like ``render`` (step.GraphedRender).  For the renders of an iteration whose images feed a loss outside this class
         (trainer.py:345-367); one object per such render -- its outputs are static memory."""
         from .step import GraphedRender
         N.require_device(*[v for k, v in example_attributes.items() if torch.is_tensor(v)])
-        return GraphedRender(self, example_attributes, no_mask=no_mask)
+        return GraphedRender(self, example_attributes, no_mask=no_mask, fast_leaf_grads=fast_leaf_grads)
 
     # ---- networks.py:364-390 -------------------------------------------------------------------------------------
     def recon_data(self, pred_data, gt_data, no_mask=False, contour=0):

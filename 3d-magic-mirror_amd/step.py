@@ -180,6 +180,29 @@ class RenderLossStep:
         return out
 
 
+def _graphed_input_grads(owner, leaf_inputs, shapes, g):
+    """What a graphed node hands back for its eight attribute inputs after the backward graph has run (g: the static gradient buffers).
+    Default: every input gets its gradient THROUGH THE ENGINE, as a view of the static buffer in the input's own shape -- AccumulateGrad then
+    clones it for a leaf (a tensor it does not own), hooks fire, torch.autograd.grad works, and nothing the caller holds aliases memory the
+    next replay overwrites.  ``owner.fast_leaf_grads`` (opt-in): a LEAF input's ``.grad`` is assigned the static buffer itself (or accumulated
+    into) and the engine gets None -- eight copy launches fewer per step, for loops that only ever call ``loss.backward()`` and reset
+    ``.grad`` to None between steps; hooks do not fire and ``torch.autograd.grad`` sees no gradient on that path."""
+    out = []
+    for k, leaf, shp in zip(LEAVES, leaf_inputs, shapes):
+        if g[k] is None or shp is None:
+            out.append(None)
+        elif leaf is None or not owner.fast_leaf_grads:
+            out.append(g[k].reshape(shp))
+        else:
+            gk = g[k].reshape(shp)
+            if leaf.grad is None:
+                leaf.grad = gk
+            else:
+                leaf.grad.add_(gk)
+            out.append(None)
+    return out
+
+
 class _GraphedFn(torch.autograd.Function):
     """loss = graphed(leaves...): the forward replays the captured render + recon_data graph, the backward the captured backward graph."""
 
@@ -188,8 +211,9 @@ class _GraphedFn(torch.autograd.Function):
         gs._load_inputs(leaves, gt)
         gs.fwd_graph.replay()
         ctx.gs = gs
-        # inputs that are autograd LEAVES get their gradient assigned directly (see backward); the others receive it through the engine
+        # (fast_leaf_grads only: inputs that are autograd LEAVES get their gradient assigned directly, see _graphed_input_grads)
         ctx.leaf_inputs = [t if (t is not None and t.is_leaf and t.requires_grad) else None for t in leaves]
+        ctx.shapes = [None if t is None else tuple(t.shape) for t in leaves]
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(gs.step.face_idx)
         # loss, face_normals: differentiable outputs; the image carries no gradient (its only consumer, the loss, is inside)
@@ -206,19 +230,7 @@ class _GraphedFn(torch.autograd.Function):
                 leaf.grad = leaf.grad.clone()
         gs._load_upstream(g_loss, g_fn)
         gs.bwd_graph.replay()
-        out = []
-        for k, leaf in zip(LEAVES, ctx.leaf_inputs):
-            if leaf is None or g[k] is None:
-                out.append(g[k])                                 # a non-leaf input: the engine hands the static tensor to whatever produced it
-            else:
-                # A leaf: what AccumulateGrad would do, minus its defensive clone of a tensor it does not own (eight copy launches per step,
-                # more host time than the whole captured step): .grad IS the static buffer until the next call (class docstring).
-                if leaf.grad is None:
-                    leaf.grad = g[k]
-                else:
-                    leaf.grad.add_(g[k])
-                out.append(None)
-        return (None, None) + tuple(out)
+        return (None, None) + tuple(_graphed_input_grads(gs, ctx.leaf_inputs, ctx.shapes, g))
 
 
 class GraphedRenderRecon:
@@ -236,10 +248,11 @@ class GraphedRenderRecon:
     The ``.grad`` of an attribute that is an autograd leaf IS that static memory until then (reset it to None between steps, as
     ``optimizer.zero_grad()`` does by default; a ``.grad`` that is kept is copied out first, so accumulation over steps stays correct).  Results are bit-identical to the eager path (same kernels, same launch order)."""
 
-    def __init__(self, dr, example_attributes, gt, no_mask=True):
+    def __init__(self, dr, example_attributes, gt, no_mask=True, fast_leaf_grads=False):
         dev = example_attributes["azimuths"].device
         f32 = lambda t: t.detach().to(torch.float32).contiguous().clone()
         self.dr, self.dev, self.no_mask = dr, dev, bool(no_mask)
+        self.fast_leaf_grads = bool(fast_leaf_grads)             # see _graphed_input_grads
         self.inputs = {k: (f32(example_attributes[k]) if example_attributes.get(k) is not None and (k != "bg" or no_mask) else None) for k in LEAVES}
         self.gt = f32(gt)
         self.step = RenderLossStep(dr, self.inputs, self.gt, no_mask=no_mask, emit_imnormal=dr.emit_imnormal, fused=True)
@@ -275,7 +288,6 @@ class GraphedRenderRecon:
     def _load_upstream(self, g_loss, g_fn):
         if g_loss is None:
             self.g_loss.zero_()                                  # the loss took no part in what is differentiated: zero, never one
-            self._g_loss_one = False
         elif g_loss.data_ptr() != self.g_loss.data_ptr():
             self.g_loss.copy_(g_loss.detach().reshape(()), non_blocking=True)
         if g_fn is not None:
@@ -293,7 +305,10 @@ class GraphedRenderRecon:
         return loss, self.step.rgba.permute(0, 3, 1, 2), attributes
 
     def run(self):
-        """No autograd at all: replay forward + backward on what the slots hold (dL/dloss = 1); gradients in ``self.grads``."""
+        """No autograd at all: replay forward + backward on what the slots hold (dL/dloss = 1, dL/dface_normals = 0); gradients in ``self.grads``."""
+        self.g_loss.fill_(1.0)                                   # (whatever an earlier autograd backward left in the upstream slots)
+        if not self._g_fn_zero:
+            self.g_fn.zero_(); self._g_fn_zero = True
         self.fwd_graph.replay(); self.bwd_graph.replay()
         return self.step.loss
 
@@ -311,6 +326,7 @@ class _GraphedRenderFn(torch.autograd.Function):
         gr.fwd_graph.replay()
         ctx.gr = gr
         ctx.leaf_inputs = [t if (t is not None and t.is_leaf and t.requires_grad) else None for t in leaves]
+        ctx.shapes = [None if t is None else tuple(t.shape) for t in leaves]
         ctx.set_materialize_grads(False)
         return gr.step.rgba, gr.step.face_normals
 
@@ -331,17 +347,7 @@ class _GraphedRenderFn(torch.autograd.Function):
         elif not gr._g_fn_zero:
             gr.g_fn.zero_(); gr._g_fn_zero = True
         gr.bwd_graph.replay()
-        out = []
-        for k, leaf in zip(LEAVES, ctx.leaf_inputs):
-            if leaf is None or g[k] is None:
-                out.append(g[k])
-            else:
-                if leaf.grad is None:
-                    leaf.grad = g[k]
-                else:
-                    leaf.grad.add_(g[k])
-                out.append(None)
-        return (None,) + tuple(out)
+        return (None,) + tuple(_graphed_input_grads(gr, ctx.leaf_inputs, ctx.shapes, g))
 
 
 class GraphedRender:
@@ -352,10 +358,11 @@ class GraphedRender:
     the static gradient buffers as ``.grad``.  The upstream gradient of the image is copied into a static slot (50 MB at B=48, 256x256: the one
     copy this path cannot avoid -- the loss lives outside).  Bit-identical to the eager render."""
 
-    def __init__(self, dr, example_attributes, no_mask=True):
+    def __init__(self, dr, example_attributes, no_mask=True, fast_leaf_grads=False):
         dev = example_attributes["azimuths"].device
         f32 = lambda t: t.detach().to(torch.float32).contiguous().clone()
         self.dr, self.dev, self.no_mask = dr, dev, bool(no_mask)
+        self.fast_leaf_grads = bool(fast_leaf_grads)             # see _graphed_input_grads
         self.inputs = {k: (f32(example_attributes[k]) if example_attributes.get(k) is not None and (k != "bg" or no_mask) else None) for k in LEAVES}
         B, H, W = self.inputs["azimuths"].shape[0], dr.render_height, dr.image_size
         self.step = RenderLossStep(dr, self.inputs, torch.zeros((B, 4, H, W), device=dev), no_mask=no_mask, emit_imnormal=dr.emit_imnormal, fused=False)

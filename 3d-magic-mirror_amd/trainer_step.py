@@ -133,12 +133,15 @@ def default_opt():
 
 
 class TrainerStep:
-    def __init__(self, template, image_size, batch, device, ratio=1, opt=None, seed=0, graphed=False):
+    def __init__(self, template, image_size, batch, device, ratio=1, opt=None, seed=0, graphed=False, lean=False):
         """graphed: the four renders go through DiffRender.graphed_render (one captured forward / backward graph pair per render of the iteration:
-        their outputs are static memory) instead of the eager autograd nodes -- same bits, less host time."""
+        their outputs are static memory) instead of the eager autograd nodes -- same bits, less host time.
+        lean: the three renders whose attributes exist up front (trainer.py:276,345,347) as ONE DiffRender.render_many call of 3B images, and the
+        fourth (trainer.py:367, whose image is discarded) as DiffRender.render_geometry -- same losses, same gradients."""
         self.opt = opt or default_opt()
         self.dev, self.B = device, batch
         self.graphed, self._gr = bool(graphed), {}
+        self.lean = bool(lean) and not graphed
         self.dr = DiffRender(template, image_size, ratio=ratio)
         torch.manual_seed(seed)
         self.netE = AttributeNet(self.dr.vertices_init, bg=self.opt.bg).to(device)
@@ -173,7 +176,8 @@ class TrainerStep:
         o, dr, Bn = self.opt, self.dr, self.B
         self.optimizerE.zero_grad(set_to_none=True)
         Ae = self.netE(self.Xa)
-        Xer, Ae = self._render(0, Ae)                                                      # render #1
+        if not self.lean:
+            Xer, Ae = self._render(0, Ae)                                                  # render #1
         Ae90 = deep_copy(Ae)
         sign = torch.where(self._u(Bn) < 0.5, -1.0, 1.0)
         Ae90["azimuths"] = -self._u(Bn, lo=o.hard_range, hi=180.0 - o.hard_range) * sign
@@ -189,10 +193,19 @@ class TrainerStep:
               "textures": a_t * Aa["textures"] + (1 - a_t) * Ab["textures"],
               "bg": (a_t * Aa["bg"] + (1 - a_t) * Ab["bg"]) if o.bg else None,
               "lights": a_l * Aa["lights"] + (1 - a_l) * Ab["lights"]}
-        Xir, Ai = self._render(1, Ai)                                                      # render #2
-        Xer90, Ae90 = self._render(2, Ae90) if o.hard else (Xer, Ae)                       # render #3
+        if self.lean and o.hard:                                                           # renders #1-#3 in one pass over 3B images
+            (Xer, Ae), (Xir, Ai), (Xer90, Ae90) = dr.render_many([Ae, Ai, Ae90], no_mask=o.bg)
+        elif self.lean:
+            (Xer, Ae), (Xir, Ai) = dr.render_many([Ae, Ai], no_mask=o.bg)
+            Xer90, Ae90 = Xer, Ae
+        else:
+            Xir, Ai = self._render(1, Ai)                                                  # render #2
+            Xer90, Ae90 = self._render(2, Ae90) if o.hard else (Xer, Ae)                   # render #3
         Aire = self.netE(Xir.detach().clone())
-        _, Aire = self._render(3, Aire)                                                    # render #4 (face_normals only)
+        if self.lean:
+            Aire = dr.render_geometry(**Aire)                                              # render #4: its image is discarded (trainer.py:367)
+        else:
+            _, Aire = self._render(3, Aire)                                                # render #4 (face_normals only)
         outs = self.critic(torch.cat((Xer90[:, :3], Xir[:, :3]), 0))
         o1, o2 = torch.split(outs, Bn, 0)
         lossR_fake = o.lambda_gan * (-o1.mean() - o.ganw * o2.mean()) / (1.0 + o.ganw)
@@ -221,10 +234,14 @@ class TrainerStep:
                     if torch.is_tensor(v):
                         v.grad = None
             Ae, Ai, A9, Ar = (dict(A) for A in sets)
-            Xer, Ae = self._render(0, Ae)
-            Xir, Ai = self._render(1, Ai)
-            Xer90, A9 = self._render(2, A9)
-            _, Ar = self._render(3, Ar)
+            if self.lean:
+                (Xer, Ae), (Xir, Ai), (Xer90, A9) = dr.render_many([Ae, Ai, A9], no_mask=o.bg)
+                Ar = dr.render_geometry(**Ar)
+            else:
+                Xer, Ae = self._render(0, Ae)
+                Xir, Ai = self._render(1, Ai)
+                Xer90, A9 = self._render(2, A9)
+                _, Ar = self._render(3, Ar)
             l = dr.recon_data(Xer, self.Xa, no_mask=o.bg) + 1e-4 * (Xer90[:, :3].mean() + Xir[:, :3].mean())
             r1, r2, r3 = dr.regularization(Ae, Ai, Ar, o)
             (l + r1 + r2 + r3).backward()
@@ -263,6 +280,15 @@ def bench(device, steps=8, warmup=3, template=None, image_size=256, batch=48):
     for _ in range(2):
         rpg()
     t_rp_g = timed(rpg, steps)
+    # the same step with renders #1-#3 as one render_many call and #4 geometry-only (lean)
+    tl = TrainerStep(template, image_size, batch, device, lean=True)
+    for _ in range(warmup):
+        tl.step()
+    t_step_l = timed(tl.step, steps)
+    rpl = tl.render_path_only()
+    for _ in range(2):
+        rpl()
+    t_rp_l = timed(rpl, steps)
     nparam = sum(p.numel() for p in ts.netE.parameters())
     return {"workload": "config3: template ellipsoid (V=%d,F=%d), B=%d, %dx%d, texture %dx%d; ResNet-18 x2 + conv stacks (%.1f M params) -> "
                         "4 renders (trainer.py order) -> recon_data -> regularisers (chamfer IC) -> one backward -> Adam"
@@ -272,5 +298,7 @@ def bench(device, steps=8, warmup=3, template=None, image_size=256, batch=48):
             "render_path_ms": round(t_rp * 1e3, 3), "render_path_share": round(t_rp / t_step, 3),
             "graphed_renders": {"images_per_s": round(batch / t_step_g, 1), "ms_per_step": round(t_step_g * 1e3, 3), "render_path_ms": round(t_rp_g * 1e3, 3),
                                 "loss": float(tg.last["loss"])},
+            "lean": {"images_per_s": round(batch / t_step_l, 1), "ms_per_step": round(t_step_l * 1e3, 3), "render_path_ms": round(t_rp_l * 1e3, 3),
+                     "loss": float(tl.last["loss"]), "what": "renders #1-#3 as one DiffRender.render_many call (3B images), #4 as render_geometry"},
             "steps": steps, "loss": loss,
             "encoder_params": nparam}

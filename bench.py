@@ -20,7 +20,8 @@ steps, each repetition bracketed by barrier + synchronize: the driver's short --
                       trainer.py makes, :276,441,509-518), one stream.
   value_api_fused     the same step through DiffRender.render_recon (loss folded into the render kernels).
   value_api_graphed   the same step through DiffRender.graphed_step: forward and backward one captured HIP graph each behind one autograd node;
-                      _slots: the caller writes its attributes into the graph's static input slots (no copies inside the call).
+                      _slots: the caller writes its attributes into the graph's static input slots (no copies inside the call) and opts in to
+                      fast_leaf_grads (leaf attributes get the static gradient buffers as .grad, not through the engine).
   value_shim          the UN-FUSED compatibility path: the kaolin-shaped operators of the import boundary called in the order of the reference's
                       DiffRender.render (networks.py:278-317; shim_chain.py) + recon_data + backward -- what a maintainer gets who only switches sys.path.
 Every stream rotates through --rotate distinct synthetic batches (default 8 per stream: > 256 MiB of inputs in total, more than
@@ -66,12 +67,17 @@ CONFIGS = {
 }
 
 
-def algorithmic_bytes(kernel, B, F, V, HW, T):
+def algorithmic_bytes(kernel, B, F, V, HW, T, fused=True, imnormal=True):
     """Per-launch algorithmic HBM bytes (DESIGN.md 'Kernels'): the share of SURVEY 8(d)'s A = 140F + 36T + 56HW that one
-    kernel owns (fp32, int32 face_idx, every logical tensor crossing HBM once per direction it is needed)."""
+    kernel owns (fp32, int32 face_idx, every logical tensor crossing HBM once per direction it is needed).
+    raster_fwd is SURVEY 8(d)'s forward minus the vertex stage: it reads the face records (52F) and the texture (12T) and writes rgba
+    (16HW) and face_idx (4HW); with the loss folded in (fused) it is also the kernel that reads the ground truth (16HW: 8(d) lists it
+    under "fwd reads", the un-fused build reads it in recon_partial instead), and when attributes['imnormal'] is materialised
+    (networks.py:320; the headline does) it writes 12HW more.  Not counted although moved: the background it composites over
+    (12HW read), the silhouette state it leaves for the backward (8HW)."""
     per_image = {
         "vertex_fwd": 12 * V + 52 * F,
-        "raster_fwd": 52 * F + 12 * T + 20 * HW,
+        "raster_fwd": 52 * F + 12 * T + 20 * HW + (16 * HW if fused else 0) + (12 * HW if imnormal else 0),
         "recon_partial": 32 * HW,
         "recon_bwd": 48 * HW,
         "order": 0,
@@ -93,18 +99,18 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
-def load_counters(name, config):
+def load_counters(name, config, suffix=""):
     """(per-kernel dict or None, note) from profiles/<name>_latest.json for this config, only if measured on these sources."""
     path = os.path.join(ROOT, "profiles", name + "_latest.json")
     try:
         j = json.load(open(path))
     except Exception:
         return None, "no " + os.path.basename(path)
-    if config not in j:
+    if config + suffix not in j:
         return None, "not collected for " + config
     if j.get("csrc_digest", {}).get(config) != csrc_digest():
         return None, "stale: kernels changed since the PMC pass (%s)" % j.get("note", "")
-    return j[config], j.get("note", "")
+    return j[config + suffix], j.get("note", "")
 
 
 def usable_cpus():
@@ -398,7 +404,8 @@ def main():
         e2f, _ = timed_median(one_api_fused, args.api_steps, reps=3)
         api_fused_value = round(world * B * args.api_steps / e2f, 1)
         # DiffRender.graphed_step: (a) attributes arrive as fresh tensors and are copied into the static slots; (b) the caller writes into the slots
-        gs = dr_api.graphed_step(batches[0][0][0], batches[0][0][1], no_mask=True)
+        gs = dr_api.graphed_step(batches[0][0][0], batches[0][0][1], no_mask=True)     # gradients through the autograd engine (default)
+        gs_fast = dr_api.graphed_step(batches[0][0][0], batches[0][0][1], no_mask=True, fast_leaf_grads=True)   # opt-in: leaves get the static buffers as .grad
 
         def one_api_graphed():
             k = ctr2[0] % nrot; ctr2[0] += 1
@@ -411,13 +418,13 @@ def main():
             one_api_graphed()
         e2g, _ = timed_median(one_api_graphed, args.api_steps, reps=3)
         api_graphed_value = round(world * B * args.api_steps / e2g, 1)
-        slot_leaves = {k: gs.inputs[k].requires_grad_(True) for k in stepmod.LEAVES}
+        slot_leaves = {k: gs_fast.inputs[k].requires_grad_(True) for k in stepmod.LEAVES}
         slot_att = dict(batches[0][0][0]); slot_att.update(slot_leaves)
 
-        def one_api_graphed_slots():                              # (the networks' outputs land in the slots; here they simply stay)
+        def one_api_graphed_slots():                              # (the networks' outputs land in the slots; here they simply stay; fast_leaf_grads)
             for v in slot_leaves.values():
                 v.grad = None
-            gs(gs.gt, **slot_att)[0].backward()
+            gs_fast(gs_fast.gt, **slot_att)[0].backward()
         for _ in range(10):
             one_api_graphed_slots()
         e2s, _ = timed_median(one_api_graphed_slots, args.api_steps, reps=3)
@@ -462,14 +469,21 @@ def main():
         step.disable_profiling()
         kernels_us = {k: float(np.mean(v)) for k, v in acc.items() if np.isfinite(np.mean(v))}
         dom = max(kernels_us, key=kernels_us.get)
-        nbytes = algorithmic_bytes(dom, B, dr.num_faces, dr.num_vertices, H * W, Ht * Wt)
+        nbytes = algorithmic_bytes(dom, B, dr.num_faces, dr.num_vertices, H * W, Ht * Wt, fused=not args.unfused, imnormal=True)
         achieved = nbytes / (kernels_us[dom] * 1e-6) / 1e9
         traffic_all, tnote = load_counters("traffic", args.config)
-        step_bytes = (140 * dr.num_faces + 36 * Ht * Wt + 56 * H * W) * B
+        traffic_rw, _ = load_counters("traffic", args.config, suffix="_rw")
+        step_bytes = (140 * dr.num_faces + 36 * Ht * Wt + 56 * H * W + 12 * H * W) * B      # SURVEY 8(d)'s A + the imnormal output the step writes
         step_us_one = (1e6 * B * world / one_stream) if one_stream else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": (traffic_all or {}).get(dom), "traffic_note": tnote,
+                    "traffic_read": (traffic_rw or {}).get(dom, [None, None])[0], "traffic_write": (traffic_rw or {}).get(dom, [None, None])[1],
+                    "traffic_formula": "2*FETCH_SIZE + WRITE_SIZE (KiB x 1024), separate --pmc passes; per-pattern factors measured on this path's "
+                                       "access patterns: profiles/r04_fetch_calibration.json",
                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(kernels_us[dom], 3),
+                    "duration_source": "hip_events (recorded by the library around the launch on its own stream; ~2.5 us longer per kernel than "
+                                       "rocprofv3's kernel-trace durations, which profiles/*_kernel_stats.md quote)",
+                    "algorithmic_includes": "face records 52F, texture 12T, rgba 16HW, face_idx 4HW, ground truth 16HW (fused loss), imnormal 12HW",
                     "whole_step": {"algorithmic_bytes": step_bytes,
                                    "frac_overlapped": round(step_bytes / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBPS, 5),
                                    "frac_one_stream": round(step_bytes / (step_us_one * 1e-6) / 1e9 / PEAK_HBM_GBPS, 5) if step_us_one else None}}
@@ -534,6 +548,12 @@ def main():
                          "(image, band of rows) with band-private accumulators in the backward's scatters; "
                          "CPU restatement of the kaolin DIB-R semantics, not kaolin" % (n_all, B, name, H, W)}
 
+    # N > 1: proof, in the line itself, that N ranks took part over the communicator the timed region used
+    ranks_seen, dist_backend = 1, None
+    if world > 1:
+        one_t = torch.ones(1, device=dev)
+        dist.all_reduce(one_t)
+        ranks_seen, dist_backend = int(one_t.item()), dist.get_backend()
     if rank == 0:
         total_images = world * B * args.steps
         head = e1 if args.mode == "eager" else elapsed           # eager: the one-stream leg is the headline
@@ -544,6 +564,7 @@ def main():
             "ms_per_step": round(head / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "value_is_b48_one_stream": args.mode == "eager",
+            "ranks_seen": ranks_seen, "dist_backend": dist_backend,
             "timing": {"reps": max(1, args.reps), "statistic": "median over the repetitions of the K-step timed region",
                        "spread_pct_of_median": spread(e1_all if args.mode == "eager" else elapsed_all)},
             "config": {"workload": "%s: template %s (V=%d,F=%d), B=%d per GPU, %dx%d, texture %dx%d, no_mask, fwd+loss+bwd to all "

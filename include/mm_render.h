@@ -93,6 +93,17 @@ typedef struct MMRenderDesc {
     float* fused_loss;              /* (1) device scalar, written by mm_render_backward; may be NULL */
     const float* fused_grad_loss;   /* (1) device scalar dL/dloss, or NULL for 1 */
     int32_t options;                /* bit set of MM_OPT_* (below); 0 = the semantics of SURVEY.md 8(a) */
+    /* 1: GEOMETRY ONLY -- the call site that discards the image and keeps attributes['face_normals'] (trainer.py:367:
+     * `_, Aire = diffRender.render(**Aire)`).  mm_render_forward then runs the vertex stage alone (camera, prepare_vertices,
+     * face_normals; nothing is rasterised, rgba / face_idx / imnormal are not written and may be NULL); mm_render_backward takes
+     * MMRenderGrads.grad_face_normals (required) and writes grad_vertices and the four camera gradients only -- the texture, light and
+     * background gradients of such a render are identically zero and are NOT written (their pointers may be NULL). */
+    int32_t geometry_only;
+    /* optional, may be NULL: one int32 the device can write -- device memory, or PINNED HOST memory, which the host can then poll without
+     * synchronising.  mm_render_backward adds to it the number of texture-gradient records it had to drop (see mm_query_workspace /
+     * mm_render_status): 0 stays 0.  Lets a caller that never synchronises (autograd nodes, captured graphs) still turn an overflowing
+     * record pool into an error one step later instead of training on NaN texture gradients. */
+    int32_t* status_flag;
 } MMRenderDesc;
 
 /* MMRenderDesc.options / MMDibrDesc.options: 0 = the semantics of SURVEY.md 8(a) (the oracle's defaults).  The bits switch,
@@ -189,6 +200,10 @@ int mm_recon_data_backward(const MMReconDesc* desc, mm_stream_t stream);
  * ------------------------------------------------------------------------------------------------------------------ */
 int mm_nearest_neighbour(int32_t B, int32_t N, int32_t M, const float* x, const float* y, float* dist, int32_t* idx,
                          mm_stream_t stream);
+/* Both directions of pytorch3d.loss.chamfer_distance in ONE launch (networks.py:342,356 always needs both): for every x its
+ * nearest y (dist_x, idx_x: (B,N)) and for every y its nearest x (dist_y, idx_y: (B,M)).  Same results as two calls above. */
+int mm_chamfer_nearest(int32_t B, int32_t N, int32_t M, const float* x, const float* y, float* dist_x, int32_t* idx_x,
+                       float* dist_y, int32_t* idx_y, mm_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------------------------------
  * Mesh regularisers: replaces DiffRender.calc_reg_loss / calc_reg_edge / calc_reg_depth /
@@ -433,8 +448,9 @@ const char* mm_last_error_detail(void);
 size_t mm_struct_size(int which);
 /* Bumped whenever a struct or the meaning of a field changes (2: op boundary added, reserved uv-tile fields and profiling slot
  * MM_PROF_BIN removed, options bits defined; 3: MMRenderDesc takes the fixed-stride vertex -> corner table instead of the CSR,
- * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN).  Bindings must refuse a library whose version differs from what they mirror. */
-#define MM_ABI_VERSION 3
+ * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, mm_chamfer_nearest).  Bindings must refuse a library whose
+ * version differs from what they mirror. */
+#define MM_ABI_VERSION 4
 int mm_abi_version(void);
 
 #ifdef __cplusplus

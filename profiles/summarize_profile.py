@@ -66,9 +66,9 @@ if st:
         dur[short(r["Name"])] = float(r["AverageNs"]) / 1e3
         lines.append("| %s | %s | %.2f | %.1f |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
     step_us = tot / calls / 1e3
-    A = (140 * F + 36 * T + 56 * HW) * B
+    A = (140 * F + 36 * T + 56 * HW + 12 * HW) * B              # SURVEY 8(d)'s A + the imnormal output the step writes
     lines += ["", "sum of per-step kernel time: **%.1f us** (%.0f images/s if launches were back to back); algorithmic bytes per step "
-                  "A = (140F + 36T + 56HW)B = %.1f MB -> %.0f GB/s = **%.1f %% of 8 TB/s**" % (step_us, B / (step_us * 1e-6), A / 1e6, A / step_us / 1e3, 100 * A / step_us / 1e3 / 8000)]
+                  "A = (140F + 36T + 56HW + 12HW imnormal)B = %.1f MB -> %.0f GB/s = **%.1f %% of 8 TB/s**" % (step_us, B / (step_us * 1e-6), A / 1e6, A / step_us / 1e3, 100 * A / step_us / 1e3 / 8000)]
     log = os.path.join(src, "stats", "bench.log")
     if os.path.exists(log):
         js = [l for l in open(log).read().splitlines() if l.startswith("{")]
@@ -76,7 +76,7 @@ if st:
             j = json.loads(js[-1])
             lines += ["", "bench line of the profiled run: value %.0f images/s, %.4f ms/step (rocprofv3 attached)" % (j["value"], j["ms_per_step"])]
 
-traffic, valu = {}, {}
+traffic, traffic_rw, valu = {}, {}, {}
 if pmc:
     lines += ["", "## HBM roofline per kernel (PMC in separate --pmc passes; traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB)", "",
               "| kernel | algorithmic MB/launch | avg us | achieved GB/s | frac of 8 TB/s | PMC traffic MB | traffic / algorithmic | L2 hit % |",
@@ -86,6 +86,7 @@ if pmc:
             continue
         b = (2 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0)) * 1024
         traffic[kname(k)] = int(b)
+        traffic_rw[kname(k)] = [int(2 * c["FETCH_SIZE"] * 1024), int(c.get("WRITE_SIZE", 0) * 1024)]
         alg = bench.algorithmic_bytes(kname(k), B, F, V, HW, T)
         hit, miss = c.get("TCC_HIT_sum", 0), c.get("TCC_MISS_sum", 0)
         if alg and k in dur:
@@ -125,6 +126,7 @@ def merge(fname, key, values, note):
 
 if traffic:
     merge("traffic_latest.json", config, traffic, "(2*FETCH_SIZE+WRITE_SIZE)*1024 per launch, " + tag)
+    merge("traffic_latest.json", config + "_rw", traffic_rw, "(2*FETCH_SIZE+WRITE_SIZE)*1024 per launch, " + tag)
 if valu:
     merge("valu_latest.json", config, valu, "SQ_INSTS_VALU per launch, " + tag)
 open(os.path.join(out, "%s_%s_kernel_stats.md" % (tag, config)), "w").write("\n".join(lines) + "\n")

@@ -184,6 +184,12 @@ def test_texture_record_pool_overflow_is_loud_and_a_larger_workspace_holds_it(pk
     for k in LEAVES:
         if k != "textures":
             _close(datt[k].grad.cpu().numpy(), g_o[k])
+    # ... and loud WITHOUT a diagnostic switch or a synchronisation of the caller's: the backward added the dropped records to the object's pinned
+    # status word (MMRenderDesc.status_flag), and the next render of this object -- any node flavour -- raises
+    assert dr.poll_dropped_records(reset=False) > 0
+    with pytest.raises(RuntimeError, match="dropped"):
+        dr.render(no_mask=True, **{k: (v.detach() if torch.is_tensor(v) else v) for k, v in datt.items()})
+    assert dr.poll_dropped_records() == 0                          # (reported once)
 
     dr, datt, gt, inp, proj, H, W, loss = run(0.0, True)           # the class API's diagnostic switch raises instead
     with pytest.raises(RuntimeError, match="texture-record pool"):
@@ -404,6 +410,82 @@ def test_graphed_step_replays_the_eager_path_bit_for_bit(pkg):
     assert torch.equal(loss_r, loss_e.detach())
     for k in LEAVES:
         assert torch.equal(gs.grads[k], d3[k].grad), k
+
+
+def test_geometry_only_render_is_the_render_without_the_image(pkg):
+    """DiffRender.render_geometry (MMRenderDesc.geometry_only), for the call site that discards the image (trainer.py:367): face_normals
+    are render's bit for bit, and the gradient a loss on them sends to vertices and camera is what the full render's backward gives when
+    only face_normals is differentiated; twice after one forward (retain_graph) as well."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 5, 64, seed=81)
+    w = torch.linspace(-1.0, 1.0, 5 * dr.num_faces * 3, device=dev).reshape(5, dr.num_faces, 3)
+    _, out = dr.render(no_mask=True, **datt)
+    (out["face_normals"] * w).sum().backward()
+    ref_fn = out["face_normals"].detach().clone()
+    ref = {k: datt[k].grad.clone() for k in ("vertices", "azimuths", "elevations", "distances", "biases")}
+    lv = {k: datt[k].detach().clone().requires_grad_(True) for k in LEAVES}
+    a = dict(datt); a.update(lv)
+    out_g = dr.render_geometry(**a)
+    assert out_g["imnormal"] is None and torch.equal(out_g["face_normals"].detach(), ref_fn)
+    tot = (out_g["face_normals"] * w).sum()
+    tot.backward(retain_graph=True)
+    for k, r in ref.items():
+        _close(lv[k].grad.cpu().numpy(), r.cpu().numpy(), 1e-6)
+    assert lv["textures"].grad is None and lv["lights"].grad is None and lv["bg"].grad is None
+    first = {k: lv[k].grad.clone() for k in ref}
+    tot.backward()                                               # a second backward on the same workspace: the arrival counter was left clean
+    for k in ref:
+        assert torch.equal(lv[k].grad, first[k] + first[k]), k
+
+
+def test_graphed_step_keeps_autograd_semantics(pkg):
+    """The graphed node's gradients go through the engine by default: torch.autograd.grad returns them, tensor hooks fire, a leaf of another
+    (reshapeable) shape is served, and a gradient the caller keeps is not overwritten by the next replay.  fast_leaf_grads is opt-in and
+    gives the same numbers; run() does not inherit the upstream slots of an earlier autograd backward."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 4, 64, seed=71)
+    gs = dr.graphed_step(datt, gt.to(dev), no_mask=True)
+    lv = {k: datt[k].detach().clone().requires_grad_(True) for k in LEAVES}
+    lv["azimuths"] = datt["azimuths"].detach().clone().reshape(-1, 1).requires_grad_(True)       # (B,1) instead of (B)
+    a = dict(datt); a.update(lv)
+    loss_e, _, _ = dr.render_recon(gt.to(dev), no_mask=True, **{k: (v.detach().clone().requires_grad_(True) if k in LEAVES else v) for k, v in datt.items()})
+    fired = []
+    lv["lights"].register_hook(lambda g: fired.append(g.clone()))
+    loss, _, _ = gs(gt.to(dev), **a)
+    assert torch.equal(loss.detach(), loss_e.detach())
+    got = torch.autograd.grad(loss, [lv[k] for k in LEAVES], retain_graph=True)
+    assert all(g is not None for g in got) and got[LEAVES.index("azimuths")].shape == (4, 1)
+    assert all(lv[k].grad is None for k in LEAVES)               # autograd.grad has no side effect on .grad
+    loss.backward()
+    assert len(fired) == 2 and torch.equal(fired[0], lv["lights"].grad)
+    kept = {k: lv[k].grad for k in LEAVES}
+    snap = {k: v.clone() for k, v in kept.items()}
+    for k, g in zip(LEAVES, got):
+        assert torch.equal(g, snap[k]), k
+    # another step on other inputs: what the caller kept must not change under it
+    _, _, d2, gt2, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", 4, 64, seed=72)
+    lv2 = {k: d2[k].detach().clone().requires_grad_(True) for k in LEAVES}
+    a2 = dict(d2); a2.update(lv2)
+    out2 = gs(gt2.to(dev), **a2)
+    (out2[2]["face_normals"].sum() * 1e-3).backward()            # the loss unused: its upstream slot is zero after this
+    torch.cuda.synchronize()
+    for k in LEAVES:
+        assert torch.equal(kept[k], snap[k]), k
+    # run() after that backward: dL/dloss = 1 and no face-normal gradient, whatever the slots held
+    with torch.no_grad():
+        for k in LEAVES:
+            gs.inputs[k].copy_(datt[k].reshape(gs.inputs[k].shape))
+        gs.gt.copy_(gt.to(dev))
+    gs.run()
+    torch.cuda.synchronize()
+    for k in LEAVES:
+        assert torch.equal(gs.grads[k].reshape(snap[k].shape), snap[k]), k
+    # the opt-in fast path: same numbers, .grad is the static buffer
+    gf = dr.graphed_step(datt, gt.to(dev), no_mask=True, fast_leaf_grads=True)
+    lv3 = {k: datt[k].detach().clone().requires_grad_(True) for k in LEAVES}
+    a3 = dict(datt); a3.update(lv3)
+    gf(gt.to(dev), **a3)[0].backward()
+    for k in LEAVES:
+        assert torch.equal(lv3[k].grad, snap[k].reshape(lv3[k].shape)), k
+        assert lv3[k].grad.data_ptr() == gf.grads[k].data_ptr()
 
 
 def test_graphed_render_replays_the_eager_render_bit_for_bit(pkg):

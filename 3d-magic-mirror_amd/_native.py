@@ -77,7 +77,7 @@ class MMMeshRegGrads(ctypes.Structure):
 class MMPrepareDesc(ctypes.Structure):
     _fields_ = [("B", c_i), ("V", c_i), ("F", c_i), ("proj", c_f * 3), ("faces", c_p), ("vc_offsets", c_p), ("vc_items", c_p),
                 ("vertices", c_p), ("transform", c_p), ("face_vertices_camera", c_p), ("face_vertices_image", c_p), ("face_normals", c_p),
-                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("proj_device", c_p)]
 
 
 class MMPrepareGrads(ctypes.Structure):
@@ -125,7 +125,7 @@ OPT_WALK_QUEUE, OPT_WALK_BATCH = 1 << 10, 1 << 11
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_render_status", "mm_render_fused_loss", "mm_debug_workspace_layout", "mm_recon_query_workspace",
-           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_vertex_corner_table", "mm_nearest_neighbour", "mm_chamfer_nearest", "mm_status_string", "mm_last_error_detail",
+           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_vertex_corner_csr_device", "mm_build_vertex_corner_table", "mm_nearest_neighbour", "mm_chamfer_nearest", "mm_status_string", "mm_last_error_detail",
            "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward", "mm_texture_flow_forward",
            "mm_texture_flow_backward", "mm_attribute_loss_query_workspace", "mm_attribute_loss_forward",
            "mm_attribute_loss_backward",
@@ -203,6 +203,7 @@ def lib():
     L.mm_struct_size.restype = ctypes.c_size_t
     L.mm_struct_size.argtypes = [ctypes.c_int]
     L.mm_build_vertex_corner_csr.argtypes = [c_i, c_i, c_p, c_p, c_p]
+    L.mm_build_vertex_corner_csr_device.argtypes = [c_i, c_i, c_p, c_p, c_p, c_p, c_p]
     L.mm_status_string.restype = ctypes.c_char_p
     L.mm_status_string.argtypes = [ctypes.c_int]
     L.mm_last_error_detail.restype = ctypes.c_char_p

@@ -15,9 +15,18 @@ namespace mm {
 // ---------------------------------------------------------------------------------------------------------------------
 // prepare_vertices
 // ---------------------------------------------------------------------------------------------------------------------
+// camera_proj: the three floats of the descriptor, or of the caller's device tensor (MMPrepareDesc.proj_device)
+__device__ inline void prepare_proj(const MMPrepareDesc& d, float* pj) {
+    if (d.proj_device) { pj[0] = d.proj_device[0]; pj[1] = d.proj_device[1]; pj[2] = d.proj_device[2]; }
+    else { pj[0] = d.proj[0]; pj[1] = d.proj[1]; pj[2] = d.proj[2]; }
+}
+__device__ inline int clamp_vertex(int i, int V) { return min(max(i, 0), V - 1); }      // (ids outside the cloud are reported by the CSR builder, never dereferenced)
+
 __global__ __launch_bounds__(256) void prepare_fwd_kernel(MMPrepareDesc d) {
     const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
     if (f >= d.F) return;
+    float pj[3];
+    prepare_proj(d, pj);
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = d.transform[b * 12 + i];
@@ -26,12 +35,12 @@ __global__ __launch_bounds__(256) void prepare_fwd_kernel(MMPrepareDesc d) {
     Float3 c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        c[k] = to_camera(vb + (size_t)d.faces[f * 3 + k] * 3, T);
-        const float pz = c[k].z * d.proj[2];
+        c[k] = to_camera(vb + (size_t)clamp_vertex(d.faces[f * 3 + k], d.V) * 3, T);
+        const float pz = c[k].z * pj[2];
         float* fc = d.face_vertices_camera + (o * 3 + k) * 3;
         fc[0] = c[k].x; fc[1] = c[k].y; fc[2] = c[k].z;
-        d.face_vertices_image[(o * 3 + k) * 2 + 0] = (c[k].x * d.proj[0]) / pz;
-        d.face_vertices_image[(o * 3 + k) * 2 + 1] = (c[k].y * d.proj[1]) / pz;
+        d.face_vertices_image[(o * 3 + k) * 2 + 0] = (c[k].x * pj[0]) / pz;
+        d.face_vertices_image[(o * 3 + k) * 2 + 1] = (c[k].y * pj[1]) / pz;
     }
     const float e0[3] = {c[1].x - c[0].x, c[1].y - c[0].y, c[1].z - c[0].z};
     const float e1[3] = {c[2].x - c[0].x, c[2].y - c[0].y, c[2].z - c[0].z};
@@ -79,11 +88,13 @@ __global__ __launch_bounds__(256) void prepare_bwd_kernel(MMPrepareDesc d, MMPre
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.f;
     const int v = blockIdx.x * 32 + (tid >> 3), cl = tid & 7;
+    float pj[3];
+    prepare_proj(d, pj);
     if (v < d.V) {
         const float p[3] = {vb[v * 3], vb[v * 3 + 1], vb[v * 3 + 2]};
         const Float3 me = to_camera(p, T);
-        const float pz = me.z * d.proj[2];
-        const float xi = (me.x * d.proj[0]) / pz, yi = (me.y * d.proj[1]) / pz;
+        const float pz = me.z * pj[2];
+        const float xi = (me.x * pj[0]) / pz, yi = (me.y * pj[1]) / pz;
         float dv[3] = {0.f, 0.f, 0.f};
         const int beg = d.vc_offsets[v], end = d.vc_offsets[v + 1];
         for (int it = beg + cl; it < end; it += 8) {
@@ -96,15 +107,16 @@ __global__ __launch_bounds__(256) void prepare_bwd_kernel(MMPrepareDesc d, MMPre
             }
             if (g.grad_face_vertices_image) {
                 const float gx = g.grad_face_vertices_image[(o * 3 + k) * 2], gy = g.grad_face_vertices_image[(o * 3 + k) * 2 + 1];
-                dv[0] += gx * d.proj[0] / pz;
-                dv[1] += gy * d.proj[1] / pz;
-                dv[2] += -(gx * xi + gy * yi) * d.proj[2] / pz;
+                dv[0] += gx * pj[0] / pz;
+                dv[1] += gy * pj[1] / pz;
+                dv[2] += -(gx * xi + gy * yi) * pj[2] / pz;
             }
             if (g.grad_face_normals) {
                 const float gn[3] = {g.grad_face_normals[o * 3], g.grad_face_normals[o * 3 + 1], g.grad_face_normals[o * 3 + 2]};
                 if (gn[0] != 0.f || gn[1] != 0.f || gn[2] != 0.f) {
-                    const Float3 A = to_camera(vb + (size_t)d.faces[f * 3] * 3, T), Bv = to_camera(vb + (size_t)d.faces[f * 3 + 1] * 3, T),
-                                 C = to_camera(vb + (size_t)d.faces[f * 3 + 2] * 3, T);
+                    const Float3 A = to_camera(vb + (size_t)clamp_vertex(d.faces[f * 3], d.V) * 3, T),
+                                 Bv = to_camera(vb + (size_t)clamp_vertex(d.faces[f * 3 + 1], d.V) * 3, T),
+                                 C = to_camera(vb + (size_t)clamp_vertex(d.faces[f * 3 + 2], d.V) * 3, T);
                     float dA[3] = {0.f, 0.f, 0.f}, dB[3] = {0.f, 0.f, 0.f}, dC[3] = {0.f, 0.f, 0.f};
                     normal_backward(A, Bv, C, gn, true, dA, dB, dC);
                     const float* mine = k == 0 ? dA : (k == 1 ? dB : dC);
@@ -135,6 +147,61 @@ __global__ __launch_bounds__(256) void prepare_bwd_kernel(MMPrepareDesc d, MMPre
     }
     __syncthreads();
     if (tid < 12) ((float*)d.workspace)[((size_t)b * gridDim.x + blockIdx.x) * 12 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+}
+
+// The vertex -> corner CSR of a face list, on the device (mm_build_vertex_corner_csr_device): ONE workgroup -- histogram of the corners'
+// vertices in LDS, block scan, scatter through LDS cursors, then every vertex's (short) list is put in ascending order by its own thread,
+// so the lists -- and with them the order of every gather that walks them -- are those of the host builder, run to run.
+#define MM_CSR_MAX_V 12288
+__global__ __launch_bounds__(1024) void csr_build_kernel(int V, int F, const int32_t* __restrict__ faces, int32_t* offsets, int32_t* items, int32_t* status) {
+    __shared__ int s_cnt[MM_CSR_MAX_V];
+    __shared__ int s_wave[16];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, n = 3 * F;
+    for (int v = tid; v < V; v += 1024) s_cnt[v] = 0;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const int v = faces[i];
+        if (v >= 0 && v < V) atomicAdd(&s_cnt[v], 1); else ++bad;
+    }
+    if (bad) atomicAdd(&s_bad, bad);
+    __syncthreads();
+    // exclusive scan: thread t owns vertices [t * per, (t + 1) * per)
+    const int per = (V + 1023) / 1024, v0 = min(V, tid * per), v1 = min(V, v0 + per);
+    int mine = 0;
+    for (int v = v0; v < v1; ++v) mine += s_cnt[v];
+    int wtot;
+    int run = wave_prefix_excl(mine, tid & 63, wtot);
+    if ((tid & 63) == 63) s_wave[tid >> 6] = wtot;
+    __syncthreads();
+    for (int w = 0; w < (tid >> 6); ++w) run += s_wave[w];
+    for (int v = v0; v < v1; ++v) { const int c = s_cnt[v]; offsets[v] = run; s_cnt[v] = run; run += c; }   // s_cnt becomes the cursor
+    if (tid == 1023) offsets[V] = run;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int v = faces[i];
+        if (v >= 0 && v < V) __hip_atomic_store(items + atomicAdd(&s_cnt[v], 1), i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    // ascending order inside every list (insertion sort of ~6 entries; agent-scope accesses: the scatter above went around this CU's L1).
+    // The lists are contiguous: vertex v's is [cursor[v-1], cursor[v]) now that every cursor stands at its list's end.
+    for (int v = tid; v < V; v += 1024) {
+        const int beg = v ? s_cnt[v - 1] : 0, end = s_cnt[v];
+        for (int i = beg + 1; i < end; ++i) {
+            const int key = __hip_atomic_load(items + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int j = i - 1;
+            for (; j >= beg; --j) {
+                const int q = __hip_atomic_load(items + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q <= key) break;
+                __hip_atomic_store(items + j + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(items + j + 1, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0 && status && s_bad) __hip_atomic_fetch_add(status, s_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(64) void prepare_final_kernel(const float* partial, int groups, float* grad_transform) {
@@ -378,6 +445,16 @@ int mm_prepare_vertices_backward(const MMPrepareDesc* d, const MMPrepareGrads* g
     if (g->grad_transform)
         hipLaunchKernelGGL(mm::prepare_final_kernel, dim3(d->B), dim3(64), 0, (hipStream_t)stream, (const float*)d->workspace, groups, g->grad_transform);
     return mm::launch_ok("prepare_vertices_final");
+}
+
+int mm_build_vertex_corner_csr_device(int32_t V, int32_t F, const int32_t* faces_dev, int32_t* offsets_dev, int32_t* items_dev,
+                                      int32_t* status_flag, mm_stream_t stream) {
+    if (!faces_dev || !offsets_dev || !items_dev) return MM_ERR_NULL_POINTER;
+    if (V <= 0 || F <= 0) return MM_ERR_BAD_SHAPE;
+    if (V > MM_CSR_MAX_V) return MM_ERR_UNSUPPORTED;
+    mm::clear_stale_error();
+    hipLaunchKernelGGL(mm::csr_build_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, V, F, faces_dev, offsets_dev, items_dev, status_flag);
+    return mm::launch_ok("vertex_corner_csr");
 }
 
 int mm_face_normals_forward(int64_t n, int32_t unit, const float* fv, float* normals, mm_stream_t stream) {

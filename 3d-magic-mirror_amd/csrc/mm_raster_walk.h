@@ -394,7 +394,13 @@ __device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, Wa
             const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
             cnt += __popcll(sm);
             if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);   // knum-th face taken
+#ifdef MM_BATCH_SOFT_SCALAR
             if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, st, s2, l, j, live); });
+#else
+            // two pairs per lane in packed fp32 (soft_pairs: the factors are bit-identical to soft_pair's, the integer sums commute): the
+            // silhouette pairs are what the heaviest single-wave tiles of a 128x128 batch spend their time on (8-14 us of 30)
+            if (__ballot(sm != 0)) soft_pairs(a, t, st, sm, s2);
+#endif
             MM_PP_MARK(4);
             wave_lds_sync();
         }

@@ -33,45 +33,46 @@ def _f32(t, dev):
     return N.as_f32(t, dev)
 
 
-_CSR_CACHE = {}
-_PROJ_CACHE = {}
+_STATUS = None            # one pinned int32 the device adds vertex ids outside the cloud to (mm_build_vertex_corner_csr_device); polled, never waited for
+_CSR_MAX_V = 12288        # MM_CSR_MAX_V (csrc/mm_ops.hip)
 
 
-def _faces_tables(faces, dev):
-    """int32 device copy of ``faces`` and its vertex->corner CSR (needed by the gather-formulated backward).
-    Cached by CONTENT: the reference re-creates the tensor on every render (``faces = self.faces.to(device)``, networks.py:272), so a key
-    of address / object identity never hits and every call would pay a device->host copy, the CSR rebuild and three uploads.  Entries
-    are looked up by (shape, dtype, device) and validated with ``torch.equal`` against the tensor they were made from -- on the tensor's own
-    device, no copy of the faces to the host; a template with other contents gets an entry of its own (a stale entry can never be used:
-    seen once as a wrong-topology render between two 1280-face templates when the key was the address)."""
-    key = (tuple(faces.shape), faces.dtype, str(faces.device), str(dev))
-    bucket = _CSR_CACHE.setdefault(key, [])
-    for hit in bucket:
-        if hit[4] is faces or torch.equal(hit[4], faces):
-            return hit
-    fh = faces.detach().to("cpu", torch.int64)
-    V = int(fh.max()) + 1 if fh.numel() else 0
-    off, items = template.vertex_corner_adjacency(V, fh)
-    hit = (faces.detach().to(device=dev, dtype=torch.int32).contiguous(), off.to(device=dev, dtype=torch.int32).contiguous(),
-           items.to(device=dev, dtype=torch.int32).contiguous(), V, faces.detach().clone())
-    if len(bucket) >= 4:
-        del bucket[0]
-    bucket.append(hit)
-    return hit
+def _status_word():
+    global _STATUS
+    if _STATUS is None:
+        _STATUS = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return _STATUS
 
 
-def _proj_tuple(camera_proj):
-    """camera_proj (3,1) as three Python floats; remembered per tensor (address + version + an on-device equality check against the copy the
-    floats were read from), so the device->host read happens once per projection, not once per render."""
-    key = (camera_proj.data_ptr(), camera_proj._version, str(camera_proj.device), tuple(camera_proj.shape))
-    hit = _PROJ_CACHE.get(key)
-    if hit is not None and (hit[1] is camera_proj or torch.equal(hit[1], camera_proj)):
-        return hit[0]
-    proj = tuple(float(x) for x in camera_proj.detach().reshape(-1).cpu().tolist())
-    if len(_PROJ_CACHE) > 16:
-        _PROJ_CACHE.clear()
-    _PROJ_CACHE[key] = (proj, camera_proj.detach().clone())
-    return proj
+def _raise_on_reported_faces():
+    """An EARLIER prepare_vertices saw vertex ids outside its cloud (reported by the device without a synchronisation; the ids were left out of
+    the gradient gather and clamped in the forward, never dereferenced)."""
+    if _STATUS is not None and int(_STATUS[0]) != 0:
+        n = int(_STATUS[0])
+        _STATUS[0] = 0
+        raise RuntimeError("prepare_vertices: an earlier call's faces held %d vertex ids outside [0, V)" % n)
+
+
+def _faces_tables(faces, V, dev):
+    """int32 device copy of ``faces`` and its vertex->corner CSR (needed by the gather-formulated backward), built ON THE DEVICE by one small
+    launch, every call.  The reference re-creates the tensor on every render (``faces = self.faces.to(device)``, networks.py:272): a cache
+    keyed by address goes stale between two templates of one shape (seen once as a wrong-topology render), and validating an entry against
+    the tensor's CONTENTS is a device -> host read, i.e. a synchronisation of the whole stream in the middle of every render (it made this
+    path host-bound at 2.2 ms per step).  No cache, no read-back: nothing to go stale, nothing to wait for."""
+    fi = faces.detach().to(device=dev, dtype=torch.int32).contiguous()
+    F = fi.shape[0]
+    off = torch.empty(V + 1, device=dev, dtype=torch.int32)
+    items = torch.empty(3 * F, device=dev, dtype=torch.int32)
+    if V <= _CSR_MAX_V:
+        N.check(N.lib().mm_build_vertex_corner_csr_device(V, F, N.ptr(fi), N.ptr(off), N.ptr(items), _status_word().data_ptr(), N.current_stream(dev)),
+                "mm_build_vertex_corner_csr_device")
+    else:                                                        # (huge clouds: the host builder, with its read-back)
+        fh = faces.detach().to("cpu", torch.int64)
+        if fh.numel() and (int(fh.max()) >= V or int(fh.min()) < 0):
+            raise RuntimeError("faces index vertex %d but vertices has %d" % (int(fh.max()), V))
+        o, it = template.vertex_corner_adjacency(V, fh)
+        off.copy_(o.to(torch.int32)); items.copy_(it.to(torch.int32))
+    return fi, off, items
 
 
 # ---- kaolin.render.mesh.prepare_vertices -------------------------------------------------------------------------------
@@ -87,27 +88,24 @@ class _PrepareFn(torch.autograd.Function):
         fn = torch.empty((B, F, 3), device=dev, dtype=torch.float32)
         d = N.MMPrepareDesc()
         d.B, d.V, d.F = B, V, F
-        for i in range(3):
-            d.proj[i] = proj[i]
+        d.proj_device = N.ptr(proj)
         d.faces, d.vc_offsets, d.vc_items = N.ptr(faces_i32), N.ptr(vc_off), N.ptr(vc_items)
         d.vertices, d.transform = N.ptr(vertices), N.ptr(transform)
         d.face_vertices_camera, d.face_vertices_image, d.face_normals = N.ptr(fvc), N.ptr(fvi), N.ptr(fn)
         N.check(N.lib().mm_prepare_vertices_forward(ctypes.byref(d), N.current_stream(dev)), "mm_prepare_vertices_forward")
-        ctx.save_for_backward(vertices, transform, faces_i32, vc_off, vc_items)
-        ctx.proj = proj
+        ctx.save_for_backward(vertices, transform, faces_i32, vc_off, vc_items, proj)
         return fvc, fvi, fn
 
     @staticmethod
     def backward(ctx, g_fvc, g_fvi, g_fn):
-        vertices, transform, faces_i32, vc_off, vc_items = ctx.saved_tensors
+        vertices, transform, faces_i32, vc_off, vc_items, proj = ctx.saved_tensors
         dev = vertices.device
         B, V, _ = vertices.shape
         c = lambda g: None if g is None else g.to(torch.float32).contiguous()
         g_fvc, g_fvi, g_fn = c(g_fvc), c(g_fvi), c(g_fn)
         d = N.MMPrepareDesc()
         d.B, d.V, d.F = B, V, faces_i32.shape[0]
-        for i in range(3):
-            d.proj[i] = ctx.proj[i]
+        d.proj_device = N.ptr(proj)
         d.faces, d.vc_offsets, d.vc_items = N.ptr(faces_i32), N.ptr(vc_off), N.ptr(vc_items)
         d.vertices, d.transform = N.ptr(vertices), N.ptr(transform)
         gv = torch.empty_like(vertices)
@@ -133,13 +131,12 @@ def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans
         camera_transform = torch.cat([rt, -(camera_trans.to(dev).reshape(-1, 1, 3) @ rt)], dim=1)
     if camera_transform.dim() != 3 or camera_transform.shape[1:] != (4, 3) or camera_transform.shape[0] != vertices.shape[0]:
         raise RuntimeError("camera_transform must be (B,4,3), got %s" % (tuple(camera_transform.shape),))
-    faces_i32, off, items, Vf, _ = _faces_tables(faces, dev)
-    if Vf > vertices.shape[1]:
-        raise RuntimeError("faces index vertex %d but vertices has %d" % (Vf - 1, vertices.shape[1]))
-    if Vf < vertices.shape[1]:                                   # trailing vertices no face uses: pad the CSR
-        off = torch.cat([off, off[-1:].expand(vertices.shape[1] - Vf)])
-    proj = _proj_tuple(camera_proj)
-    if len(proj) != 3:
+    if faces.dim() != 2 or faces.shape[1] != 3:
+        raise RuntimeError("faces must be (F,3), got %s" % (tuple(faces.shape),))
+    _raise_on_reported_faces()
+    faces_i32, off, items = _faces_tables(faces, int(vertices.shape[1]), dev)
+    proj = camera_proj.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()       # stays on the device: read by the kernels
+    if proj.numel() != 3:
         raise RuntimeError("camera_proj must have 3 entries")
     return _PrepareFn.apply(vertices, camera_transform.to(dev), faces_i32, off, items, proj)
 

@@ -182,17 +182,20 @@ class RenderLossStep:
 
 def _graphed_input_grads(owner, leaf_inputs, shapes, g):
     """What a graphed node hands back for its eight attribute inputs after the backward graph has run (g: the static gradient buffers).
-    Default: every input gets its gradient THROUGH THE ENGINE, as a view of the static buffer in the input's own shape -- AccumulateGrad then
-    clones it for a leaf (a tensor it does not own), hooks fire, torch.autograd.grad works, and nothing the caller holds aliases memory the
-    next replay overwrites.  ``owner.fast_leaf_grads`` (opt-in): a LEAF input's ``.grad`` is assigned the static buffer itself (or accumulated
+    Default: every input gets its gradient THROUGH THE ENGINE in the input's own shape -- a private copy for a leaf, a view of the static
+    buffer for a non-leaf (whose producer consumes it within this backward pass) -- so hooks fire, torch.autograd.grad works, and nothing the
+    caller holds aliases memory the next replay overwrites.  ``owner.fast_leaf_grads`` (opt-in): a LEAF input's ``.grad`` is assigned the static buffer itself (or accumulated
     into) and the engine gets None -- eight copy launches fewer per step, for loops that only ever call ``loss.backward()`` and reset
     ``.grad`` to None between steps; hooks do not fire and ``torch.autograd.grad`` sees no gradient on that path."""
     out = []
     for k, leaf, shp in zip(LEAVES, leaf_inputs, shapes):
         if g[k] is None or shp is None:
             out.append(None)
-        elif leaf is None or not owner.fast_leaf_grads:
-            out.append(g[k].reshape(shp))
+        elif leaf is None:
+            out.append(g[k].reshape(shp))                        # a non-leaf input: consumed by the producer's backward inside this pass
+        elif not owner.fast_leaf_grads:
+            out.append(g[k].reshape(shp).clone())                # (a view would be STOLEN by AccumulateGrad -- its tensor object has one owner -- and
+                                                                 #  .grad would alias the static buffer after all: the copy is what keeps the caller's)
         else:
             gk = g[k].reshape(shp)
             if leaf.grad is None:

@@ -133,15 +133,18 @@ def default_opt():
 
 
 class TrainerStep:
-    def __init__(self, template, image_size, batch, device, ratio=1, opt=None, seed=0, graphed=False, lean=False):
+    def __init__(self, template, image_size, batch, device, ratio=1, opt=None, seed=0, graphed=False, lean=False, many=False):
         """graphed: the four renders go through DiffRender.graphed_render (one captured forward / backward graph pair per render of the iteration:
         their outputs are static memory) instead of the eager autograd nodes -- same bits, less host time.
-        lean: the three renders whose attributes exist up front (trainer.py:276,345,347) as ONE DiffRender.render_many call of 3B images, and the
-        fourth (trainer.py:367, whose image is discarded) as DiffRender.render_geometry -- same losses, same gradients."""
+        lean: the fourth render (trainer.py:367, whose image is discarded) as DiffRender.render_geometry -- same losses, same gradients.
+        many (with lean): the three renders whose attributes exist up front (trainer.py:276,345,347) as ONE DiffRender.render_many call of 3B
+        images.  Pays where a batch of 48 does not fill the chip (128x128); at 256x256 one pass over 144 images takes as long as three over 48
+        and the concatenations cost more than the launches saved (profiles/r04_render_path.md)."""
         self.opt = opt or default_opt()
         self.dev, self.B = device, batch
         self.graphed, self._gr = bool(graphed), {}
-        self.lean = bool(lean) and not graphed
+        self.lean = bool(lean) and not graphed                   # render #4 geometry-only
+        self.many = bool(many) and self.lean                     # renders #1-#3 as one render_many call
         self.dr = DiffRender(template, image_size, ratio=ratio)
         torch.manual_seed(seed)
         self.netE = AttributeNet(self.dr.vertices_init, bg=self.opt.bg).to(device)
@@ -176,7 +179,7 @@ class TrainerStep:
         o, dr, Bn = self.opt, self.dr, self.B
         self.optimizerE.zero_grad(set_to_none=True)
         Ae = self.netE(self.Xa)
-        if not self.lean:
+        if not self.many:
             Xer, Ae = self._render(0, Ae)                                                  # render #1
         Ae90 = deep_copy(Ae)
         sign = torch.where(self._u(Bn) < 0.5, -1.0, 1.0)
@@ -193,9 +196,9 @@ class TrainerStep:
               "textures": a_t * Aa["textures"] + (1 - a_t) * Ab["textures"],
               "bg": (a_t * Aa["bg"] + (1 - a_t) * Ab["bg"]) if o.bg else None,
               "lights": a_l * Aa["lights"] + (1 - a_l) * Ab["lights"]}
-        if self.lean and o.hard:                                                           # renders #1-#3 in one pass over 3B images
+        if self.many and o.hard:                                                           # renders #1-#3 in one pass over 3B images
             (Xer, Ae), (Xir, Ai), (Xer90, Ae90) = dr.render_many([Ae, Ai, Ae90], no_mask=o.bg)
-        elif self.lean:
+        elif self.many:
             (Xer, Ae), (Xir, Ai) = dr.render_many([Ae, Ai], no_mask=o.bg)
             Xer90, Ae90 = Xer, Ae
         else:
@@ -234,13 +237,15 @@ class TrainerStep:
                     if torch.is_tensor(v):
                         v.grad = None
             Ae, Ai, A9, Ar = (dict(A) for A in sets)
-            if self.lean:
+            if self.many:
                 (Xer, Ae), (Xir, Ai), (Xer90, A9) = dr.render_many([Ae, Ai, A9], no_mask=o.bg)
-                Ar = dr.render_geometry(**Ar)
             else:
                 Xer, Ae = self._render(0, Ae)
                 Xir, Ai = self._render(1, Ai)
                 Xer90, A9 = self._render(2, A9)
+            if self.lean:
+                Ar = dr.render_geometry(**Ar)
+            else:
                 _, Ar = self._render(3, Ar)
             l = dr.recon_data(Xer, self.Xa, no_mask=o.bg) + 1e-4 * (Xer90[:, :3].mean() + Xir[:, :3].mean())
             r1, r2, r3 = dr.regularization(Ae, Ai, Ar, o)
@@ -299,6 +304,6 @@ def bench(device, steps=8, warmup=3, template=None, image_size=256, batch=48):
             "graphed_renders": {"images_per_s": round(batch / t_step_g, 1), "ms_per_step": round(t_step_g * 1e3, 3), "render_path_ms": round(t_rp_g * 1e3, 3),
                                 "loss": float(tg.last["loss"])},
             "lean": {"images_per_s": round(batch / t_step_l, 1), "ms_per_step": round(t_step_l * 1e3, 3), "render_path_ms": round(t_rp_l * 1e3, 3),
-                     "loss": float(tl.last["loss"]), "what": "renders #1-#3 as one DiffRender.render_many call (3B images), #4 as render_geometry"},
+                     "loss": float(tl.last["loss"]), "what": "render #4 (image discarded, trainer.py:367) as DiffRender.render_geometry"},
             "steps": steps, "loss": loss,
             "encoder_params": nparam}

@@ -333,6 +333,8 @@ typedef struct MMPrepareDesc {
     float* face_normals;            /* (B,F,3)   */
     void* workspace;                /* backward only: >= mm_prepare_vertices_query_workspace bytes (per-workgroup dT partials) */
     size_t workspace_bytes;
+    const float* proj_device;       /* optional: camera_proj as 3 floats in DEVICE memory, read instead of proj[] -- a caller whose projection
+                                     * is a device tensor (kaolin's prepare_vertices takes one) needs no device -> host read */
 } MMPrepareDesc;
 
 typedef struct MMPrepareGrads {
@@ -434,6 +436,12 @@ int mm_mask_iou_backward(const MMMaskIouDesc* desc, const float* grad_loss, floa
  * ------------------------------------------------------------------------------------------------------------------ */
 /* Build the vertex -> corner CSR from HOST faces (F,3).  offsets: (V+1), items: (3F).  Returns MM_OK or an error. */
 int mm_build_vertex_corner_csr(int32_t V, int32_t F, const int32_t* faces_host, int32_t* offsets_host, int32_t* items_host);
+/* The same CSR built ON THE DEVICE from device-resident faces, enqueued on the stream (one small launch, no host round trip): what the
+ * kaolin-shaped prepare_vertices needs when `faces` arrives as a fresh device tensor on every call (networks.py:272 re-uploads it).
+ * offsets_dev (V+1), items_dev (3F), every vertex's list ascending like the host builder's.  Vertex ids outside [0, V) are counted into
+ * *status_flag (optional; device or pinned host memory, added to) and left out of the lists.  V <= 12288. */
+int mm_build_vertex_corner_csr_device(int32_t V, int32_t F, const int32_t* faces_dev, int32_t* offsets_dev, int32_t* items_dev,
+                                      int32_t* status_flag, mm_stream_t stream);
 /* The same adjacency with a fixed stride, as MMRenderDesc.vc_table wants it (one trip to memory for a vertex's corners AND their faces'
  * vertex ids, where the CSR needs three).  Returns the stride (the template's largest valence) if table_host is NULL; otherwise fills
  * table_host (V, stride, 4) for the given stride (>= that valence) and returns MM_OK, or an MMStatus error. */
@@ -448,7 +456,7 @@ const char* mm_last_error_detail(void);
 size_t mm_struct_size(int which);
 /* Bumped whenever a struct or the meaning of a field changes (2: op boundary added, reserved uv-tile fields and profiling slot
  * MM_PROF_BIN removed, options bits defined; 3: MMRenderDesc takes the fixed-stride vertex -> corner table instead of the CSR,
- * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, mm_chamfer_nearest).  Bindings must refuse a library whose
+ * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, mm_chamfer_nearest, mm_build_vertex_corner_csr_device).  Bindings must refuse a library whose
  * version differs from what they mirror. */
 #define MM_ABI_VERSION 4
 int mm_abi_version(void);

@@ -288,3 +288,41 @@ def test_operators_composed_like_the_reference_match_the_fused_render(pkg, kal, 
                                             T.grad.cpu().numpy())
     for k, ref in (("distances", dd), ("elevations", de), ("azimuths", da), ("biases", db)):
         _close(A2[k].grad, ref, 2e-4)
+
+
+@pytest.mark.parametrize("name", ["sphere", "smpl_uv"])
+def test_device_built_vertex_corner_csr_is_the_host_builders(kal, name):
+    """prepare_vertices builds its vertex -> corner CSR on the device, every call, without reading anything back (the reference hands it a
+    fresh `faces` tensor per render): offsets and items are those of the host builder, list order included, and the build is repeatable."""
+    import importlib
+    ops = importlib.import_module("3d-magic-mirror_amd.ops")
+    tmpl = importlib.import_module("3d-magic-mirror_amd.template")
+    z = np.load(os.path.join(TEMPLATES, name + ".npz"))
+    faces = torch.from_numpy(z["faces"].astype(np.int64))
+    V = int(z["vertices"].shape[0])
+    off_h, items_h = tmpl.vertex_corner_adjacency(V, faces)
+    for _ in range(3):
+        fi, off, items = ops._faces_tables(faces.cuda(), V, torch.device("cuda:0"))
+        assert torch.equal(off.cpu().long(), off_h.long()) and torch.equal(items.cpu().long(), items_h.long())
+        assert torch.equal(fi.cpu().long(), faces)
+
+
+def test_vertex_ids_outside_the_cloud_are_reported_not_dereferenced(kal):
+    """A face list that indexes a vertex the cloud does not have: nothing is read out of bounds, the device reports it through a pinned
+    status word, and the NEXT prepare_vertices raises -- no synchronisation on the hot path."""
+    import importlib
+    ops = importlib.import_module("3d-magic-mirror_amd.ops")
+    z = np.load(os.path.join(TEMPLATES, "sphere.npz"))
+    faces = torch.from_numpy(z["faces"].astype(np.int64)).cuda()
+    V = int(z["vertices"].shape[0])
+    verts = torch.from_numpy(z["vertices"].astype(np.float32)).cuda()[None].repeat(2, 1, 1)
+    T = torch.eye(4, 3, device="cuda:0")[None].repeat(2, 1, 1).contiguous()
+    T[:, 3, 2] = -3.0
+    proj = torch.tensor([[2.5], [2.5], [-1.0]], device="cuda:0")
+    bad = faces.clone(); bad[5, 1] = V + 7
+    fvc, fvi, fn = kal.render.mesh.prepare_vertices(verts, bad, proj, camera_transform=T)
+    torch.cuda.synchronize()
+    assert torch.isfinite(fvc).all()
+    with pytest.raises(RuntimeError, match="outside"):
+        kal.render.mesh.prepare_vertices(verts, faces, proj, camera_transform=T)
+    kal.render.mesh.prepare_vertices(verts, faces, proj, camera_transform=T)       # reported once

@@ -101,7 +101,7 @@ class MMTexMapDesc(ctypes.Structure):
 
 
 class MMTexMapGrads(ctypes.Structure):
-    _fields_ = [("grad_out", c_p), ("grad_uv", c_p), ("grad_textures", c_p)]
+    _fields_ = [("grad_out", c_p), ("grad_uv", c_p), ("grad_textures", c_p), ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t)]
 
 
 class MMShDesc(ctypes.Structure):
@@ -131,7 +131,7 @@ EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_
            "mm_attribute_loss_backward",
            "mm_prepare_vertices_query_workspace", "mm_prepare_vertices_forward", "mm_prepare_vertices_backward",
            "mm_face_normals_forward", "mm_face_normals_backward", "mm_dibr_query_workspace", "mm_dibr_rasterization_forward",
-           "mm_dibr_rasterization_backward", "mm_texture_mapping_forward", "mm_texture_mapping_backward", "mm_sh_lighting_forward",
+           "mm_dibr_rasterization_backward", "mm_texture_mapping_forward", "mm_texture_mapping_backward", "mm_texture_mapping_backward_query_workspace", "mm_sh_lighting_forward",
            "mm_sh_lighting_backward", "mm_mask_iou_forward", "mm_mask_iou_backward", "mm_struct_size",
            "mm_abi_version")
 
@@ -196,6 +196,8 @@ def lib():
     L.mm_dibr_rasterization_backward.argtypes = [P(MMDibrDesc), P(MMDibrGrads), c_p]
     L.mm_texture_mapping_forward.argtypes = [P(MMTexMapDesc), c_p]
     L.mm_texture_mapping_backward.argtypes = [P(MMTexMapDesc), P(MMTexMapGrads), c_p]
+    L.mm_texture_mapping_backward_query_workspace.argtypes = [P(MMTexMapDesc)]
+    L.mm_texture_mapping_backward_query_workspace.restype = ctypes.c_size_t
     L.mm_sh_lighting_forward.argtypes = [P(MMShDesc), c_p]
     L.mm_sh_lighting_backward.argtypes = [P(MMShDesc), P(MMShGrads), c_p]
     L.mm_mask_iou_forward.argtypes = [P(MMMaskIouDesc), c_p]

@@ -82,7 +82,8 @@ struct Workspace {
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
-    int* nheavy;           // (B,2)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty
+    int* nheavy;           // (B,4)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty;
+                           //            how many behind the cooperative ones are split by pixel rows over several waves
     int* bincount;         // (B,nbins)  candidates per screen bin (big screens / meshes only: bincount_kernel -> order_kernel)
     int* fflag;            // (B,F,2)    [0] = 1: the face won a pixel; [1] = 1: an uncovered pixel took it into its silhouette product.  Only such faces
                            //            receive gradient from the pixels, and only they are swept by the backward -- a face that only OWNS pixels over its
@@ -151,7 +152,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
     w.ltot = (long long*)(p + o);   o += align256((size_t)B * MM_LSUB * 4 * sizeof(long long));
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
-    w.nheavy = (int*)(p + o);       o += align256((size_t)B * 2 * sizeof(int));
+    w.nheavy = (int*)(p + o);       o += align256((size_t)B * 4 * sizeof(int));
     w.bincount = (int*)(p + o);     o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
     w.fflag = (int*)(p + o);        o += align256((size_t)B * F * 2 * sizeof(int));   // (ints, not bytes: a byte store may alias every later load in the compiler's eyes)
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);

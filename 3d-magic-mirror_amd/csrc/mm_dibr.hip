@@ -35,7 +35,7 @@ static DibrWorkspace carve_dibr(void* base, int B, int F, int H, int W) {
     w.geo = (float4*)(p + o);            o += align256((size_t)B * F * 3 * sizeof(float4));
     w.binmask = (uint64_t*)(p + o);      o += align256((size_t)B * w.nbx * w.nby * w.words * sizeof(uint64_t));
     w.order = (unsigned short*)(p + o);  o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
-    w.nheavy = (int*)(p + o);            o += align256((size_t)B * 2 * sizeof(int));
+    w.nheavy = (int*)(p + o);            o += align256((size_t)B * 4 * sizeof(int));
     w.bincount = (int*)(p + o);          o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
     w.soft = (float2*)(p + o);           o += align256((size_t)B * H * W * sizeof(float2));
     w.fidx = (int32_t*)(p + o);          o += align256((size_t)B * H * W * sizeof(int32_t));
@@ -132,17 +132,28 @@ __device__ inline float seg_nearest_t(float px, float py, float ux, float uy, fl
     return t;
 }
 
+// The sweep: MM_DB_FL lanes per face walk the face's inflated pixel box; lane sl takes box pixels sl, sl + 16, ... -- a FIXED assignment.
+// kRegs (up to MM_DB_REG_D feature channels: the reference has 6): every lane adds its own pixels' contributions up in registers, in its own
+// fixed order, and the sixteen partial sums of a face are added by a fixed butterfly: no atomics at all, the gradients are bitwise
+// reproducible, and the LDS float atomics this kernel used to issue (~81 ns of the CU's LDS unit per wave-instruction, whatever the
+// addresses: profiles/r02_lds_atomic_calibration.txt) are gone.  More channels than that: per-face LDS accumulators with float atomics
+// (order-dependent in the last bits), as before.
+#define MM_DB_REG_D 8
+template <bool kRegs>
 __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
-    __shared__ float s_acc[4][MM_DB_FPW][MM_DB_ACC];
+    __shared__ float s_acc[kRegs ? 1 : 4][kRegs ? 1 : MM_DB_FPW][kRegs ? 1 : MM_DB_ACC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / MM_DB_FL, sl = lane % MM_DB_FL;
     const long long wid = (long long)blockIdx.x * 4 + wave;      // (face quartet, image): the waves of a workgroup sweep one image's neighbours
     const int b = (int)(wid % a.B);
     const int f_raw = (int)(wid / a.B) * MM_DB_FPW + grp;
     const bool live = f_raw < a.F;
     const int f = live ? f_raw : 0;
-    float* acc = s_acc[wave][grp];
+    float* acc = kRegs ? nullptr : s_acc[wave][grp];
+    float racc[kRegs ? 6 + 3 * MM_DB_REG_D : 1];
+#pragma unroll
+    for (int k = 0; k < (kRegs ? 6 + 3 * MM_DB_REG_D : 1); ++k) racc[k] = 0.f;
     const int nacc = 6 + 3 * a.D;
-    for (int k = sl; k < nacc; k += MM_DB_FL) acc[k] = 0.f;
+    if (!kRegs) for (int k = sl; k < nacc; k += MM_DB_FL) acc[k] = 0.f;
     const size_t o = (size_t)b * a.F + f, hw = (size_t)a.H * a.W;
     const float4 p0 = a.geo[o * 3 + 0], p1 = a.geo[o * 3 + 1], g2 = a.geo[o * 3 + 2];
     const unsigned org = __float_as_uint(g2.z), ext = __float_as_uint(g2.w);
@@ -156,6 +167,7 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
     static_assert(MM_DB_FL == 16, "the exchange strides below start at the lanes-per-face count");
     nmax = max(nmax, (int)lane_xchg<16>((unsigned)nmax, threadIdx.x & 63)); nmax = max(nmax, (int)lane_xchg<32>((unsigned)nmax, threadIdx.x & 63));
     wave_lds_sync();
+    auto add = [&](int k, float v) { if (kRegs) racc[k] += v; else atomicAdd(&acc[k], v); };   // (k is a compile-time constant at every call with kRegs)
     for (int base = 0; base < nmax; base += MM_DB_FL) {
         const int idx = base + sl;
         if (idx >= npx) continue;
@@ -171,19 +183,30 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
             const float* g = a.g_interp + pix * a.D;
             const float* ff = a.feats + o * 3 * a.D;
             float G0 = 0.f, G1 = 0.f, G2 = 0.f;
-            for (int d = 0; d < a.D; ++d) {
-                const float gd = g[d];
-                G0 += gd * ff[d]; G1 += gd * ff[a.D + d]; G2 += gd * ff[2 * a.D + d];
-                if (a.dfeat && gd != 0.f) {
-                    atomicAdd(&acc[6 + d], w0 * gd); atomicAdd(&acc[6 + a.D + d], w1 * gd); atomicAdd(&acc[6 + 2 * a.D + d], w2 * gd);
+            if (kRegs) {
+#pragma unroll
+                for (int d = 0; d < MM_DB_REG_D; ++d) {
+                    if (d < a.D) {
+                        const float gd = g[d];
+                        G0 += gd * ff[d]; G1 += gd * ff[a.D + d]; G2 += gd * ff[2 * a.D + d];
+                        if (a.dfeat) { racc[6 + d] += w0 * gd; racc[6 + MM_DB_REG_D + d] += w1 * gd; racc[6 + 2 * MM_DB_REG_D + d] += w2 * gd; }
+                    }
+                }
+            } else {
+                for (int d = 0; d < a.D; ++d) {
+                    const float gd = g[d];
+                    G0 += gd * ff[d]; G1 += gd * ff[a.D + d]; G2 += gd * ff[2 * a.D + d];
+                    if (a.dfeat && gd != 0.f) {
+                        atomicAdd(&acc[6 + d], w0 * gd); atomicAdd(&acc[6 + a.D + d], w1 * gd); atomicAdd(&acc[6 + 2 * a.D + d], w2 * gd);
+                    }
                 }
             }
             const float Gm = (w0 * G0 + w1 * G1) + w2 * G2;
             const float dw0 = (G0 - Gm) / nrm, dw1 = (G1 - Gm) / nrm, dw2 = (G2 - Gm) / nrm;
             const float aex = p0.x - x0, aey = p0.y - y0, bex = p0.z - x0, bey = p0.w - y0, cex = p1.x - x0, cey = p1.y - y0;
-            atomicAdd(&acc[0], (dw1 * (-cey) + dw2 * bey) * a.mult); atomicAdd(&acc[1], (dw1 * cex + dw2 * (-bex)) * a.mult);
-            atomicAdd(&acc[2], (dw0 * cey + dw2 * (-aey)) * a.mult); atomicAdd(&acc[3], (dw0 * (-cex) + dw2 * aex) * a.mult);
-            atomicAdd(&acc[4], (dw0 * (-bey) + dw1 * aey) * a.mult); atomicAdd(&acc[5], (dw0 * bex + dw1 * (-aex)) * a.mult);
+            add(0, (dw1 * (-cey) + dw2 * bey) * a.mult); add(1, (dw1 * cex + dw2 * (-bex)) * a.mult);
+            add(2, (dw0 * cey + dw2 * (-aey)) * a.mult); add(3, (dw0 * (-cex) + dw2 * aex) * a.mult);
+            add(4, (dw0 * (-bey) + dw1 * aey) * a.mult); add(5, (dw0 * bex + dw1 * (-aex)) * a.mult);
         } else if (fi == -1 && a.g_soft) {
             // K4 (Appendix A.2): this face is among the pixel's first knum soft-mask faces iff its inflated box holds the pixel
             // and its index does not exceed the knum-th face the forward took
@@ -208,13 +231,43 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
                 const float excl = (q != 0.f) ? (onezero ? 0.f : qnz / q) : (onezero ? qnz : 0.f);
                 const float gd = ga * excl * (-(p * a.sigmainv) / s2) * a.mult;
                 if (gd != 0.f) {
-                    const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;
+                    // edge e runs from corner e to corner (e + 1) % 3
                     const float cu = -2.f * (1.f - t) * gd, cv = -2.f * t * gd;
-                    atomicAdd(&acc[iu], cu * qx); atomicAdd(&acc[iu + 1], cu * qy);
-                    atomicAdd(&acc[iv], cv * qx); atomicAdd(&acc[iv + 1], cv * qy);
+                    if (kRegs) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {             // (corner c receives cu if it starts the edge, cv if it ends it: selects, no indexed registers)
+                            const float wgt = (c == e ? cu : 0.f) + (c == (e == 2 ? 0 : e + 1) ? cv : 0.f);
+                            racc[2 * c] += wgt * qx; racc[2 * c + 1] += wgt * qy;
+                        }
+                    } else {
+                        const int iu = e * 2, iv = (e == 2 ? 0 : e + 1) * 2;
+                        atomicAdd(&acc[iu], cu * qx); atomicAdd(&acc[iu + 1], cu * qy);
+                        atomicAdd(&acc[iv], cv * qx); atomicAdd(&acc[iv + 1], cv * qy);
+                    }
                 }
             }
         }
+    }
+    if (kRegs) {
+        // the face's sixteen lanes: a fixed butterfly (every lane ends with the total)
+#pragma unroll
+        for (int k = 0; k < 6 + 3 * MM_DB_REG_D; ++k) {
+            float v = racc[k];
+            v += xchg_f32<8>(v, lane); v += xchg_f32<4>(v, lane); v += xchg_f32<2>(v, lane); v += xchg_f32<1>(v, lane);
+            racc[k] = v;
+        }
+        if (live && sl == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) a.dfvi[o * 6 + k] = racc[k];
+            if (a.dfeat) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int d = 0; d < MM_DB_REG_D; ++d)
+                        if (d < a.D) a.dfeat[o * 3 * a.D + c * a.D + d] = racc[6 + c * MM_DB_REG_D + d];
+            }
+        }
+        return;
     }
     wave_lds_sync();
     if (live) {
@@ -291,7 +344,8 @@ int mm_dibr_rasterization_backward(const MMDibrDesc* d, const MMDibrGrads* g, mm
     a.dfvi = g->grad_face_vertices_image; a.dfeat = g->grad_face_features;
     clear_stale_error();
     const long long nwaves = (long long)d->B * ((d->F + MM_DB_FPW - 1) / MM_DB_FPW);
-    hipLaunchKernelGGL(dibr_bwd_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    if (d->D <= MM_DB_REG_D) hipLaunchKernelGGL(dibr_bwd_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);   // deterministic
+    else hipLaunchKernelGGL(dibr_bwd_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     return launch_ok("dibr_bwd");
 }
 

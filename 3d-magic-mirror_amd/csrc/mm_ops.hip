@@ -8,6 +8,7 @@
 // fixed-order reduction needs a second, tiny one), with the same device functions the fused render kernels use (to_camera,
 // bilin_setup, sh_bands), so values agree bit for bit with the fused path's intermediate quantities.
 // Semantics: SURVEY.md 8(a) rows a5, a6, a9, a10, a14; gradients Appendix A.3 and exact chain rules of the forwards.
+#include <algorithm>
 #include "mm_device.h"
 
 namespace mm {
@@ -186,10 +187,23 @@ __global__ __launch_bounds__(1024) void csr_build_kernel(int V, int F, const int
     }
     __threadfence();
     __syncthreads();
-    // ascending order inside every list (insertion sort of ~6 entries; agent-scope accesses: the scatter above went around this CU's L1).
-    // The lists are contiguous: vertex v's is [cursor[v-1], cursor[v]) now that every cursor stands at its list's end.
+    // ascending order inside every list.  The lists are contiguous: vertex v's is [cursor[v-1], cursor[v]) now that every cursor stands at its
+    // list's end.  Up to twelve entries (every template of the reference: valence <= 10) are fetched in ONE trip, sorted in registers by a fixed
+    // network and stored back; a longer list is insertion-sorted in place (agent-scope accesses: the scatter above went around this CU's L1).
     for (int v = tid; v < V; v += 1024) {
-        const int beg = v ? s_cnt[v - 1] : 0, end = s_cnt[v];
+        const int beg = v ? s_cnt[v - 1] : 0, end = s_cnt[v], len = end - beg;
+        if (len <= 12) {
+            int e[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) e[k] = k < len ? __hip_atomic_load(items + beg + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7FFFFFFF;
+#pragma unroll
+            for (int pass = 0; pass < 12; ++pass)
+#pragma unroll
+                for (int k = pass & 1; k + 1 < 12; k += 2) { const int lo = min(e[k], e[k + 1]), hi = max(e[k], e[k + 1]); e[k] = lo; e[k + 1] = hi; }   // odd-even transposition
+#pragma unroll
+            for (int k = 0; k < 12; ++k) if (k < len) items[beg + k] = e[k];
+            continue;
+        }
         for (int i = beg + 1; i < end; ++i) {
             const int key = __hip_atomic_load(items + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int j = i - 1;
@@ -285,9 +299,49 @@ __global__ __launch_bounds__(256) void texmap_fwd_kernel(MMTexMapDesc d) {
 // The texture gradient is a scatter.  The fused path gathers it through per-tile record lists; this stand-alone operator keeps
 // kaolin/ATen's formulation (hardware float atomics into a zero-filled gradient) but never issues an atomic for a zero
 // contribution: pixels no face covers all sample uv = (0,0) and would otherwise pile onto one texel.
+// Scratch of the deterministic texture-gradient scatter: per image max |grad_out| (float bits), then one 64-bit fixed-point accumulator per texel.
+__host__ __device__ inline size_t texmap_acc_offset(int B) { return align256((size_t)B * sizeof(unsigned)); }
+__global__ __launch_bounds__(256) void texmap_max_kernel(MMTexMapDesc d, const float* grad_out, unsigned* gmax) {
+    const int b = blockIdx.y;
+    const size_t n = (size_t)d.N * d.C;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(grad_out[(size_t)b * n + i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(gmax + b, __float_as_uint(m));     // (non-negative floats order like their bits; NaN / inf: an inf scale below)
+}
+// every contribution is |grad_out| * weight with weight <= 1: the image's largest is placed at 2^40, 2^22 of them fit a 63-bit sum
+__device__ inline float texmap_scale(unsigned maxbits, float& inv) {
+    const float M = __uint_as_float(maxbits);
+    if (!(M > 0.f) || !(M < INFINITY)) { inv = 0.f; return 0.f; }
+    int e;
+    (void)frexpf(M, &e);
+    const int k = min(max(40 - e, -80), 126);
+    inv = ldexpf(1.f, -k);
+    return ldexpf(1.f, k);
+}
+__global__ __launch_bounds__(256) void texmap_finish_kernel(MMTexMapDesc d, const unsigned* gmax, const long long* acc, float* grad_textures) {
+    const int b = blockIdx.y;
+    const size_t n = (size_t)d.C * d.Ht * d.Wt;
+    float inv;
+    (void)texmap_scale(gmax[b], inv);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) grad_textures[(size_t)b * n + i] = (float)acc[(size_t)b * n + i] * inv;
+}
+
+template <bool kFixed>
 __global__ __launch_bounds__(256) void texmap_bwd_kernel(MMTexMapDesc d, MMTexMapGrads g) {
     const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
     if (n >= d.N) return;
+    float scale = 1.f, inv_unused;
+    long long* acc64 = nullptr;
+    if (kFixed) {
+        scale = texmap_scale(((const unsigned*)g.workspace)[b], inv_unused);
+        acc64 = (long long*)((char*)g.workspace + texmap_acc_offset(d.B));
+    }
+    // one contribution to texel `idx` of the (B,C,Ht,Wt) gradient: a 64-bit integer add (exact, commutative) or a float atomic
+    auto scatter = [&](size_t idx, float v) {
+        if (kFixed) atomicAdd((unsigned long long*)(acc64 + idx), (unsigned long long)__float2ll_rn(v * scale));
+        else atomicAdd(g.grad_textures + idx, v);
+    };
     const size_t p = (size_t)b * d.N + n;
     const float u = d.uv[p * 2], v = d.uv[p * 2 + 1];
     const size_t plane = (size_t)d.Ht * d.Wt;
@@ -298,7 +352,7 @@ __global__ __launch_bounds__(256) void texmap_bwd_kernel(MMTexMapDesc d, MMTexMa
             nearest_texel(u, v, d.Ht, d.Wt, x, y);
             for (int c = 0; c < d.C; ++c) {
                 const float go = g.grad_out[p * d.C + c];
-                if (go != 0.f) atomicAdd(g.grad_textures + ((size_t)b * d.C + c) * plane + (size_t)y * d.Wt + x, go);
+                if (go != 0.f) scatter(((size_t)b * d.C + c) * plane + (size_t)y * d.Wt + x, go);
             }
         }
         return;
@@ -314,11 +368,11 @@ __global__ __launch_bounds__(256) void texmap_bwd_kernel(MMTexMapDesc d, MMTexMa
         const float tnw = inw ? tex[(size_t)s.y0 * d.Wt + s.x0] : 0.f, tne = ine ? tex[(size_t)s.y0 * d.Wt + s.x1] : 0.f;
         const float tsw = isw ? tex[(size_t)s.y1 * d.Wt + s.x0] : 0.f, tse = ise ? tex[(size_t)s.y1 * d.Wt + s.x1] : 0.f;
         if (g.grad_textures && go != 0.f) {
-            float* dt = g.grad_textures + ((size_t)b * d.C + c) * plane;
-            if (inw) atomicAdd(dt + (size_t)s.y0 * d.Wt + s.x0, go * s.wnw);
-            if (ine) atomicAdd(dt + (size_t)s.y0 * d.Wt + s.x1, go * s.wne);
-            if (isw) atomicAdd(dt + (size_t)s.y1 * d.Wt + s.x0, go * s.wsw);
-            if (ise) atomicAdd(dt + (size_t)s.y1 * d.Wt + s.x1, go * s.wse);
+            const size_t dt = ((size_t)b * d.C + c) * plane;
+            if (inw) scatter(dt + (size_t)s.y0 * d.Wt + s.x0, go * s.wnw);
+            if (ine) scatter(dt + (size_t)s.y0 * d.Wt + s.x1, go * s.wne);
+            if (isw) scatter(dt + (size_t)s.y1 * d.Wt + s.x0, go * s.wsw);
+            if (ise) scatter(dt + (size_t)s.y1 * d.Wt + s.x1, go * s.wse);
         }
         gix += go * ((tne - tnw) * ey + (tse - tsw) * s.ty);
         giy += go * ((tsw - tnw) * ex + (tse - tne) * s.tx);
@@ -345,26 +399,47 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(MMShDesc d) {
     d.out[p] = coef;
 }
 
-__global__ __launch_bounds__(256) void sh_bwd_kernel(MMShDesc d, MMShGrads g) {
-    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-    const bool live = n < d.N;
-    const size_t p = (size_t)b * d.N + (live ? n : 0);
-    const float x = d.normals[p * 3], y = d.normals[p * 3 + 1], z = d.normals[p * 3 + 2];
-    const float go = live ? g.grad_out[p] : 0.f;
+// One workgroup of 1024 threads per image: the nine light gradients are sums over ALL of the image's points -- per thread over its points in
+// index order, a fixed butterfly per wave, the sixteen waves in index order: no atomics (2 304 float atomics per image on nine addresses took
+// 87 us at B=48, 128x128), no zero-fill, bitwise reproducible.
+__global__ __launch_bounds__(1024) void sh_bwd_kernel(MMShDesc d, MMShGrads g) {
+    __shared__ float s_red[16][9];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float* L = d.lights + b * 9;
-    if (live && g.grad_normals) {
-        g.grad_normals[p * 3 + 0] = go * (((MM_SH_C1 * L[1] + MM_SH_C4 * y * L[4]) + MM_SH_C7 * z * L[7]) + 2.f * MM_SH_C8 * x * L[8]);
-        g.grad_normals[p * 3 + 1] = go * (((MM_SH_C1 * L[3] + MM_SH_C4 * x * L[4]) + MM_SH_C4 * z * L[5]) - 2.f * MM_SH_C8 * y * L[8]);
-        g.grad_normals[p * 3 + 2] = go * (((MM_SH_C1 * L[2] + MM_SH_C4 * y * L[5]) + 2.f * MM_SH_C6 * z * L[6]) + MM_SH_C7 * x * L[7]);
-    }
-    if (g.grad_lights) {
-        float bnd[9];
-        sh_bands(x, y, z, bnd);
+    float L9[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const float s = wave_sum(go * bnd[i]);
-            if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(g.grad_lights + b * 9 + i, s);
+    for (int i = 0; i < 9; ++i) L9[i] = L[i];
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    for (int n = tid; n < d.N; n += 1024) {
+        const size_t p = (size_t)b * d.N + n;
+        const float x = d.normals[p * 3], y = d.normals[p * 3 + 1], z = d.normals[p * 3 + 2];
+        const float go = g.grad_out[p];
+        if (g.grad_normals) {
+            g.grad_normals[p * 3 + 0] = go * (((MM_SH_C1 * L9[1] + MM_SH_C4 * y * L9[4]) + MM_SH_C7 * z * L9[7]) + 2.f * MM_SH_C8 * x * L9[8]);
+            g.grad_normals[p * 3 + 1] = go * (((MM_SH_C1 * L9[3] + MM_SH_C4 * x * L9[4]) + MM_SH_C4 * z * L9[5]) - 2.f * MM_SH_C8 * y * L9[8]);
+            g.grad_normals[p * 3 + 2] = go * (((MM_SH_C1 * L9[2] + MM_SH_C4 * y * L9[5]) + 2.f * MM_SH_C6 * z * L9[6]) + MM_SH_C7 * x * L9[7]);
         }
+        if (g.grad_lights) {
+            float bnd[9];
+            sh_bands(x, y, z, bnd);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[i] += go * bnd[i];
+        }
+    }
+    if (!g.grad_lights) return;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float s = wave_sum(acc[i]);
+        if ((tid & 63) == 0) s_red[tid >> 6][i] = s;
+    }
+    __syncthreads();
+    if (tid < 9) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += s_red[w][tid];
+        g.grad_lights[b * 9 + tid] = s;
     }
 }
 
@@ -495,10 +570,27 @@ int mm_texture_mapping_backward(const MMTexMapDesc* d, const MMTexMapGrads* g, m
     if (st != MM_OK) return st;
     if (!g || !g->grad_out || (!g->grad_uv && !g->grad_textures)) return MM_ERR_NULL_POINTER;
     mm::clear_stale_error();
-    if (g->grad_textures && hipMemsetAsync(g->grad_textures, 0, sizeof(float) * (size_t)d->B * d->C * d->Ht * d->Wt, (hipStream_t)stream) != hipSuccess)
-        return mm::launch_ok("texture_mapping_memset") == MM_OK ? MM_ERR_LAUNCH : MM_ERR_LAUNCH;
-    hipLaunchKernelGGL(mm::texmap_bwd_kernel, dim3((d->N + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d, *g);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t texels = (size_t)d->B * d->C * d->Ht * d->Wt;
+    if (g->grad_textures && g->workspace) {                      // deterministic: max |grad_out| -> 64-bit fixed-point scatter -> convert
+        if (g->workspace_bytes < mm_texture_mapping_backward_query_workspace(d) || ((uintptr_t)g->workspace & 255)) return MM_ERR_WORKSPACE;
+        if (hipMemsetAsync(g->workspace, 0, mm_texture_mapping_backward_query_workspace(d), s) != hipSuccess) return MM_ERR_LAUNCH;
+        const unsigned nb = (unsigned)std::min<size_t>(((size_t)d->N * d->C + 255) / 256, 64);
+        hipLaunchKernelGGL(mm::texmap_max_kernel, dim3(nb, d->B), dim3(256), 0, s, *d, g->grad_out, (unsigned*)g->workspace);
+        hipLaunchKernelGGL(mm::texmap_bwd_kernel<true>, dim3((d->N + 255) / 256, d->B), dim3(256), 0, s, *d, *g);
+        const unsigned nf = (unsigned)std::min<size_t>(((size_t)d->C * d->Ht * d->Wt + 255) / 256, 256);
+        hipLaunchKernelGGL(mm::texmap_finish_kernel, dim3(nf, d->B), dim3(256), 0, s, *d, (const unsigned*)g->workspace,
+                           (const long long*)((const char*)g->workspace + mm::texmap_acc_offset(d->B)), g->grad_textures);
+        return mm::launch_ok("texture_mapping_bwd");
+    }
+    if (g->grad_textures && hipMemsetAsync(g->grad_textures, 0, sizeof(float) * texels, s) != hipSuccess) return MM_ERR_LAUNCH;
+    hipLaunchKernelGGL(mm::texmap_bwd_kernel<false>, dim3((d->N + 255) / 256, d->B), dim3(256), 0, s, *d, *g);
     return mm::launch_ok("texture_mapping_bwd");
+}
+
+size_t mm_texture_mapping_backward_query_workspace(const MMTexMapDesc* d) {
+    if (!d || d->B <= 0 || d->C <= 0 || d->Ht <= 0 || d->Wt <= 0) return 0;
+    return mm::texmap_acc_offset(d->B) + mm::align256((size_t)d->B * d->C * d->Ht * d->Wt * sizeof(long long));
 }
 
 static int check_sh(const MMShDesc* d) {
@@ -522,8 +614,7 @@ int mm_sh_lighting_backward(const MMShDesc* d, const MMShGrads* g, mm_stream_t s
     if (st != MM_OK) return st;
     if (!g || !g->grad_out || (!g->grad_normals && !g->grad_lights)) return MM_ERR_NULL_POINTER;
     mm::clear_stale_error();
-    if (g->grad_lights && hipMemsetAsync(g->grad_lights, 0, sizeof(float) * (size_t)d->B * 9, (hipStream_t)stream) != hipSuccess) return MM_ERR_LAUNCH;
-    hipLaunchKernelGGL(mm::sh_bwd_kernel, dim3((d->N + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d, *g);
+    hipLaunchKernelGGL(mm::sh_bwd_kernel, dim3(d->B), dim3(1024), 0, (hipStream_t)stream, *d, *g);
     return mm::launch_ok("sh_lighting_bwd");
 }
 

@@ -52,8 +52,9 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_
         // tiles four per WAVE (shade_empty_tiles); the grid is sized for "no tile is empty", workgroups behind the last one exit
         int b, j;
         walk_image_rank((int)blockIdx.x, a.B, a.spread, b, j);
-        const int nh = kBlock ? a.nheavy[2 * b] : 0, nne = a.nheavy[2 * b + 1];
-        const int W1 = kBlock ? nh + (max(nne - nh, 0) + 3) / 4 : nne;       // workgroups that walk: heavy tiles one each, the others four each (or one)
+        const int nh = kBlock ? a.nheavy[4 * b] : 0, nne = a.nheavy[4 * b + 1], ns = kBlock ? min(a.nheavy[4 * b + 2], max(nne - nh, 0)) : 0;
+        // workgroups that walk: heavy tiles one each, split tiles 4 / MM_SEMI_SPLIT each, the others four each (or one)
+        const int W1 = kBlock ? nh + semi_groups(ns) + (max(nne - nh - ns, 0) + 3) / 4 : nne;
         const int per = kBlock ? 16 : 4, W2 = (4 * a.blocks_per_image - nne + per - 1) / per;   // workgroups that shade empty tiles
         limit = nne;
         if (j >= W1) {                                           // (interleaving the two kinds of workgroup evenly was measured: no gain at 512x512,
@@ -149,9 +150,9 @@ __global__ __launch_bounds__(256) void order_kernel(RasterArgs a, unsigned short
             s_key[4 * blk] = s_key[4 * blk + 1] = s_key[4 * blk + 2] = s_key[4 * blk + 3] = (unsigned short)c;
             atomicAdd(&s_start[c], 4);
         }
-        tile_sort_scatter<256, 4>(nslot, s_key, s_start, s_wave, order + (size_t)b * nslot, nheavy + 2 * b);
+        tile_sort_scatter<256, 4>(nslot, s_key, s_start, s_wave, order + (size_t)b * nslot, nheavy + 4 * b);
     } else
-        tile_sort_scatter<256, 1>(nslot, s_key, s_start, s_wave, order + (size_t)b * nslot, nheavy + 2 * b);
+        tile_sort_scatter<256, 1>(nslot, s_key, s_start, s_wave, order + (size_t)b * nslot, nheavy + 4 * b);
 }
 
 RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {

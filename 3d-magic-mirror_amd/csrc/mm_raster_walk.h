@@ -95,12 +95,24 @@ __device__ inline TileCtx make_tile(const RasterArgs& a, int wv, int rank, bool&
         int j;
         walk_image_rank((int)blockIdx.x, a.B, a.spread, t.b, j);
         if (rank >= 0) j = rank;
-        const int nh = kBlock ? a.nheavy[2 * t.b] : 0;
+        const int nh = kBlock ? a.nheavy[4 * t.b] : 0;
+        const int ns = kBlock && MM_SEMI_SPLIT > 1 ? min(a.nheavy[4 * t.b + 2], max(limit - nh, 0)) : 0, nsg = semi_groups(ns);
         int idx;
+        t.pixmask = ~0ull;
         if (!kBlock) idx = j;
         else if (j < nh) { idx = j; coop = true; }
-        else idx = nh + (j - nh) * 4 + wv;
-        valid = idx < limit;
+        else if (j < nh + nsg) {
+            // a SPLIT tile: MM_SEMI_SPLIT waves walk the same candidates, each for its share of the tile's pixel rows.  Nothing is shared and
+            // nothing synchronised -- every per-pixel result depends on its own pixel alone -- so the walk's fixed part is paid twice (four
+            // times) and the pair work, which is what these tiles' 25-30 us consist of, is halved (quartered).
+            const int k = (j - nh) * 4 + wv, ti = k / MM_SEMI_SPLIT, part = k % MM_SEMI_SPLIT;
+            idx = nh + ti;
+            valid = ti < ns;
+            constexpr int rows = 8 / MM_SEMI_SPLIT;               // (pixel p of the tile is lane p: row = p >> 3)
+            t.pixmask = (rows * 8 >= 64 ? ~0ull : ((1ull << (rows * 8)) - 1ull)) << (part * rows * 8);
+        }
+        else idx = nh + ns + (j - nh - nsg) * 4 + wv;
+        valid = valid && idx < limit;
         const unsigned e = a.order[(size_t)t.b * nslot + (valid ? idx : 0)];
         const int slot = (int)(e & 0x7FFFu);
         t.empty = (e >> 15) != 0;                                // the plan kernel counted no candidate at all for this tile
@@ -109,6 +121,7 @@ __device__ inline TileCtx make_tile(const RasterArgs& a, int wv, int rank, bool&
         map_block(kBlock ? blockIdx.x : blockIdx.x >> 2, a.B, a.blocks_per_image, t.b, blk);
         t.wave = kBlock ? wv : (int)(blockIdx.x & 3);
         t.empty = false;
+        t.pixmask = ~0ull;
     }
     t.blk = blk;
     t.lane = threadIdx.x & 63;
@@ -171,6 +184,7 @@ __device__ inline void candidate_masks(const RasterArgs& a, const TileCtx& t, co
     const bool front = (a.options & MM_OPT_CULL_STRICT) ? g2.y > 0.f : g2.y >= 0.f;
     zb = depth_bound(g1.z, g1.w, g2.x);
     box_masks(a, t, xmin, ymin, xmax, ymax, front && zb >= zfloor, soft && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED)), bmode, mh, ms);
+    mh &= t.pixmask; ms &= t.pixmask;                            // (a split tile: this wave's rows only)
 }
 __device__ inline void stage_slot(WaveStage* st, int slot, int f, const float4& g0, const float4& g1, const float4& g2, unsigned zb) {
     st->p0[slot] = g0; st->p1[slot] = g1;
@@ -394,12 +408,10 @@ __device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, Wa
             const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
             cnt += __popcll(sm);
             if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);   // knum-th face taken
-#ifdef MM_BATCH_SOFT_SCALAR
-            if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, st, s2, l, j, live); });
+#ifdef MM_BATCH_SOFT_PACKED                                             // (two pairs per lane in packed fp32, as the compacting walk does: measured SLOWER
+            if (__ballot(sm != 0)) soft_pairs(a, t, st, sm, s2);         //  here, raster_fwd 34.4 / 92.8 / 191.7 us against 33.8 / 88.4 / 184.7 at 128x128 / 256x256 / B=384)
 #else
-            // two pairs per lane in packed fp32 (soft_pairs: the factors are bit-identical to soft_pair's, the integer sums commute): the
-            // silhouette pairs are what the heaviest single-wave tiles of a 128x128 batch spend their time on (8-14 us of 30)
-            if (__ballot(sm != 0)) soft_pairs(a, t, st, sm, s2);
+            if (__ballot(sm != 0)) pair_parallel(t, st, sm, [&](int l, int j, bool live) { soft_pair(a, t, st, st, s2, l, j, live); });
 #endif
             MM_PP_MARK(4);
             wave_lds_sync();

@@ -337,15 +337,16 @@ class DiffRender(object):
         backward that drops texture-gradient records -- eager, C++ node or captured graph -- is noticed WITHOUT a synchronisation."""
         if self._status is None:
             self._status = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._status_word = ctypes.c_int32.from_address(self._status.data_ptr())     # (a plain host read per poll: ~0.1 us)
         return self._status.data_ptr()
 
     def poll_dropped_records(self, reset=True):
         """Texture-gradient records dropped by backward passes that have COMPLETED since the last poll (no synchronisation: a host read)."""
         if self._status is None:
             return 0
-        n = int(self._status[0])
+        n = self._status_word.value
         if n and reset:
-            self._status[0] = 0
+            self._status_word.value = 0
         return n
 
     def _raise_if_records_were_dropped(self):

@@ -270,7 +270,10 @@ class _TexMapFn(torch.autograd.Function):
         if guv is None and gtex is None:
             return None, None, None
         d = N.MMTexMapDesc(B, uv.shape[1], C, Ht, Wt, ctx.mode, N.ptr(uv), N.ptr(tex), None)
-        gr = N.MMTexMapGrads(N.ptr(g), N.ptr(guv), N.ptr(gtex))
+        ws = None
+        if gtex is not None:                                     # 64-bit fixed-point scatter: a bitwise reproducible texture gradient
+            ws = torch.empty(N.lib().mm_texture_mapping_backward_query_workspace(ctypes.byref(d)), device=dev, dtype=torch.uint8)
+        gr = N.MMTexMapGrads(N.ptr(g), N.ptr(guv), N.ptr(gtex), N.ptr(ws), 0 if ws is None else ws.numel())
         N.check(N.lib().mm_texture_mapping_backward(ctypes.byref(d), ctypes.byref(gr), N.current_stream(dev)), "mm_texture_mapping_backward")
         return guv, gtex, None
 

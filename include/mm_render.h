@@ -400,8 +400,14 @@ typedef struct MMTexMapDesc {
 typedef struct MMTexMapGrads {
     const float* grad_out;          /* (B,N,C) */
     float* grad_uv;                 /* (B,N,2) overwritten, or NULL (zero for MM_TEXMAP_NEAREST) */
-    float* grad_textures;           /* (B,C,Ht,Wt) overwritten (zero-filled on the stream, then float atomics), or NULL */
+    float* grad_textures;           /* (B,C,Ht,Wt) overwritten, or NULL */
+    /* optional scratch of >= mm_texture_mapping_backward_query_workspace bytes (256-byte aligned).  With it the texture gradient is
+     * accumulated in 64-bit FIXED POINT (per-image power-of-two scale from max |grad_out|; integer adds commute) and is bitwise
+     * reproducible; without it (NULL) the scatter uses float atomics (order-dependent in the last bits). */
+    void* workspace;
+    size_t workspace_bytes;
 } MMTexMapGrads;
+size_t mm_texture_mapping_backward_query_workspace(const MMTexMapDesc* desc);
 int mm_texture_mapping_forward(const MMTexMapDesc* desc, mm_stream_t stream);
 int mm_texture_mapping_backward(const MMTexMapDesc* desc, const MMTexMapGrads* grads, mm_stream_t stream);
 
@@ -456,7 +462,7 @@ const char* mm_last_error_detail(void);
 size_t mm_struct_size(int which);
 /* Bumped whenever a struct or the meaning of a field changes (2: op boundary added, reserved uv-tile fields and profiling slot
  * MM_PROF_BIN removed, options bits defined; 3: MMRenderDesc takes the fixed-stride vertex -> corner table instead of the CSR,
- * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, mm_chamfer_nearest, mm_build_vertex_corner_csr_device).  Bindings must refuse a library whose
+ * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, MMTexMapGrads.workspace, mm_chamfer_nearest, mm_build_vertex_corner_csr_device).  Bindings must refuse a library whose
  * version differs from what they mirror. */
 #define MM_ABI_VERSION 4
 int mm_abi_version(void);

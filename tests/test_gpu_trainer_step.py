@@ -78,22 +78,20 @@ def test_graphed_renders_give_the_eager_step_bit_for_bit():
 
 def test_lean_step_is_the_step():
     """TrainerStep(lean=True, many=True): renders #1-#3 as ONE DiffRender.render_many call over 3B images and render #4 as render_geometry (its
-    image is discarded, trainer.py:367).  Forward values are those of the four separate calls bit for bit (an image does not depend on its batch); the
-    backward agrees to rounding: three optimisation steps give the same losses to 1e-5 and the same encoder weights to 1e-6."""
+    image is discarded, trainer.py:367).  The forward is that of the four separate calls bit for bit (an image does not depend on its batch):
+    same loss; the backward agrees to rounding: the encoder's gradient of the first step to 1e-4 of its largest entry.  (Weights after a few
+    Adam steps are not compared: Adam's first updates are lr * g / |g|, which turns a last-bit difference of a tiny gradient into a full step.)"""
     mod = importlib.import_module("3d-magic-mirror_amd.trainer_step")
     path = os.path.join(TEMPLATES, "sphere.npz")
     torch.backends.cudnn.deterministic = True
     runs = []
     for lean in (False, True):
         ts = mod.TrainerStep(path, 64, 4, torch.device("cuda:0"), lean=lean, many=lean)
-        first = float(ts.step())
-        losses = [first] + [float(ts.step()) for _ in range(2)]
-        runs.append((losses, [p.detach().clone() for p in ts.netE.parameters()]))
-    assert runs[0][0][0] == runs[1][0][0], (runs[0][0], runs[1][0])      # the first step's loss: forward only
-    for a, b in zip(runs[0][0], runs[1][0]):
-        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (runs[0][0], runs[1][0])
-    worst = max(float((a - b).abs().max()) for a, b in zip(runs[0][1], runs[1][1]))
-    assert worst < 1e-5, worst
+        loss = float(ts.step(optimize=False))
+        runs.append((loss, {k: float(v) for k, v in ts.last.items()}, [p.grad.detach().clone() for p in ts.netE.parameters()]))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1], (runs[0][:2], runs[1][:2])
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(a.abs().max())), (float((a - b).abs().max()), float(a.abs().max()))
 
 
 def test_render_many_is_the_separate_renders():

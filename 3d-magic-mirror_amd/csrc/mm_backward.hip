@@ -369,8 +369,11 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
 __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage* s_stage) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / MM_FL, sl = lane % MM_FL;
     SweepStage* st = &s_stage[wave];
-    const long long wid = (long long)block * 4 + wave;            // wave index over (item octet, image)
-    const int b = (int)(wid % a.B);
+    const long long wid = (long long)block * 4 + MM_WAVE_UNIFORM(wave);   // wave index over (item octet, image)
+    // (wave-uniform by construction; saying so makes the image's scalars -- item count, chunk size, the 32 shards of the fixed-point scale -- SCALAR
+    //  loads from the scalar cache instead of 34 vector loads of one address per wave: 8 000 waves x 34 wave-loads were ~a third of the kernel's
+    //  vector-memory instructions)
+    const int b = MM_WAVE_UNIFORM(wid % a.B);
     const int2 ni = a.nitems[b];                                  // items of the image, pixels per chunk
     // The image's items are dealt to its waves ROUND-ROBIN (wave w takes items w, w + nw, w + 2 nw, ...): the chunks of a close-up face are
     // consecutive items, most of their pixels owned, and a wave holding eight of them in a row (a thousand hits, sixteen dependent rounds

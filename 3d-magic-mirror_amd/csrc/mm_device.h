@@ -12,6 +12,13 @@
 #include "../../include/mm_render.h"
 
 #define MM_WAVE 64
+// a value that is the same in all lanes of the wave BY CONSTRUCTION (derived from threadIdx.x >> 6 and the like), said so: the compiler then
+// keeps it in a scalar register, and what is addressed by it becomes scalar arithmetic and scalar-cache loads.  -DMM_NO_SCALAR_WAVE: A/B switch.
+#ifdef MM_NO_SCALAR_WAVE
+#define MM_WAVE_UNIFORM(x) (x)
+#else
+#define MM_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
+#endif
 #define MM_TILE 8             // a wave owns an 8x8 pixel tile, one lane per pixel
 #define MM_BLOCK_PX 16        // a 256-thread workgroup renders a 16x16 pixel block: 2x2 wave tiles
 #define MM_BLOCK_WAVES 4
@@ -82,8 +89,7 @@ struct Workspace {
     float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
-    int* nheavy;           // (B,4)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty;
-                           //            how many behind the cooperative ones are split by pixel rows over several waves
+    int* nheavy;           // (B,4)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty
     int* bincount;         // (B,nbins)  candidates per screen bin (big screens / meshes only: bincount_kernel -> order_kernel)
     int* fflag;            // (B,F,2)    [0] = 1: the face won a pixel; [1] = 1: an uncovered pixel took it into its silhouette product.  Only such faces
                            //            receive gradient from the pixels, and only they are swept by the backward -- a face that only OWNS pixels over its

@@ -15,15 +15,6 @@ namespace mm {
 #ifndef MM_HEAVY_MAX
 #define MM_HEAVY_MAX 32       // ... if it is among the image's MM_HEAVY_MAX heaviest
 #endif
-#ifndef MM_SEMI_CAND
-#define MM_SEMI_CAND 96       // a tile with at least this many candidates (and not cooperative) is SPLIT BY PIXEL ROWS over MM_SEMI_SPLIT waves ...
-#endif
-#ifndef MM_SEMI_MAX
-#define MM_SEMI_MAX 64        // ... if it is among the image's MM_SEMI_MAX heaviest behind the cooperative ones
-#endif
-#ifndef MM_SEMI_SPLIT
-#define MM_SEMI_SPLIT 2       // waves per such tile: 2 (rows 0-3 / 4-7) or 4 (two rows each); 1 switches the split off
-#endif
 
 // s_key: the slots' clipped counts (written by the caller's threads before the call, one __syncthreads behind them is taken here);
 // s_start: 1024 ints (histogram, then the first output position of every key), zeroed by the caller before the counts were added;
@@ -46,13 +37,7 @@ __device__ inline void tile_sort_scatter(int nslot, const unsigned short* s_key,
     for (int j = 0; j < KPT; ++j) { s_start[1023 - (KPT * tid + j)] = before; before += h[j]; }
     __syncthreads();
     // tiles with at least MM_HEAVY_CAND candidates come first: the slots in front of key MM_HEAVY_CAND - 1
-    if (tid == 0) {
-        const int nh = min(s_start[MM_HEAVY_CAND - 1], MM_HEAVY_MAX);
-        nheavy[0] = nh; nheavy[1] = s_start[0];                   // slots in front of key 0: not empty
-        // behind the cooperative tiles: the tiles with at least MM_SEMI_CAND candidates, walked by MM_SEMI_SPLIT waves each (a share of the
-        // tile's pixel rows per wave, nothing shared: make_tile)
-        nheavy[2] = min(max(s_start[MM_SEMI_CAND - 1] - nh, 0), MM_SEMI_MAX);
-    }
+    if (tid == 0) { nheavy[0] = min(s_start[MM_HEAVY_CAND - 1], MM_HEAVY_MAX); nheavy[1] = s_start[0]; }   // slots in front of key 0: not empty
     __syncthreads();
     // GROUP consecutive slots (the tiles of a block: equal keys, set by the caller) take GROUP consecutive places
     for (int g = tid; g * GROUP < nslot; g += NT) {

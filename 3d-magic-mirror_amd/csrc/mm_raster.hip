@@ -45,16 +45,16 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_
     MM_TIMELINE_BEGIN();
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
     MM_PP_BEGIN();
-    const int wv = kBlock ? threadIdx.x >> 6 : 0;
+    const int wv = kBlock ? MM_WAVE_UNIFORM(threadIdx.x >> 6) : 0;   // (wave-uniform, said so: the tile's coordinates, its order entry and its
+                                                                                             //  mask row's address are then scalar arithmetic and scalar-cache loads)
     int limit = 4 * a.blocks_per_image, rank = -1;               // rank: this workgroup's index among its image's walking workgroups (-1: from blockIdx)
     if (a.order) {
         // workgroups of image b, in launch order: heavy tiles (one each), the other non-empty tiles (four each, or one), then the empty
         // tiles four per WAVE (shade_empty_tiles); the grid is sized for "no tile is empty", workgroups behind the last one exit
         int b, j;
         walk_image_rank((int)blockIdx.x, a.B, a.spread, b, j);
-        const int nh = kBlock ? a.nheavy[4 * b] : 0, nne = a.nheavy[4 * b + 1], ns = kBlock ? min(a.nheavy[4 * b + 2], max(nne - nh, 0)) : 0;
-        // workgroups that walk: heavy tiles one each, split tiles 4 / MM_SEMI_SPLIT each, the others four each (or one)
-        const int W1 = kBlock ? nh + semi_groups(ns) + (max(nne - nh - ns, 0) + 3) / 4 : nne;
+        const int nh = kBlock ? a.nheavy[4 * b] : 0, nne = a.nheavy[4 * b + 1];
+        const int W1 = kBlock ? nh + (max(nne - nh, 0) + 3) / 4 : nne;       // workgroups that walk: heavy tiles one each, the others four each (or one)
         const int per = kBlock ? 16 : 4, W2 = (4 * a.blocks_per_image - nne + per - 1) / per;   // workgroups that shade empty tiles
         limit = nne;
         if (j >= W1) {                                           // (interleaving the two kinds of workgroup evenly was measured: no gain at 512x512,

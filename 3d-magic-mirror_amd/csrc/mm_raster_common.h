@@ -26,7 +26,7 @@ struct RasterArgs {
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
     int* trcnt; int ntx_tex, ntiles_tex;     // (B,ntiles) covered pixels per 32x32-texel tile under their bilinear footprint: sizes the backward's record lists
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
-    const int* nheavy;                      // (B,4) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty; how many are split by rows
+    const int* nheavy;                      // (B,4) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty
     int spread;                             // sorted order: eight consecutive workgroups = eight ranks of one image (walk_image_rank); 2: the four tiles of a block on one XCD
     int block_sort;                         // the order kernel sorts 16x16 blocks, a block's four tiles stay together (bins of 16 pixels or more)
     const int* bincount;                    // (B,nbins) candidates per screen bin, or nullptr (small screens: the order kernel counts the mask bits itself)
@@ -58,14 +58,11 @@ struct TileCtx {
     float xf0, yf0;                         // (float)(2 tx0 + 1 - W), (float)(H - 2 ty0 - 1): the tile's first column / row in the pixel-centre convention;
                                             // column i is kx * (xf0 + 2 i), row i is ky * (yf0 - 2 i)  (exact integers: the same floats as pixel_x_k / pixel_y_k)
     const uint64_t* mask;                   // this wave's bin row of candidate bits: `words` 64-bit words
-    uint64_t pixmask;                       // the tile's pixels THIS wave renders (bit = lane): all of them, or its share of the rows of a split tile
 };
-// workgroups (of four waves) that walk ns split tiles
-__host__ __device__ inline int semi_groups(int ns) { return MM_SEMI_SPLIT > 1 ? (ns * MM_SEMI_SPLIT + 3) / 4 : 0; }
 
 __device__ inline void tile_pixels(const RasterArgs& a, TileCtx& t) {
     t.px = t.tx0 + (t.lane & 7); t.py = t.ty0 + (t.lane >> 3);
-    t.in_img = t.px < a.W && t.py < a.H && ((t.pixmask >> t.lane) & 1ull);      // (a split tile: the other waves' rows are "outside" for this one)
+    t.in_img = t.px < a.W && t.py < a.H;
     t.xf0 = (float)(2 * t.tx0 + 1 - a.W); t.yf0 = (float)(a.H - 2 * t.ty0 - 1);
     if (t.empty) { t.x0 = t.y0 = 0.f; return; }                 // wave-uniform: an empty tile never looks at pixel centres
     t.x0 = pixel_x_k(t.px, a.W, a.kx); t.y0 = pixel_y_k(t.py, a.H, a.ky);
@@ -670,7 +667,7 @@ inline int walk_spread(const RasterArgs& a) {
 }
 inline unsigned walk_grid(const RasterArgs& a, bool block) {
     if (!a.order) return (unsigned)a.B * (unsigned)a.blocks_per_image * (block ? 1u : 4u);
-    const unsigned per_image = block ? (unsigned)(MM_HEAVY_MAX + semi_groups(MM_SEMI_MAX) + (4 * a.blocks_per_image + 3) / 4) : (unsigned)a.blocks_per_image * 4u;
+    const unsigned per_image = block ? (unsigned)(MM_HEAVY_MAX + (4 * a.blocks_per_image + 3) / 4) : (unsigned)a.blocks_per_image * 4u;
     return (unsigned)a.B * ((per_image + 31u) & ~31u);           // (ranks beyond an image's last workgroup exit at once)
 }
 

@@ -96,24 +96,12 @@ __device__ inline TileCtx make_tile(const RasterArgs& a, int wv, int rank, bool&
         walk_image_rank((int)blockIdx.x, a.B, a.spread, t.b, j);
         if (rank >= 0) j = rank;
         const int nh = kBlock ? a.nheavy[4 * t.b] : 0;
-        const int ns = kBlock && MM_SEMI_SPLIT > 1 ? min(a.nheavy[4 * t.b + 2], max(limit - nh, 0)) : 0, nsg = semi_groups(ns);
         int idx;
-        t.pixmask = ~0ull;
         if (!kBlock) idx = j;
         else if (j < nh) { idx = j; coop = true; }
-        else if (j < nh + nsg) {
-            // a SPLIT tile: MM_SEMI_SPLIT waves walk the same candidates, each for its share of the tile's pixel rows.  Nothing is shared and
-            // nothing synchronised -- every per-pixel result depends on its own pixel alone -- so the walk's fixed part is paid twice (four
-            // times) and the pair work, which is what these tiles' 25-30 us consist of, is halved (quartered).
-            const int k = (j - nh) * 4 + wv, ti = k / MM_SEMI_SPLIT, part = k % MM_SEMI_SPLIT;
-            idx = nh + ti;
-            valid = ti < ns;
-            constexpr int rows = 8 / MM_SEMI_SPLIT;               // (pixel p of the tile is lane p: row = p >> 3)
-            t.pixmask = (rows * 8 >= 64 ? ~0ull : ((1ull << (rows * 8)) - 1ull)) << (part * rows * 8);
-        }
-        else idx = nh + ns + (j - nh - nsg) * 4 + wv;
-        valid = valid && idx < limit;
-        const unsigned e = a.order[(size_t)t.b * nslot + (valid ? idx : 0)];
+        else idx = nh + (j - nh) * 4 + wv;
+        valid = idx < limit;
+        const unsigned e = (unsigned)MM_WAVE_UNIFORM(a.order[(size_t)t.b * nslot + (valid ? idx : 0)]);
         const int slot = (int)(e & 0x7FFFu);
         t.empty = (e >> 15) != 0;                                // the plan kernel counted no candidate at all for this tile
         blk = slot >> 2; t.wave = slot & 3;
@@ -121,7 +109,6 @@ __device__ inline TileCtx make_tile(const RasterArgs& a, int wv, int rank, bool&
         map_block(kBlock ? blockIdx.x : blockIdx.x >> 2, a.B, a.blocks_per_image, t.b, blk);
         t.wave = kBlock ? wv : (int)(blockIdx.x & 3);
         t.empty = false;
-        t.pixmask = ~0ull;
     }
     t.blk = blk;
     t.lane = threadIdx.x & 63;
@@ -172,6 +159,12 @@ __device__ inline int idw_next(IdWindows& iw, const TileCtx& t, WaveStage* st) {
 #ifndef MM_HARD_ROW_MAX
 #define MM_HARD_ROW_MAX 6
 #endif
+#ifndef MM_NEAR_PASSES
+#define MM_NEAR_PASSES 2          // depth bands a flush's colour candidates are evaluated in, nearest first (1: one pass in index order)
+#endif
+#ifndef MM_NEAR_MIN_PAIRS
+#define MM_NEAR_MIN_PAIRS 256     // ... if the flush has more (pixel, candidate) box pairs than this
+#endif
 // the two pixel masks of this lane's candidate (front-face box: colour; inflated box: silhouette), candidate-major
 //   zfloor: the smallest depth_ord any in-image pixel of the tile holds (0 while one of them holds nothing): a front face whose depth bound
 //   lies below it cannot win any pixel of the tile and is not a colour candidate at all;  zb: the face's depth bound (kept with the candidate)
@@ -184,7 +177,6 @@ __device__ inline void candidate_masks(const RasterArgs& a, const TileCtx& t, co
     const bool front = (a.options & MM_OPT_CULL_STRICT) ? g2.y > 0.f : g2.y >= 0.f;
     zb = depth_bound(g1.z, g1.w, g2.x);
     box_masks(a, t, xmin, ymin, xmax, ymax, front && zb >= zfloor, soft && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED)), bmode, mh, ms);
-    mh &= t.pixmask; ms &= t.pixmask;                            // (a split tile: this wave's rows only)
 }
 __device__ inline void stage_slot(WaveStage* st, int slot, int f, const float4& g0, const float4& g1, const float4& g2, unsigned zb) {
     st->p0[slot] = g0; st->p1[slot] = g1;
@@ -310,14 +302,45 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
         { int th; (void)wave_prefix_excl(__popcll(mh), t.lane, th); MM_PP_COUNT(1ull << 32, (unsigned long long)th); }   // flushes | colour pairs
 #endif
         if (__ballot(mh != 0)) {
-            // The pair list is written row by row, every lane its own row: that costs as many trips as the LONGEST row has bits.  Rows =
-            // candidates (the masks as they are) suit small faces (a few pixels each, many candidates); a close-up face covers the whole
-            // tile (64 bits) while a pixel lies in a handful of boxes: then rows = pixels, at the price of one bit transpose.
-            const bool by_cand = wave_max_i32(__popcll(mh)) <= MM_HARD_ROW_MAX;     // (wave-uniform; one instantiation of the pair code for both)
-            hard_pairs(a, t, st, by_cand ? mh : wave_transpose64(mh, t.lane), by_cand);
-            const unsigned long long kk = st->key[t.lane];
-            open = t.in_img && kk == 0ull;
-            zfloor = wave_min_u32(t.in_img ? (unsigned)(kk >> 32) : 0xFFFFFFFFu);
+            // NEAREST FIRST.  The winner is an order-free maximum, so the flush's candidates may be evaluated in any order -- and the order decides
+            // how much early-z saves: in index order a pixel under forty overlapping boxes meets its nearest face at a random place of the list.
+            // The queued candidates are therefore taken in MM_NEAR_PASSES bands of their depth bound, nearest band first (band edges evenly
+            // spaced between the flush's smallest and largest bound: two wave reductions, no sort); after every band the tile's depth floor is
+            // refreshed and the candidates of the farther bands that lie entirely behind what EVERY pixel already holds lose their masks before
+            // a single pair of theirs is listed; the others meet tighter per-pixel depths in the pair filter.  (Strictly behind only: equal
+            // depths, which the lower index wins, are never cut -- kaolin's "strict z > best in index order")
+            const unsigned zbd = t.lane < n ? __float_as_uint(st->p2[t.lane].w) : 0u;
+            int npass = 1;
+            unsigned zlo = 0u, zhi = 0u;
+#if MM_NEAR_PASSES > 1
+            {
+                int pairs_total;
+                (void)wave_prefix_excl(__popcll(mh), t.lane, pairs_total);
+                if (pairs_total > MM_NEAR_MIN_PAIRS) {            // (wave-uniform) a short list: one pass, as before
+                    zhi = (unsigned)wave_max_i32((int)(zbd >> 1)) << 1;                         // (31-bit reductions: the bands need no last bit)
+                    zlo = wave_min_u32(mh != 0 ? zbd : 0xFFFFFFFFu);
+                    npass = zhi > zlo ? MM_NEAR_PASSES : 1;
+                }
+            }
+#endif
+            uint64_t left = mh;
+            for (int pass = 0; pass < npass; ++pass) {
+                // band `pass` holds the bounds in (edge[pass + 1], edge[pass]]: edge[0] = +inf, edge[npass] = -inf
+                const unsigned lo_edge = pass + 1 < npass ? zhi - (unsigned)(((unsigned long long)(zhi - zlo) * (unsigned)(pass + 1)) / (unsigned)npass) : 0u;
+                uint64_t m = (zbd >= lo_edge) ? left : 0ull;
+                left &= ~m;
+                if (pass > 0 && zbd < zfloor) m = 0ull;           // entirely behind the tile by now (zfloor: refreshed below)
+                if (__ballot(m != 0)) {
+                    // The pair list is written row by row, every lane its own row: that costs as many trips as the LONGEST row has bits.  Rows =
+                    // candidates (the masks as they are) suit small faces (a few pixels each, many candidates); a close-up face covers the whole
+                    // tile (64 bits) while a pixel lies in a handful of boxes: then rows = pixels, at the price of one bit transpose.
+                    const bool by_cand = wave_max_i32(__popcll(m)) <= MM_HARD_ROW_MAX;     // (wave-uniform; one instantiation of the pair code for both)
+                    hard_pairs(a, t, st, by_cand ? m : wave_transpose64(m, t.lane), by_cand);
+                    const unsigned long long kk = st->key[t.lane];
+                    open = t.in_img && kk == 0ull;
+                    zfloor = wave_min_u32(t.in_img ? (unsigned)(kk >> 32) : 0xFFFFFFFFu);
+                }
+            }
             MM_PP_MARK(3);
         }
         const uint64_t openm = __ballot(open && cnt < a.knum);

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void dibr_pack_kernel(PackArgs a) {
 template <bool kBlock, bool kQueue>
 __global__ __launch_bounds__(kBlock ? 256 : 64) void raster_dibr_kernel(RasterArgs a) {
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
-    const int wv = kBlock ? MM_WAVE_UNIFORM(threadIdx.x >> 6) : 0;
+    const int wv = kBlock ? threadIdx.x >> 6 : 0;
     bool valid, coop;
     const TileCtx t = make_tile<kBlock>(a, wv, -1, valid, coop, 4 * a.blocks_per_image);
     unsigned long long key;

@@ -306,8 +306,15 @@ __global__ __launch_bounds__(256) void texmap_max_kernel(MMTexMapDesc d, const f
     const size_t n = (size_t)d.N * d.C;
     float m = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(grad_out[(size_t)b * n + i]));
+    __shared__ float s_m[4];
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(gmax + b, __float_as_uint(m));     // (non-negative floats order like their bits; NaN / inf: an inf scale below)
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // ONE atomic per workgroup (a few per image: thousands of waves on 48 words queued at the memory side took 60 us)
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        if (m > 0.f) atomicMax(gmax + b, __float_as_uint(m));      // (non-negative floats order like their bits; NaN / inf: an inf scale below)
+    }
 }
 // every contribution is |grad_out| * weight with weight <= 1: the image's largest is placed at 2^40, 2^22 of them fit a 63-bit sum
 __device__ inline float texmap_scale(unsigned maxbits, float& inv) {
@@ -575,7 +582,7 @@ int mm_texture_mapping_backward(const MMTexMapDesc* d, const MMTexMapGrads* g, m
     if (g->grad_textures && g->workspace) {                      // deterministic: max |grad_out| -> 64-bit fixed-point scatter -> convert
         if (g->workspace_bytes < mm_texture_mapping_backward_query_workspace(d) || ((uintptr_t)g->workspace & 255)) return MM_ERR_WORKSPACE;
         if (hipMemsetAsync(g->workspace, 0, mm_texture_mapping_backward_query_workspace(d), s) != hipSuccess) return MM_ERR_LAUNCH;
-        const unsigned nb = (unsigned)std::min<size_t>(((size_t)d->N * d->C + 255) / 256, 64);
+        const unsigned nb = (unsigned)std::min<size_t>(((size_t)d->N * d->C + 255) / 256, 8);
         hipLaunchKernelGGL(mm::texmap_max_kernel, dim3(nb, d->B), dim3(256), 0, s, *d, g->grad_out, (unsigned*)g->workspace);
         hipLaunchKernelGGL(mm::texmap_bwd_kernel<true>, dim3((d->N + 255) / 256, d->B), dim3(256), 0, s, *d, *g);
         const unsigned nf = (unsigned)std::min<size_t>(((size_t)d->C * d->Ht * d->Wt + 255) / 256, 256);

@@ -45,8 +45,7 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_
     MM_TIMELINE_BEGIN();
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
     MM_PP_BEGIN();
-    const int wv = kBlock ? MM_WAVE_UNIFORM(threadIdx.x >> 6) : 0;   // (wave-uniform, said so: the tile's coordinates, its order entry and its
-                                                                                             //  mask row's address are then scalar arithmetic and scalar-cache loads)
+    const int wv = kBlock ? threadIdx.x >> 6 : 0;               // (MM_WAVE_UNIFORM here and on the order entry: 83 instead of 96 VGPRs, but 1-3 % SLOWER at every size)
     int limit = 4 * a.blocks_per_image, rank = -1;               // rank: this workgroup's index among its image's walking workgroups (-1: from blockIdx)
     if (a.order) {
         // workgroups of image b, in launch order: heavy tiles (one each), the other non-empty tiles (four each, or one), then the empty

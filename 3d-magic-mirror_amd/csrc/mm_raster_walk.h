@@ -101,7 +101,7 @@ __device__ inline TileCtx make_tile(const RasterArgs& a, int wv, int rank, bool&
         else if (j < nh) { idx = j; coop = true; }
         else idx = nh + (j - nh) * 4 + wv;
         valid = idx < limit;
-        const unsigned e = (unsigned)MM_WAVE_UNIFORM(a.order[(size_t)t.b * nslot + (valid ? idx : 0)]);
+        const unsigned e = a.order[(size_t)t.b * nslot + (valid ? idx : 0)];
         const int slot = (int)(e & 0x7FFFu);
         t.empty = (e >> 15) != 0;                                // the plan kernel counted no candidate at all for this tile
         blk = slot >> 2; t.wave = slot & 3;

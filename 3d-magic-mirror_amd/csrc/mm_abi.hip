@@ -31,6 +31,7 @@ static int check_render(const MMRenderDesc* d, bool backward) {
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->V <= 0 || d->F <= 0 || d->Ht <= 0 || d->Wt <= 0) return MM_ERR_BAD_SHAPE;
     if (d->knum <= 0) return MM_ERR_UNSUPPORTED;
     if (d->H > 65535 || d->W > 65535) return MM_ERR_UNSUPPORTED;                 // pixel boxes are packed in 16 + 16 bits
+    if (d->Ht > 8160 || d->Wt > 8160) return MM_ERR_UNSUPPORTED;                 // texture-tile boxes are packed in 8 bits per coordinate (255 tiles of 32 texels)
     if (d->geometry_only) {                                                       // vertex stage only: what it reads and writes
         if (!d->faces || !d->vertices || !d->azimuths || !d->elevations || !d->distances || !d->biases || !d->face_normals) return MM_ERR_NULL_POINTER;
     } else {
@@ -79,7 +80,7 @@ int mm_debug_workspace_layout(const MMRenderDesc* d, size_t* out5) {
     out5[0] = (size_t)((char*)w.chunkmap - (char*)nullptr); out5[1] = (size_t)((char*)w.items - (char*)nullptr);
     out5[2] = (size_t)((char*)w.nitems - (char*)nullptr); out5[3] = (size_t)((char*)w.part - (char*)nullptr); out5[4] = (size_t)w.item_cap;
     out5[5] = (size_t)((char*)w.gp - (char*)nullptr); out5[6] = (size_t)((char*)w.gp2 - (char*)nullptr); out5[7] = (size_t)((char*)w.soft - (char*)nullptr);
-    out5[8] = (size_t)((char*)w.tcnt - (char*)nullptr); out5[9] = (size_t)w.ntiles; out5[10] = (size_t)w.trcap; out5[11] = (size_t)((char*)w.trcnt - (char*)nullptr);
+    out5[8] = (size_t)((char*)w.tcnt - (char*)nullptr); out5[9] = (size_t)w.ntiles; out5[10] = (size_t)w.nst; out5[11] = (size_t)((char*)w.tbox - (char*)nullptr);
     return MM_OK;
 }
 

@@ -30,7 +30,7 @@ struct BwdArgs {
     float* dl_part;
     float* grad_bg;
     unsigned* ticket;
-    int* tcur; int* tdrop; const int* trcnt; int* toff; int* tstatus; TexRecord* trec; int ntiles_, trcap;   // texture records (Workspace)
+    TexRecord* trec; unsigned* tbox; int nst;                      // texture-gradient records per pixel, screen-tile-major; per-tile texture-tile boxes (Workspace)
     int* status_flag;                                            // MMRenderDesc.status_flag (may be pinned host memory) or nullptr
     // fused recon_data (gt == nullptr: off)
     const float* gt; const float* rgba; const float* grad_loss; float* loss; float image_weight;

@@ -170,29 +170,58 @@ __device__ inline void tex_accumulate(const BwdArgs& a, int (*s_acc)[MM_TS * MM_
 
 __device__ inline float tex_record_max(const TexRecord& rc) { return fmaxf(fmaxf(fabsf(rc.d0), fabsf(rc.d1)), fabsf(rc.d2)); }
 
-// 2a. texture gradient: one workgroup per (image, 32x32-texel tile) streams the records the pixel pass appended for the
-//     tile into LDS accumulators and writes every texel of the tile once.
+// 2a. texture gradient: one workgroup per (image, 32x32-texel tile).  Its records are those of the SCREEN tiles whose texture-tile box (left by the
+//     pixel pass) holds this tile: every wave takes 64 boxes at a time (lane = screen tile, one coalesced load), and for every hit all 64 lanes read
+//     that screen tile's 64 records (1.5 KB in a row) and keep those whose bilinear footprint really touches the tile.  Two sweeps: the largest
+//     contribution (the tile's fixed-point scale), then the accumulation into LDS -- integer adds, so neither the order of the screen tiles nor which
+//     wave takes which matters: bitwise reproducible.  Every texel of the tile is written once (no zero-fill of grad_textures).
+template <class F>
+__device__ inline void for_each_tile_record(const BwdArgs& a, int b, int ttx, int tty, int wave, int lane, F&& f) {
+    const unsigned* boxes = a.tbox + (size_t)b * a.nst;
+    const TexRecord* recs = a.trec + (size_t)b * a.nst * 64;
+    for (int s0 = wave * 64; s0 < a.nst; s0 += 256) {
+        const unsigned bx = s0 + lane < a.nst ? boxes[s0 + lane] : MM_TBOX_EMPTY;
+        const int x0 = (int)(bx & 255u), y0 = (int)((bx >> 8) & 255u), x1 = (int)((bx >> 16) & 255u), y1 = (int)(bx >> 24);
+        unsigned long long hits = __ballot(ttx >= x0 && ttx <= x1 && tty >= y0 && tty <= y1);
+        while (hits) {
+            const int j = __ffsll(hits) - 1;
+            hits &= hits - 1;
+            f(recs[(size_t)(s0 + j) * 64 + lane]);
+        }
+    }
+}
+// does the record's footprint touch the tile whose first texel is (tx0, ty0)?  (the same corner tests as tex_accumulate)
+__device__ inline bool tex_record_touches(const BwdArgs& a, const TexRecord& rc, int tx0, int ty0) {
+    if (rc.xy == MM_TREC_NONE) return false;
+    const int x0 = (int)(rc.xy & 0xFFFFu), y0 = (int)(rc.xy >> 16);
+    const int lx0 = x0 - tx0, lx1 = lx0 + 1, ly0 = y0 - ty0, ly1 = ly0 + 1;
+    const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && x0 + 1 < a.Wt;
+    const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && y0 + 1 < a.Ht;
+    return (cx0 || cx1) && (cy0 || cy1);
+}
 __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s_acc)[MM_TS * MM_TS]) {
     __shared__ float s_max[4];
+    __shared__ int s_cnt[4];
     const int ntiles = a.ntx * a.nty;
     int b, T;
     map_block(block, a.B, ntiles, b, T);
-    const int tid = threadIdx.x;
-    const int tx0 = (T % a.ntx) * MM_TS, ty0 = (T / a.ntx) * MM_TS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ttx = T % a.ntx, tty = T / a.ntx, tx0 = ttx * MM_TS, ty0 = tty * MM_TS;
     MM_PP_BEGIN();
-    const int nall = a.tcur[(size_t)b * ntiles + T], off = a.toff[(size_t)b * ntiles + T] - 1;
-    const int dropped = a.tdrop[b];                            // records of the image its array had no room for (pixel_bwd)
-    const int nrec = max(0, min(nall, a.trcap - off));           // (the list is cut where the array ends)
-    const TexRecord* recs = a.trec + (size_t)b * a.trcap + off;
     MM_PP_MARK(0);
-    // largest contribution of the tile's records (first pass; the second one below re-reads them from L2)
+    // first sweep: largest contribution and number of the tile's records
     float mx = 0.f;
-    for (int r = tid; r < nrec; r += 256) mx = fmaxf(mx, tex_record_max(recs[r]));
+    int cnt = 0;
+    for_each_tile_record(a, b, ttx, tty, wave, lane, [&](const TexRecord& rc) {
+        if (tex_record_touches(a, rc, tx0, ty0)) { mx = fmaxf(mx, tex_record_max(rc)); ++cnt; }
+    });
     mx = wave_max(mx);
-    if ((tid & 63) == 0) s_max[tid >> 6] = mx;
+    { int tot; (void)wave_prefix_excl(cnt, lane, tot); cnt = tot; }
+    if (lane == 0) { s_max[wave] = mx; s_cnt[wave] = cnt; }
     for (int i = tid; i < 3 * MM_TS * MM_TS / 4; i += 256) ((int4*)&s_acc[0][0])[i] = make_int4(0, 0, 0, 0);   // (16-byte LDS stores)
     __syncthreads();
     mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const int nrec = ((s_cnt[0] + s_cnt[1]) + s_cnt[2]) + s_cnt[3];
     MM_PP_MARK(1);
     float inv = 0.f;
     if (mx > 0.f && mx < INFINITY) {                             // workgroup-uniform; nothing to add up otherwise (about half of all tiles)
@@ -201,15 +230,10 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s
         const int k2 = min(max(30 - e, -100), 120);
         const float scale = ldexpf(1.f, k2);
         inv = ldexpf(1.f, -k2);
-        for (int r = tid; r < nrec; r += 256) tex_accumulate(a, s_acc, recs[r], tx0, ty0, scale);
+        for_each_tile_record(a, b, ttx, tty, wave, lane, [&](const TexRecord& rc) {
+            if (rc.xy != MM_TREC_NONE) tex_accumulate(a, s_acc, rc, tx0, ty0, scale);     // (the second sweep re-reads the records from L2)
+        });
         __syncthreads();
-    }
-    if (dropped != 0) {                                          // the image lost records: its texture gradient is NOT a gradient -- say so in every texel
-        inv = __builtin_nanf("");
-        if (T == 0 && tid == 0) {
-            a.tstatus[b] = dropped;
-            if (a.status_flag) __hip_atomic_fetch_add(a.status_flag, dropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the host may be polling it)
-        }
     }
     MM_PP_MARK(2);
     MM_PP_COUNT(nrec, 0);
@@ -456,7 +480,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.grad_rgba = g->grad_rgba;   // (face flags: only the compacting walk of the forward sets them)
     a.gp = w.gp; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.ticket = w.ticket;
-    a.tcur = w.tcur; a.tdrop = w.tdrop; a.trcnt = w.trcnt; a.toff = w.toff; a.tstatus = w.tstatus; a.trec = w.trec; a.ntiles_ = w.ntiles; a.trcap = w.trcap;
+    a.trec = w.trec; a.tbox = w.tbox; a.nst = w.nst;
     a.gmax = w.gmax;                                             // (B, MM_GSHARD, 8): two maxima per 32-byte sector
     a.status_flag = d->status_flag;
     a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;

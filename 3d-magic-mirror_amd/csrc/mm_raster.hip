@@ -164,7 +164,6 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H;
     a.bincount = nullptr; a.spread = 0;
     a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.fflag = w.fflag; a.gt = d->fused_gt; a.ltot = w.ltot;
-    a.trcnt = w.trcnt; a.ntx_tex = (d->Wt + MM_UV_TILE - 1) / MM_UV_TILE; a.ntiles_tex = w.ntiles;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     a.order = nullptr;

@@ -550,7 +550,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.faces = d->faces; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.cam = w.cam; a.geo = w.geo; a.face_normals = d->face_normals;
-    a.tcnt = w.tcnt; a.ntcnt = w.ntcnt + d->B + d->B * w.ntiles;   // (+ the status words and the forward's per-tile counts: cleared by the forward only)
+    a.tcnt = w.tcnt; a.ntcnt = w.ntcnt + d->B;                  // (+ the status words: cleared by the forward only)
     a.ltot = w.ltot; a.nltot = d->B * MM_LSUB * 4;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mask = d->geometry_only ? nullptr : w.binmask; a.fflag = w.fflag;      // (geometry only: nothing walks the screen bins)

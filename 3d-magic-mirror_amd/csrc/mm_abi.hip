@@ -11,6 +11,8 @@ int launch_vertex_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace
 int launch_raster_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_raster_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
 int launch_fused_loss(const MMRenderDesc*, const Workspace&, hipStream_t);
+bool step_fusable(const MMRenderDesc*, const Workspace&);
+int launch_raster_step(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
 size_t recon_workspace_bytes(const MMReconDesc*);
 int launch_recon_fwd(const MMReconDesc*, hipStream_t);
 int launch_recon_bwd(const MMReconDesc*, hipStream_t);
@@ -113,6 +115,29 @@ int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_
     if (d->no_mask && !g->grad_bg) return MM_ERR_NULL_POINTER;
     mm::clear_stale_error();
     st = mm::launch_raster_bwd(d, g, w, s);
+    if (st != MM_OK) return st;
+    return mm::launch_vertex_bwd(d, g, w, s);
+}
+
+int mm_render_step(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {
+    int st = check_render(d, true);
+    if (st != MM_OK) return st;
+    if (d->geometry_only || !d->fused_gt) return MM_ERR_UNSUPPORTED;              // the step is render + FUSED recon_data + backward
+    if (!d->rgba) return MM_ERR_NULL_POINTER;
+    if (!g || !g->grad_vertices || !g->grad_textures || !g->grad_lights || !g->grad_azimuths || !g->grad_elevations || !g->grad_distances ||
+        !g->grad_biases || (d->no_mask && !g->grad_bg))
+        return MM_ERR_NULL_POINTER;
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    mm::clear_stale_error();
+    st = mm::launch_vertex_fwd(d, w, s);
+    if (st != MM_OK) return st;
+    if (mm::step_fusable(d, w)) st = mm::launch_raster_step(d, g, w, s);            // order, walk + pixel pass + sweep plan, gather
+    else {
+        st = mm::launch_raster_fwd(d, w, s);
+        if (st != MM_OK) return st;
+        st = mm::launch_raster_bwd(d, g, w, s);
+    }
     if (st != MM_OK) return st;
     return mm::launch_vertex_bwd(d, g, w, s);
 }

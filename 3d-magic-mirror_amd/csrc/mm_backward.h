@@ -51,5 +51,7 @@ __device__ inline void wave_sync_lds() {
 
 #define MM_PLAN_WGS 4              // plan workgroups per image where faces are many (else one), see mm_pixel_bwd.hip
 int launch_pixel_bwd(const BwdArgs& a, const MMRenderDesc* d, hipStream_t s);     // mm_pixel_bwd.hip
+BwdArgs make_bwd_args(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w);                 // mm_backward.hip
+int launch_gather_bwd(const BwdArgs& a, const MMRenderDesc* d, const Workspace& w, hipStream_t s);        // mm_backward.hip
 
 }  // namespace mm

@@ -126,13 +126,26 @@ __device__ inline int compact_hits(const bool (&own)[MM_SWEEP], const bool (&opn
 // contribution is bounded by |dL/dalpha| * mult * sqrt(2 sigma' / e), sigma' = sigmainv / mult^2 (the maximum of d exp(-sigma' d^2)
 // times the constant factors of Appendix A.2).  The largest contribution is placed at 2^40: 2^22 of them fit a 63-bit sum, and
 // the unit is 2^-40 of it.
-__device__ inline float face_sum_scale(const BwdArgs& a, int b, float& inv) {
+// Fused loss: dL/dalpha of an uncovered pixel = ka * gm + kb * (1 - gm), gm = the ground-truth mask at the pixel, ka / kb from the image's loss totals
+// (Appendix A.4; the exact integer sums the raster waves left) -- formed HERE, where the totals are final, so that the pixel pass needs none of them.
+struct AlphaCoef { float ka, kb; };
+__device__ inline AlphaCoef alpha_coefficients(const BwdArgs& a, int b) {
+    float l1s, up, un;
+    loss_totals(a.ltot, b, l1s, up, un);
+    const float U = un + 1e-10f;
+    const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
+    AlphaCoef c;
+    c.ka = -gs / ((float)a.B * U); c.kb = gs * up / ((float)a.B * U * U);
+    return c;
+}
+__device__ inline float face_sum_scale(const BwdArgs& a, int b, const AlphaCoef& ac, float& inv) {
     float m2 = 0.f, m4 = 0.f;
 #pragma unroll
     for (int sh = 0; sh < MM_GSHARD; ++sh) {
         m2 = fmaxf(m2, __uint_as_float(a.gmax[((size_t)b * MM_GSHARD + sh) * 8]));
         m4 = fmaxf(m4, __uint_as_float(a.gmax[((size_t)b * MM_GSHARD + sh) * 8 + 1]));
     }
+    if (a.gt) m4 = fmaxf(fabsf(ac.ka), fabsf(ac.kb));           // gm in [0, 1]: |ka gm + kb (1 - gm)| <= max(|ka|, |kb|)
     const float sig = a.sigmainv / (a.mult * a.mult);
     const float M = fmaxf(m2, m4 * a.mult * sqrtf(2.f * sig * 0.36787944f) * 1.0001f);
     if (!(M > 0.f) || !(M < INFINITY)) { inv = 0.f; return 0.f; }
@@ -309,7 +322,7 @@ __device__ inline void item_finish(const BwdArgs& a, FaceSlot& fs, const ItemLoa
 //     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The hits of a trip are
 //     ballot-compacted over the whole wave and finished by all 64 lanes (one round of loads per trip) into the per-face
 //     fixed-point LDS sums.  This lane's face is `f` of image `b`, and its group sweeps box pixels [lo, hi) of it.
-__device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f, int lane, const FaceBox& fb, int lo, int hi, float scale MM_PP_ARG) {
+__device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f, int lane, const FaceBox& fb, int lo, int hi, float scale, const AlphaCoef& ac MM_PP_ARG) {
     const int grp = lane / MM_FL, sl = lane % MM_FL;
     const size_t hw = (size_t)a.H * a.W;
     const float s2 = a.mult * a.mult;
@@ -370,9 +383,14 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
                 ld[u].owned = (it & 0x8000u) != 0;
                 ld[u].q0 = make_float4(0.f, 0.f, 0.f, 0.f); ld[u].q1 = ld[u].q0; ld[u].sq = 0.f; ld[u].lf = 0; ld[u].q2 = 0.f;
                 if (ld[u].live) {
-                    ld[u].q2 = a.gp2[pix];
-                    if (ld[u].owned) { ld[u].q0 = a.gp[pix * 2 + 0]; ld[u].q1 = a.gp[pix * 2 + 1]; }
-                    else { const float2 sl2 = a.soft[pix]; ld[u].sq = sl2.x; ld[u].lf = __float_as_int(sl2.y); }
+                    if (ld[u].owned) { ld[u].q2 = a.gp2[pix]; ld[u].q0 = a.gp[pix * 2 + 0]; ld[u].q1 = a.gp[pix * 2 + 1]; }
+                    else {
+                        const float2 sl2 = a.soft[pix]; ld[u].sq = sl2.x; ld[u].lf = __float_as_int(sl2.y);
+                        if (a.gt) {                               // (wave-uniform) fused loss: dL/dalpha from the ground-truth mask and the image's coefficients
+                            const float gm = a.gt[((size_t)b * 4 + 3) * hw + (size_t)ld[u].py * a.W + ld[u].px];
+                            ld[u].q2 = ac.ka * gm + ac.kb * (1.f - gm);
+                        } else ld[u].q2 = a.gp2[pix];
+                    }
                 }
             }
             MM_PP_MARK(3);
@@ -415,8 +433,10 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     const int hi = live && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED)) ? min(fb.npx, lo + ni.y) : lo;
     MM_PP_BEGIN();
     float inv;
-    const float scale = face_sum_scale(a, b, inv);
-    face_sweep(a, st, b, e.x, lane, fb, lo, hi, scale MM_PP_PASS);
+    AlphaCoef ac; ac.ka = ac.kb = 0.f;
+    if (a.gt) ac = alpha_coefficients(a, b);                     // (b is scalar: scalar loads + scalar-ish arithmetic, once per wave)
+    const float scale = face_sum_scale(a, b, ac, inv);
+    face_sweep(a, st, b, e.x, lane, fb, lo, hi, scale, ac MM_PP_PASS);
     if (live) for (int k = sl; k < 9; k += MM_FL) a.part[((size_t)b * a.item_cap + item) * 12 + k] = (float)st->slot[grp].acc[k] * inv;
     MM_PP_MARK(5);
     MM_PP_FLUSH(gather_face, wid);
@@ -467,7 +487,7 @@ int launch_fused_loss(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     return launch_ok("fused_loss");
 }
 
-int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
+BwdArgs make_bwd_args(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w) {
     BwdArgs a;
     a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.Ht = d->Ht; a.Wt = d->Wt; a.knum = d->knum;
     a.blocks_x = (d->W + MM_BLOCK_PX - 1) / MM_BLOCK_PX;
@@ -489,9 +509,10 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.plan_chunkmap = w.chunkmap; a.plan_items = w.items; a.plan_nitems = w.nitems; a.plan_wgs = d->F > 4096 ? MM_PLAN_WGS : 1;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures;
-    // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)
-    launch_pixel_bwd(a, d, s);
-    if (launch_ok("pixel_bwd") != MM_OK) return MM_ERR_LAUNCH;
+    return a;
+}
+
+int launch_gather_bwd(const BwdArgs& a, const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
     {
         ProfScope p(d->prof_events, MM_PROF_GATHER_BWD, s);
         const int ntex = a.ntx * a.nty * d->B;
@@ -504,6 +525,14 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
         hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex, dbg_skip);
     }
     return launch_ok("raster_bwd");
+}
+
+int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
+    const BwdArgs a = make_bwd_args(d, g, w);
+    // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)
+    launch_pixel_bwd(a, d, s);
+    if (launch_ok("pixel_bwd") != MM_OK) return MM_ERR_LAUNCH;
+    return launch_gather_bwd(a, d, w, s);
 }
 
 }  // namespace mm

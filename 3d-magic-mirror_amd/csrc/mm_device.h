@@ -84,7 +84,7 @@ struct Workspace {
     float4* gp;            // (B,H,W,2)  covered pixels: K2 contributions of the pixel to its face {d/d(ax,ay,bx,by)} {d/d(cx,cy), d/d(nx,ny)}:
                            //            one 32-byte record = one cache line per item
     float* gp2;            // (B,H,W)    covered pixels: d/d(nz); uncovered pixels: dL/dalpha
-    float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
+    float* dl_part;        // (B,4*blocks,12) per-tile partial sums of dL/dlights (9 used), one 48-byte row per 8x8 tile slot
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
     int* nheavy;           // (B,4)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty
@@ -151,7 +151,7 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.gp = (float4*)(p + o);        o += align256((size_t)B * H * W * 2 * sizeof(float4));
     w.gp2 = (float*)(p + o);        o += align256((size_t)B * H * W * sizeof(float));
     w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
-    w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
+    w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 4 * 12 * sizeof(float));
     w.ltot = (long long*)(p + o);   o += align256((size_t)B * MM_LSUB * 4 * sizeof(long long));
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
     w.nheavy = (int*)(p + o);       o += align256((size_t)B * 4 * sizeof(int));

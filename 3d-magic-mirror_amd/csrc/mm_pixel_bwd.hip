@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     map_block(blockIdx.x - a.plan_wgs * a.B, a.B, a.blocks_per_image, b, blk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     PixelWaveOut o;
-    pixel_backward_wave<kNoMask>(a, b, blk, wave, lane, o);
+    pixel_backward_wave<kNoMask>(a, b, blk, wave, lane, MM_HF_LOAD, o);
     if (lane == 0) { s_gm[wave][0] = o.m2; s_gm[wave][1] = o.m4; }
     __syncthreads();
     if (threadIdx.x >= 64 && threadIdx.x < 66) {                 // non-negative floats order like their bit patterns: integer max, one atomic per

@@ -106,8 +106,10 @@ struct PixelWaveOut { float dl[9]; float m2, m4; };
 // alpha_from_gt (BwdArgs): fused loss only -- dL/dalpha of the uncovered pixels is NOT written (gp2) nor bounded (m4) here: the face gather forms
 // it from the ground-truth mask and the image's loss totals itself.  That keeps this pass free of the totals, which is what lets it run inside the
 // forward's walk kernel, before the totals are complete.
+// hf_in: the pixel's winning face if the caller holds it (the walk kernel, right behind its epilogue), MM_HF_LOAD: read it from face_idx
+#define MM_HF_LOAD (-2)
 template <bool kNoMask>
-__device__ inline void pixel_backward_wave(const BwdArgs& a, int b, int blk, int wave, int lane, PixelWaveOut& out) {
+__device__ inline void pixel_backward_wave(const BwdArgs& a, int b, int blk, int wave, int lane, int hf_in, PixelWaveOut& out) {
     const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
     const int px = bx * MM_BLOCK_PX + (wave & 1) * MM_TILE + (lane & 7), py = by * MM_BLOCK_PX + (wave >> 1) * MM_TILE + (lane >> 3);
     const bool in_img = px < a.W && py < a.H;
@@ -136,14 +138,14 @@ __device__ inline void pixel_backward_wave(const BwdArgs& a, int b, int blk, int
         const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
         kl1 = gs * a.image_weight / ((float)a.B * 3.f * (float)a.H * (float)a.W);
         if (in_img) {
-            hf = a.face_idx[pix];
+            hf = hf_in == MM_HF_LOAD ? a.face_idx[pix] : hf_in;
             const float* g = a.gt + (size_t)b * 4 * hw;
             const float gm = g[3 * hw + pin];
             gmv = gm;
 #pragma unroll
             for (int c = 0; c < 3; ++c) gi3[c] = g[c * hw + pin] * gm + 1.f * (1.f - gm);
         }
-    } else if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
+    } else if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = hf_in == MM_HF_LOAD ? a.face_idx[pix] : hf_in; }
     const float gin[3] = {g4.x, g4.y, g4.z};
     // dL/d(colour c of this pixel) given its un-clamped value `pre`: the caller's gradient, or the fused loss's (the forward's clamp and
     // masking expressions, shade_store / shade_empty_tiles + networks.py:370-377)

@@ -27,6 +27,7 @@ struct RasterArgs {
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     const int* nheavy;                      // (B,4) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty
     int spread;                             // sorted order: eight consecutive workgroups = eight ranks of one image (walk_image_rank); 2: the four tiles of a block on one XCD
+    int walk_groups;                        // mm_render_step: workgroups of the walk proper; the ones behind them plan the backward's face sweep
     int block_sort;                         // the order kernel sorts 16x16 blocks, a block's four tiles stay together (bins of 16 pixels or more)
     const int* bincount;                    // (B,nbins) candidates per screen bin, or nullptr (small screens: the order kernel counts the mask bits itself)
     // outputs

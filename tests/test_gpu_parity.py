@@ -716,14 +716,25 @@ def test_fused_step_matches_oracle_and_unfused(pkg, oracle, name, B, S, seed):
     plain = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in datt.items()}
     fused = stepmod.RenderLossStep(dr, plain, gt.to(dev), no_mask=True, fused=True, loss_scale=0.5)
     unfused = stepmod.RenderLossStep(dr, plain, gt.to(dev), no_mask=True, fused=False, loss_scale=0.5)
-    fused.run(); unfused.run()
+    # fused.run() is ONE call, mm_render_step (the pixel pass rides in the walk kernel: five launches); two_calls = mm_render_forward +
+    # mm_render_backward on the same fused descriptor (six launches)
+    two_calls = stepmod.RenderLossStep(dr, plain, gt.to(dev), no_mask=True, fused=True, loss_scale=0.5)
+    two_calls.one_call = False
+    fused.run(); unfused.run(); two_calls.run()
     torch.cuda.synchronize()
     loss_o, g_o = oracle.step(inp, gt.numpy(), H, W, True, proj, image_weight=dr.image_weight)
     assert abs(float(fused.loss) - loss_o) < 2e-5 and abs(float(unfused.loss) - loss_o) < 2e-5
     assert torch.equal(fused.face_idx, unfused.face_idx) and torch.equal(fused.rgba, unfused.rgba)
+    assert torch.equal(fused.face_idx, two_calls.face_idx) and torch.equal(fused.rgba, two_calls.rgba) and torch.equal(fused.loss, two_calls.loss)
     for k in LEAVES:
         _close(fused.grads[k].cpu().numpy() / 0.5, g_o[k])
         _close(unfused.grads[k].cpu().numpy() / 0.5, g_o[k])
+        _close(two_calls.grads[k].cpu().numpy() / 0.5, g_o[k])
+        _close(fused.grads[k].cpu().numpy(), two_calls.grads[k].cpu().numpy(), 1e-6)      # the same pass, run from another kernel
+    first = {k: fused.grads[k].clone() for k in LEAVES}
+    fused.run(); torch.cuda.synchronize()                          # the one-call step is bitwise reproducible too
+    for k in LEAVES:
+        assert torch.equal(fused.grads[k], first[k]), k
 
 
 def test_chamfer_matches_bruteforce(pkg):

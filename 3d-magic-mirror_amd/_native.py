@@ -124,7 +124,7 @@ OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9
 OPT_WALK_QUEUE, OPT_WALK_BATCH = 1 << 10, 1 << 11
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
-EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_render_step", "mm_render_status", "mm_render_fused_loss", "mm_debug_workspace_layout", "mm_recon_query_workspace",
+EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_render_status", "mm_render_fused_loss", "mm_debug_workspace_layout", "mm_recon_query_workspace",
            "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_vertex_corner_csr_device", "mm_build_vertex_corner_table", "mm_nearest_neighbour", "mm_chamfer_nearest", "mm_status_string", "mm_last_error_detail",
            "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward", "mm_texture_flow_forward",
            "mm_texture_flow_backward", "mm_attribute_loss_query_workspace", "mm_attribute_loss_forward",
@@ -165,7 +165,6 @@ def lib():
     L.mm_query_workspace.argtypes = [ctypes.POINTER(MMRenderDesc)]
     L.mm_render_forward.argtypes = [ctypes.POINTER(MMRenderDesc), c_p]
     L.mm_render_backward.argtypes = [ctypes.POINTER(MMRenderDesc), ctypes.POINTER(MMRenderGrads), c_p]
-    L.mm_render_step.argtypes = [ctypes.POINTER(MMRenderDesc), ctypes.POINTER(MMRenderGrads), c_p]
     L.mm_render_fused_loss.argtypes = [ctypes.POINTER(MMRenderDesc), c_p]
     L.mm_render_status.argtypes = [ctypes.POINTER(MMRenderDesc), c_p, ctypes.POINTER(ctypes.c_int32)]
     L.mm_recon_query_workspace.restype = ctypes.c_size_t

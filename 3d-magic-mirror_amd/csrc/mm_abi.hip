@@ -11,8 +11,6 @@ int launch_vertex_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace
 int launch_raster_fwd(const MMRenderDesc*, const Workspace&, hipStream_t);
 int launch_raster_bwd(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
 int launch_fused_loss(const MMRenderDesc*, const Workspace&, hipStream_t);
-bool step_fusable(const MMRenderDesc*, const Workspace&);
-int launch_raster_step(const MMRenderDesc*, const MMRenderGrads*, const Workspace&, hipStream_t);
 size_t recon_workspace_bytes(const MMReconDesc*);
 int launch_recon_fwd(const MMReconDesc*, hipStream_t);
 int launch_recon_bwd(const MMReconDesc*, hipStream_t);
@@ -33,7 +31,6 @@ static int check_render(const MMRenderDesc* d, bool backward) {
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->V <= 0 || d->F <= 0 || d->Ht <= 0 || d->Wt <= 0) return MM_ERR_BAD_SHAPE;
     if (d->knum <= 0) return MM_ERR_UNSUPPORTED;
     if (d->H > 65535 || d->W > 65535) return MM_ERR_UNSUPPORTED;                 // pixel boxes are packed in 16 + 16 bits
-    if (d->Ht > 8160 || d->Wt > 8160) return MM_ERR_UNSUPPORTED;                 // texture-tile boxes are packed in 8 bits per coordinate (255 tiles of 32 texels)
     if (d->geometry_only) {                                                       // vertex stage only: what it reads and writes
         if (!d->faces || !d->vertices || !d->azimuths || !d->elevations || !d->distances || !d->biases || !d->face_normals) return MM_ERR_NULL_POINTER;
     } else {
@@ -82,7 +79,7 @@ int mm_debug_workspace_layout(const MMRenderDesc* d, size_t* out5) {
     out5[0] = (size_t)((char*)w.chunkmap - (char*)nullptr); out5[1] = (size_t)((char*)w.items - (char*)nullptr);
     out5[2] = (size_t)((char*)w.nitems - (char*)nullptr); out5[3] = (size_t)((char*)w.part - (char*)nullptr); out5[4] = (size_t)w.item_cap;
     out5[5] = (size_t)((char*)w.gp - (char*)nullptr); out5[6] = (size_t)((char*)w.gp2 - (char*)nullptr); out5[7] = (size_t)((char*)w.soft - (char*)nullptr);
-    out5[8] = (size_t)((char*)w.tcnt - (char*)nullptr); out5[9] = (size_t)w.ntiles; out5[10] = (size_t)w.nst; out5[11] = (size_t)((char*)w.tbox - (char*)nullptr);
+    out5[8] = (size_t)((char*)w.tcnt - (char*)nullptr); out5[9] = (size_t)w.ntiles; out5[10] = (size_t)w.trcap; out5[11] = (size_t)((char*)w.trcnt - (char*)nullptr);
     return MM_OK;
 }
 
@@ -115,29 +112,6 @@ int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_
     if (d->no_mask && !g->grad_bg) return MM_ERR_NULL_POINTER;
     mm::clear_stale_error();
     st = mm::launch_raster_bwd(d, g, w, s);
-    if (st != MM_OK) return st;
-    return mm::launch_vertex_bwd(d, g, w, s);
-}
-
-int mm_render_step(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_t stream) {
-    int st = check_render(d, true);
-    if (st != MM_OK) return st;
-    if (d->geometry_only || !d->fused_gt) return MM_ERR_UNSUPPORTED;              // the step is render + FUSED recon_data + backward
-    if (!d->rgba) return MM_ERR_NULL_POINTER;
-    if (!g || !g->grad_vertices || !g->grad_textures || !g->grad_lights || !g->grad_azimuths || !g->grad_elevations || !g->grad_distances ||
-        !g->grad_biases || (d->no_mask && !g->grad_bg))
-        return MM_ERR_NULL_POINTER;
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
-    hipStream_t s = (hipStream_t)stream;
-    mm::clear_stale_error();
-    st = mm::launch_vertex_fwd(d, w, s);
-    if (st != MM_OK) return st;
-    if (mm::step_fusable(d, w)) st = mm::launch_raster_step(d, g, w, s);            // order, walk + pixel pass + sweep plan, gather
-    else {
-        st = mm::launch_raster_fwd(d, w, s);
-        if (st != MM_OK) return st;
-        st = mm::launch_raster_bwd(d, g, w, s);
-    }
     if (st != MM_OK) return st;
     return mm::launch_vertex_bwd(d, g, w, s);
 }

@@ -30,7 +30,7 @@ struct BwdArgs {
     float* dl_part;
     float* grad_bg;
     unsigned* ticket;
-    TexRecord* trec; unsigned* tbox; int nst;                      // texture-gradient records per pixel, screen-tile-major; per-tile texture-tile boxes (Workspace)
+    int* tcur; int* tdrop; const int* trcnt; int* toff; int* tstatus; TexRecord* trec; int ntiles_, trcap;   // texture records (Workspace)
     int* status_flag;                                            // MMRenderDesc.status_flag (may be pinned host memory) or nullptr
     // fused recon_data (gt == nullptr: off)
     const float* gt; const float* rgba; const float* grad_loss; float* loss; float image_weight;
@@ -51,7 +51,5 @@ __device__ inline void wave_sync_lds() {
 
 #define MM_PLAN_WGS 4              // plan workgroups per image where faces are many (else one), see mm_pixel_bwd.hip
 int launch_pixel_bwd(const BwdArgs& a, const MMRenderDesc* d, hipStream_t s);     // mm_pixel_bwd.hip
-BwdArgs make_bwd_args(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w);                 // mm_backward.hip
-int launch_gather_bwd(const BwdArgs& a, const MMRenderDesc* d, const Workspace& w, hipStream_t s);        // mm_backward.hip
 
 }  // namespace mm

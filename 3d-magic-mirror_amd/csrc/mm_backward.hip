@@ -126,26 +126,13 @@ __device__ inline int compact_hits(const bool (&own)[MM_SWEEP], const bool (&opn
 // contribution is bounded by |dL/dalpha| * mult * sqrt(2 sigma' / e), sigma' = sigmainv / mult^2 (the maximum of d exp(-sigma' d^2)
 // times the constant factors of Appendix A.2).  The largest contribution is placed at 2^40: 2^22 of them fit a 63-bit sum, and
 // the unit is 2^-40 of it.
-// Fused loss: dL/dalpha of an uncovered pixel = ka * gm + kb * (1 - gm), gm = the ground-truth mask at the pixel, ka / kb from the image's loss totals
-// (Appendix A.4; the exact integer sums the raster waves left) -- formed HERE, where the totals are final, so that the pixel pass needs none of them.
-struct AlphaCoef { float ka, kb; };
-__device__ inline AlphaCoef alpha_coefficients(const BwdArgs& a, int b) {
-    float l1s, up, un;
-    loss_totals(a.ltot, b, l1s, up, un);
-    const float U = un + 1e-10f;
-    const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
-    AlphaCoef c;
-    c.ka = -gs / ((float)a.B * U); c.kb = gs * up / ((float)a.B * U * U);
-    return c;
-}
-__device__ inline float face_sum_scale(const BwdArgs& a, int b, const AlphaCoef& ac, float& inv) {
+__device__ inline float face_sum_scale(const BwdArgs& a, int b, float& inv) {
     float m2 = 0.f, m4 = 0.f;
 #pragma unroll
     for (int sh = 0; sh < MM_GSHARD; ++sh) {
         m2 = fmaxf(m2, __uint_as_float(a.gmax[((size_t)b * MM_GSHARD + sh) * 8]));
         m4 = fmaxf(m4, __uint_as_float(a.gmax[((size_t)b * MM_GSHARD + sh) * 8 + 1]));
     }
-    if (a.gt) m4 = fmaxf(fabsf(ac.ka), fabsf(ac.kb));           // gm in [0, 1]: |ka gm + kb (1 - gm)| <= max(|ka|, |kb|)
     const float sig = a.sigmainv / (a.mult * a.mult);
     const float M = fmaxf(m2, m4 * a.mult * sqrtf(2.f * sig * 0.36787944f) * 1.0001f);
     if (!(M > 0.f) || !(M < INFINITY)) { inv = 0.f; return 0.f; }
@@ -183,58 +170,29 @@ __device__ inline void tex_accumulate(const BwdArgs& a, int (*s_acc)[MM_TS * MM_
 
 __device__ inline float tex_record_max(const TexRecord& rc) { return fmaxf(fmaxf(fabsf(rc.d0), fabsf(rc.d1)), fabsf(rc.d2)); }
 
-// 2a. texture gradient: one workgroup per (image, 32x32-texel tile).  Its records are those of the SCREEN tiles whose texture-tile box (left by the
-//     pixel pass) holds this tile: every wave takes 64 boxes at a time (lane = screen tile, one coalesced load), and for every hit all 64 lanes read
-//     that screen tile's 64 records (1.5 KB in a row) and keep those whose bilinear footprint really touches the tile.  Two sweeps: the largest
-//     contribution (the tile's fixed-point scale), then the accumulation into LDS -- integer adds, so neither the order of the screen tiles nor which
-//     wave takes which matters: bitwise reproducible.  Every texel of the tile is written once (no zero-fill of grad_textures).
-template <class F>
-__device__ inline void for_each_tile_record(const BwdArgs& a, int b, int ttx, int tty, int wave, int lane, F&& f) {
-    const unsigned* boxes = a.tbox + (size_t)b * a.nst;
-    const TexRecord* recs = a.trec + (size_t)b * a.nst * 64;
-    for (int s0 = wave * 64; s0 < a.nst; s0 += 256) {
-        const unsigned bx = s0 + lane < a.nst ? boxes[s0 + lane] : MM_TBOX_EMPTY;
-        const int x0 = (int)(bx & 255u), y0 = (int)((bx >> 8) & 255u), x1 = (int)((bx >> 16) & 255u), y1 = (int)(bx >> 24);
-        unsigned long long hits = __ballot(ttx >= x0 && ttx <= x1 && tty >= y0 && tty <= y1);
-        while (hits) {
-            const int j = __ffsll(hits) - 1;
-            hits &= hits - 1;
-            f(recs[(size_t)(s0 + j) * 64 + lane]);
-        }
-    }
-}
-// does the record's footprint touch the tile whose first texel is (tx0, ty0)?  (the same corner tests as tex_accumulate)
-__device__ inline bool tex_record_touches(const BwdArgs& a, const TexRecord& rc, int tx0, int ty0) {
-    if (rc.xy == MM_TREC_NONE) return false;
-    const int x0 = (int)(rc.xy & 0xFFFFu), y0 = (int)(rc.xy >> 16);
-    const int lx0 = x0 - tx0, lx1 = lx0 + 1, ly0 = y0 - ty0, ly1 = ly0 + 1;
-    const bool cx0 = lx0 >= 0 && lx0 < MM_TS, cx1 = lx1 >= 0 && lx1 < MM_TS && x0 + 1 < a.Wt;
-    const bool cy0 = ly0 >= 0 && ly0 < MM_TS, cy1 = ly1 >= 0 && ly1 < MM_TS && y0 + 1 < a.Ht;
-    return (cx0 || cx1) && (cy0 || cy1);
-}
+// 2a. texture gradient: one workgroup per (image, 32x32-texel tile) streams the records the pixel pass appended for the
+//     tile into LDS accumulators and writes every texel of the tile once.
 __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s_acc)[MM_TS * MM_TS]) {
     __shared__ float s_max[4];
-    __shared__ int s_cnt[4];
     const int ntiles = a.ntx * a.nty;
     int b, T;
     map_block(block, a.B, ntiles, b, T);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ttx = T % a.ntx, tty = T / a.ntx, tx0 = ttx * MM_TS, ty0 = tty * MM_TS;
+    const int tid = threadIdx.x;
+    const int tx0 = (T % a.ntx) * MM_TS, ty0 = (T / a.ntx) * MM_TS;
     MM_PP_BEGIN();
+    const int nall = a.tcur[(size_t)b * ntiles + T], off = a.toff[(size_t)b * ntiles + T] - 1;
+    const int dropped = a.tdrop[b];                            // records of the image its array had no room for (pixel_bwd)
+    const int nrec = max(0, min(nall, a.trcap - off));           // (the list is cut where the array ends)
+    const TexRecord* recs = a.trec + (size_t)b * a.trcap + off;
     MM_PP_MARK(0);
-    // first sweep: largest contribution and number of the tile's records
+    // largest contribution of the tile's records (first pass; the second one below re-reads them from L2)
     float mx = 0.f;
-    int cnt = 0;
-    for_each_tile_record(a, b, ttx, tty, wave, lane, [&](const TexRecord& rc) {
-        if (tex_record_touches(a, rc, tx0, ty0)) { mx = fmaxf(mx, tex_record_max(rc)); ++cnt; }
-    });
+    for (int r = tid; r < nrec; r += 256) mx = fmaxf(mx, tex_record_max(recs[r]));
     mx = wave_max(mx);
-    { int tot; (void)wave_prefix_excl(cnt, lane, tot); cnt = tot; }
-    if (lane == 0) { s_max[wave] = mx; s_cnt[wave] = cnt; }
+    if ((tid & 63) == 0) s_max[tid >> 6] = mx;
     for (int i = tid; i < 3 * MM_TS * MM_TS / 4; i += 256) ((int4*)&s_acc[0][0])[i] = make_int4(0, 0, 0, 0);   // (16-byte LDS stores)
     __syncthreads();
     mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-    const int nrec = ((s_cnt[0] + s_cnt[1]) + s_cnt[2]) + s_cnt[3];
     MM_PP_MARK(1);
     float inv = 0.f;
     if (mx > 0.f && mx < INFINITY) {                             // workgroup-uniform; nothing to add up otherwise (about half of all tiles)
@@ -243,10 +201,15 @@ __device__ inline void texture_gather_block(const BwdArgs& a, int block, int (*s
         const int k2 = min(max(30 - e, -100), 120);
         const float scale = ldexpf(1.f, k2);
         inv = ldexpf(1.f, -k2);
-        for_each_tile_record(a, b, ttx, tty, wave, lane, [&](const TexRecord& rc) {
-            if (rc.xy != MM_TREC_NONE) tex_accumulate(a, s_acc, rc, tx0, ty0, scale);     // (the second sweep re-reads the records from L2)
-        });
+        for (int r = tid; r < nrec; r += 256) tex_accumulate(a, s_acc, recs[r], tx0, ty0, scale);
         __syncthreads();
+    }
+    if (dropped != 0) {                                          // the image lost records: its texture gradient is NOT a gradient -- say so in every texel
+        inv = __builtin_nanf("");
+        if (T == 0 && tid == 0) {
+            a.tstatus[b] = dropped;
+            if (a.status_flag) __hip_atomic_fetch_add(a.status_flag, dropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the host may be polling it)
+        }
     }
     MM_PP_MARK(2);
     MM_PP_COUNT(nrec, 0);
@@ -322,7 +285,7 @@ __device__ inline void item_finish(const BwdArgs& a, FaceSlot& fs, const ItemLoa
 //     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The hits of a trip are
 //     ballot-compacted over the whole wave and finished by all 64 lanes (one round of loads per trip) into the per-face
 //     fixed-point LDS sums.  This lane's face is `f` of image `b`, and its group sweeps box pixels [lo, hi) of it.
-__device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f, int lane, const FaceBox& fb, int lo, int hi, float scale, const AlphaCoef& ac MM_PP_ARG) {
+__device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f, int lane, const FaceBox& fb, int lo, int hi, float scale MM_PP_ARG) {
     const int grp = lane / MM_FL, sl = lane % MM_FL;
     const size_t hw = (size_t)a.H * a.W;
     const float s2 = a.mult * a.mult;
@@ -383,14 +346,9 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
                 ld[u].owned = (it & 0x8000u) != 0;
                 ld[u].q0 = make_float4(0.f, 0.f, 0.f, 0.f); ld[u].q1 = ld[u].q0; ld[u].sq = 0.f; ld[u].lf = 0; ld[u].q2 = 0.f;
                 if (ld[u].live) {
-                    if (ld[u].owned) { ld[u].q2 = a.gp2[pix]; ld[u].q0 = a.gp[pix * 2 + 0]; ld[u].q1 = a.gp[pix * 2 + 1]; }
-                    else {
-                        const float2 sl2 = a.soft[pix]; ld[u].sq = sl2.x; ld[u].lf = __float_as_int(sl2.y);
-                        if (a.gt) {                               // (wave-uniform) fused loss: dL/dalpha from the ground-truth mask and the image's coefficients
-                            const float gm = a.gt[((size_t)b * 4 + 3) * hw + (size_t)ld[u].py * a.W + ld[u].px];
-                            ld[u].q2 = ac.ka * gm + ac.kb * (1.f - gm);
-                        } else ld[u].q2 = a.gp2[pix];
-                    }
+                    ld[u].q2 = a.gp2[pix];
+                    if (ld[u].owned) { ld[u].q0 = a.gp[pix * 2 + 0]; ld[u].q1 = a.gp[pix * 2 + 1]; }
+                    else { const float2 sl2 = a.soft[pix]; ld[u].sq = sl2.x; ld[u].lf = __float_as_int(sl2.y); }
                 }
             }
             MM_PP_MARK(3);
@@ -433,10 +391,8 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     const int hi = live && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED)) ? min(fb.npx, lo + ni.y) : lo;
     MM_PP_BEGIN();
     float inv;
-    AlphaCoef ac; ac.ka = ac.kb = 0.f;
-    if (a.gt) ac = alpha_coefficients(a, b);                     // (b is scalar: scalar loads + scalar-ish arithmetic, once per wave)
-    const float scale = face_sum_scale(a, b, ac, inv);
-    face_sweep(a, st, b, e.x, lane, fb, lo, hi, scale, ac MM_PP_PASS);
+    const float scale = face_sum_scale(a, b, inv);
+    face_sweep(a, st, b, e.x, lane, fb, lo, hi, scale MM_PP_PASS);
     if (live) for (int k = sl; k < 9; k += MM_FL) a.part[((size_t)b * a.item_cap + item) * 12 + k] = (float)st->slot[grp].acc[k] * inv;
     MM_PP_MARK(5);
     MM_PP_FLUSH(gather_face, wid);
@@ -487,7 +443,7 @@ int launch_fused_loss(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     return launch_ok("fused_loss");
 }
 
-BwdArgs make_bwd_args(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w) {
+int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
     BwdArgs a;
     a.B = d->B; a.H = d->H; a.W = d->W; a.F = d->F; a.Ht = d->Ht; a.Wt = d->Wt; a.knum = d->knum;
     a.blocks_x = (d->W + MM_BLOCK_PX - 1) / MM_BLOCK_PX;
@@ -500,7 +456,7 @@ BwdArgs make_bwd_args(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.grad_rgba = g->grad_rgba;   // (face flags: only the compacting walk of the forward sets them)
     a.gp = w.gp; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;
     a.ticket = w.ticket;
-    a.trec = w.trec; a.tbox = w.tbox; a.nst = w.nst;
+    a.tcur = w.tcur; a.tdrop = w.tdrop; a.trcnt = w.trcnt; a.toff = w.toff; a.tstatus = w.tstatus; a.trec = w.trec; a.ntiles_ = w.ntiles; a.trcap = w.trcap;
     a.gmax = w.gmax;                                             // (B, MM_GSHARD, 8): two maxima per 32-byte sector
     a.status_flag = d->status_flag;
     a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
@@ -509,10 +465,9 @@ BwdArgs make_bwd_args(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.plan_chunkmap = w.chunkmap; a.plan_items = w.items; a.plan_nitems = w.nitems; a.plan_wgs = d->F > 4096 ? MM_PLAN_WGS : 1;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;
     a.grad_textures = g->grad_textures;
-    return a;
-}
-
-int launch_gather_bwd(const BwdArgs& a, const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
+    // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)
+    launch_pixel_bwd(a, d, s);
+    if (launch_ok("pixel_bwd") != MM_OK) return MM_ERR_LAUNCH;
     {
         ProfScope p(d->prof_events, MM_PROF_GATHER_BWD, s);
         const int ntex = a.ntx * a.nty * d->B;
@@ -525,14 +480,6 @@ int launch_gather_bwd(const BwdArgs& a, const MMRenderDesc* d, const Workspace& 
         hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex, dbg_skip);
     }
     return launch_ok("raster_bwd");
-}
-
-int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
-    const BwdArgs a = make_bwd_args(d, g, w);
-    // w.tcnt is zero here: cleared by the vertex stage of the forward and again by every vertex backward (no memset launch)
-    launch_pixel_bwd(a, d, s);
-    if (launch_ok("pixel_bwd") != MM_OK) return MM_ERR_LAUNCH;
-    return launch_gather_bwd(a, d, w, s);
 }
 
 }  // namespace mm

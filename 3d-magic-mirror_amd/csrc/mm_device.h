@@ -55,11 +55,13 @@ __host__ __device__ inline int bin_shift_for(int H, int W, int F) {
     return 5;
 }
 
-// One covered pixel's contribution to the texture gradient, left by the pixel backward at the pixel's own place (screen-tile-major); the
-// workgroup of a texture tile streams the records of the screen tiles whose footprint box holds it (no lists, no atomics, nothing to overflow).
-struct TexRecord { unsigned xy; float tx, ty, d0, d1, d2; };       // xy = x0 | y0 << 16 (top-left texel); MM_TREC_NONE: the pixel has none
-#define MM_TREC_NONE 0xFFFFFFFFu
-#define MM_TBOX_EMPTY 0x0000FFFFu                                  // x0 = y0 = 255 > x1 = y1 = 0
+// One covered pixel's contribution to the texture gradient, appended by the pixel backward to the list of every texture
+// tile its bilinear footprint touches; the tile's workgroup streams its list (no search, no atomics on HBM).
+struct TexRecord { unsigned xy; float tx, ty, d0, d1, d2; };       // xy = x0 | y0 << 16 (top-left texel)
+// The lists of an image are PACKED into one array: the forward counts, per tile, the covered pixels whose footprint touches it (raster_fwd's
+// epilogue: an upper bound of the records, exact when no texture gradient is zero), every workgroup of the pixel backward turns the counts
+// into the tiles' offsets (the plan workgroup of the image: mm_pixel_bwd.hip), and a tile's records go to [offset, offset + count).  Nothing is sized per tile -- the visible
+// surface lands in a few tiles of the texture (a close-up puts four fifths of an image's records into one of 128).
 // which form of the forward walk a shape gets (mm_raster_walk.h): the compacting queue (+ the face flags the backward's sweep plan reads) for
 // screen bins larger than a tile, the per-batch walk for 8-pixel bins; MM_OPT_WALK_QUEUE / MM_OPT_WALK_BATCH force one (identical results)
 inline bool walk_queue_mode(int options, int bin_shift) {
@@ -84,7 +86,7 @@ struct Workspace {
     float4* gp;            // (B,H,W,2)  covered pixels: K2 contributions of the pixel to its face {d/d(ax,ay,bx,by)} {d/d(cx,cy), d/d(nx,ny)}:
                            //            one 32-byte record = one cache line per item
     float* gp2;            // (B,H,W)    covered pixels: d/d(nz); uncovered pixels: dL/dalpha
-    float* dl_part;        // (B,4*blocks,12) per-tile partial sums of dL/dlights (9 used), one 48-byte row per 8x8 tile slot
+    float* dl_part;        // (B,blocks,12) per-workgroup partial sums of dL/dlights (9 used)
     int blocks_per_image;
     unsigned short* order; // (B,4*blocks) raster tiles of an image, most soft-mask candidates first (launch order = heavy first)
     int* nheavy;           // (B,4)      how many of an image's first tiles (in that order) are walked by four waves together; how many are not empty
@@ -95,15 +97,17 @@ struct Workspace {
     long long* ltot;       // (B,MM_LSUB,4) fused loss: per image {sum|pi-gi|, sum p*g, sum p+g-p*g, -} in 2^-32 fixed point, spread over
                            //            MM_LSUB sub-accumulators (64-bit integer atomics of the raster waves: exact, order-free); zeroed by vertex_fwd
     int* tcnt;             // the counters of the backward, ntcnt ints in all, zeroed by the vertex stage of the forward and by every vertex backward for the
-    int ntcnt;             //            next one: gmax (below)
+    int ntcnt;             //            next one: tcur, toff, tdrop, gmax (below), in this order
+    int* tcur;             // (B,ntiles) records appended to a texture tile's list so far (pixel_bwd)
+    int* tdrop;            // (B)        records an image's array had no room for (pixel_bwd counts; the texture gather poisons the image and sets tstatus)
     unsigned* gmax;        // (B,MM_GSHARD,8) per-image maxima of the pixel backward (float bits: max |K2 number|, max |dL/dalpha|)
-    int* tstatus;          // (B)        always 0 since round 4 (nothing can overflow any more): what mm_render_status reads; zeroed by vertex_fwd
-    TexRecord* trec;       // (B,nst,64) one texture-gradient record per PIXEL, screen-tile-major (tile slot = 16x16 block * 4 + quadrant, lane = pixel of
-                           //            the 8x8 tile): written by the pixel pass for every pixel of a tile that has any (xy = ~0: none), 1.5 KB per tile
-    unsigned* tbox;        // (B,nst)    per screen tile: the range of 32x32-texel TEXTURE tiles its pixels' bilinear footprints touch, x0 | y0 << 8 |
-                           //            x1 << 16 | y1 << 24 (inclusive; MM_TBOX_EMPTY: no record).  Written for EVERY tile by every pixel pass; the texture
-                           //            gather of a texture tile reads the boxes and streams the records of the screen tiles whose box holds it
-    int nst;               //            screen tile slots per image = 4 * blocks_per_image
+    int* tstatus;          // (B)        records dropped by the last backward: zeroed by vertex_fwd, set by the texture gather, which also poisons the
+                           //            image's texture gradient with NaN (mm_render_status reads it)
+    int* trcnt;            // (B,ntiles) covered pixels whose bilinear footprint touches the tile: zeroed by vertex_fwd, counted by raster_fwd
+    int* toff;             // (B,ntiles) 1 + offset of the tile's list in the image's record array (pixel_bwd's plan workgroup of the image; 0 = not yet)
+    TexRecord* trec;       // (B,trcap)  the images' record arrays.  trcap = 9/8 H W by default -- every pixel covered and one footprint in eight across
+                           //            a tile border; a larger workspace_bytes enlarges it
+    int trcap;
     int2* chunkmap;        // (B,F)      {first sweep item, number of items} of every face (plan kernel, every forward)
     int2* items;           // (B,item_cap) sweep items {face, chunk of its box}
     int2* nitems;          // (B)        {items listed, pixels per chunk in this image (MM_CHUNK_PX << k)}
@@ -151,26 +155,35 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.gp = (float4*)(p + o);        o += align256((size_t)B * H * W * 2 * sizeof(float4));
     w.gp2 = (float*)(p + o);        o += align256((size_t)B * H * W * sizeof(float));
     w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
-    w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 4 * 12 * sizeof(float));
+    w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
     w.ltot = (long long*)(p + o);   o += align256((size_t)B * MM_LSUB * 4 * sizeof(long long));
     w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
     w.nheavy = (int*)(p + o);       o += align256((size_t)B * 4 * sizeof(int));
     w.bincount = (int*)(p + o);     o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
     w.fflag = (int*)(p + o);        o += align256((size_t)B * F * 2 * sizeof(int));   // (ints, not bytes: a byte store may alias every later load in the compiler's eyes)
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
-    w.ntcnt = (int)((size_t)B * MM_GSHARD * 8);
-    w.tcnt = (int*)(p + o);         o += align256(((size_t)w.ntcnt + B) * sizeof(int));
-    w.gmax = (unsigned*)w.tcnt;
+    const size_t ndrop = ((size_t)B * w.ntiles * 2 + B + 7) / 8 * 8 - (size_t)B * w.ntiles * 2;   // (gmax starts on a 32-byte sector)
+    w.ntcnt = (int)((size_t)B * w.ntiles * 2 + ndrop + (size_t)B * MM_GSHARD * 8);
+    w.tcnt = (int*)(p + o);         o += align256(((size_t)w.ntcnt + B + (size_t)B * w.ntiles) * sizeof(int));
+    w.tcur = w.tcnt;
+    w.toff = w.tcur + (size_t)B * w.ntiles;
+    w.tdrop = w.toff + (size_t)B * w.ntiles;
+    w.gmax = (unsigned*)(w.tdrop + ndrop);
     w.tstatus = w.tcnt + w.ntcnt;
+    w.trcnt = w.tstatus + B;
     w.item_cap = F + (int)(((size_t)16 * H * W + MM_CHUNK_PX - 1) / MM_CHUNK_PX);
     w.chunkmap = (int2*)(p + o);    o += align256((size_t)B * F * sizeof(int2));
     w.items = (int2*)(p + o);       o += align256((size_t)B * w.item_cap * sizeof(int2));
     w.nitems = (int2*)(p + o);      o += align256((size_t)B * sizeof(int2));
     w.part = (float*)(p + o);       o += align256((size_t)B * w.item_cap * 12 * sizeof(float));
-    w.nst = 4 * w.blocks_per_image;
-    w.tbox = (unsigned*)(p + o);    o += align256((size_t)B * w.nst * sizeof(unsigned));
-    w.trec = (TexRecord*)(p + o);   o += align256((size_t)B * w.nst * 64 * sizeof(TexRecord));
-    (void)avail;                                                  // (nothing is sized by the caller's generosity any more)
+    w.trec = (TexRecord*)(p + o);                                 // (last: the record arrays take what the caller gives beyond the minimum)
+    const size_t rc_min = ((size_t)H * W * 9 / 8 + 255) & ~(size_t)255;
+    size_t rc = rc_min;
+    const size_t need = o + align256((size_t)B * rc_min * sizeof(TexRecord));
+    if (avail > need) rc += (avail - need) / ((size_t)B * sizeof(TexRecord));
+    if (rc > ((size_t)1 << 30)) rc = (size_t)1 << 30;
+    w.trcap = (int)rc;
+    o += align256((size_t)B * rc_min * sizeof(TexRecord));
     w.bytes = o;
     return w;
 }

@@ -24,7 +24,6 @@
 //   * the epilogue (winner -> uv -> texels -> shade -> store) is written as TWO dependent trips to memory (mm_raster_common.h: shade_store).
 #include "mm_raster_walk.h"
 #include "mm_order.h"
-#include "mm_pixel_pass.h"
 
 MM_TIMELINE_STORAGE(raster_fwd)
 MM_PP_STORAGE(raster_fwd)       // 0 tile setup, 1 mask -> id list, 2 fetch + stage + box tests + transposes, 3 colour pairs, 4 silhouette pairs, 5 shade + store
@@ -40,32 +39,12 @@ namespace mm {
 #ifndef MM_RASTER_WPE
 #define MM_RASTER_WPE 5
 #endif
-#ifndef MM_STEP_WPE
-#define MM_STEP_WPE 5          // the walk kernel with the pixel pass behind every tile (mm_render_step): waves per SIMD its registers are held to
-#endif
-// the pixel pass of the backward for the tile this wave has just shaded (mm_render_step): the wave's largest K2 number goes to the image's sharded
-// maximum (one atomic per wave that has one), everything else is stored by pixel_backward_wave itself
-template <bool kNoMask>
-__device__ inline void step_pixel_pass(const BwdArgs& ab, int b, int blk, int quad, int lane, int hf) {
-    PixelWaveOut o;
-    pixel_backward_wave<kNoMask>(ab, b, blk, quad, lane, hf, o);
-    if (lane == 0 && o.m2 > 0.f) atomicMax(ab.gmax + ((size_t)b * MM_GSHARD + ((blk * 4 + quad) & (MM_GSHARD - 1))) * 8, __float_as_uint(o.m2));
-}
-
 // kQueue: the compacting walk (tile_walk) for screen bins larger than a tile; otherwise the per-batch walk (tile_walk_batch)
-// kStep (mm_render_step, fused loss, per-batch walk, 256-thread shape): the backward's pixel pass runs right behind every tile's epilogue (same
-// wave, operands still in the caches), and the LAST workgroups of the grid plan the face sweep -- the step has no pixel_bwd launch
-template <bool kNoMask, bool kBlock, bool kQueue, bool kStep>
-__global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_eu(kStep ? MM_STEP_WPE : MM_RASTER_WPE, kStep ? MM_STEP_WPE : MM_RASTER_WPE))) void raster_fwd_kernel(RasterArgs a, BwdArgs ab) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
+template <bool kNoMask, bool kBlock, bool kQueue>
+__global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_eu(MM_RASTER_WPE, MM_RASTER_WPE))) void raster_fwd_kernel(RasterArgs a) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
     MM_TIMELINE_BEGIN();
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
     MM_PP_BEGIN();
-    if (kStep && (int)blockIdx.x >= a.walk_groups) {             // (workgroup-uniform) the sweep plan: needs the face records only, nothing here waits for it
-        static_assert(!kStep || sizeof(WaveStage) * 4 >= MM_PLAN_LDS_BYTES, "the plan's staging overlays the candidate staging");
-        const int k = (int)blockIdx.x - a.walk_groups;
-        plan_sweep_items(ab, k / ab.plan_wgs, k % ab.plan_wgs, s_stage);
-        return;
-    }
     const int wv = kBlock ? threadIdx.x >> 6 : 0;               // (MM_WAVE_UNIFORM here and on the order entry: 83 instead of 96 VGPRs, but 1-3 % SLOWER at every size)
     int limit = 4 * a.blocks_per_image, rank = -1;               // rank: this workgroup's index among its image's walking workgroups (-1: from blockIdx)
     if (a.order) {
@@ -81,12 +60,6 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_
             if (j - W1 >= W2) return;                            //  slower at 128x128, where every walking workgroup is resident from the start)
             const int e0 = nne + (j - W1) * per + wv * 4, ne = min(4, 4 * a.blocks_per_image - e0);
             if (ne > 0) shade_empty_tiles<kNoMask>(a, b, e0, ne, threadIdx.x & 63);
-            if (kStep) {                                         // the same four tiles' pixel pass (uncovered: background gradient, light partial, empty box)
-                for (int q = 0; q < ne; ++q) {
-                    const unsigned sl = a.order[(size_t)b * 4 * a.blocks_per_image + e0 + q] & 0x7FFFu;
-                    step_pixel_pass<kNoMask>(ab, b, (int)sl >> 2, (int)sl & 3, threadIdx.x & 63, -1);
-                }
-            }
             return;
         }
         rank = j;
@@ -106,7 +79,6 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_
     }
     shade_store<kNoMask>(a, t, key, ss);
     flush_taken_last(a, t, &s_stage[(kBlock && coop) ? 0 : wv]);
-    if (kStep) step_pixel_pass<kNoMask>(ab, t.b, t.blk, t.wave, t.lane, (t.px < a.W && t.py < a.H && key != 0ull) ? depth_key_rank(key) : -1);
     MM_PP_MARK(5);
     MM_PP_FLUSH(raster_fwd, (long long)blockIdx.x * (kBlock ? 4 : 1) + wv);
     MM_TIMELINE_END(raster_fwd);
@@ -190,8 +162,9 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H;
-    a.bincount = nullptr; a.spread = 0; a.walk_groups = 0;
+    a.bincount = nullptr; a.spread = 0;
     a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.fflag = w.fflag; a.gt = d->fused_gt; a.ltot = w.ltot;
+    a.trcnt = w.trcnt; a.ntx_tex = (d->Wt + MM_UV_TILE - 1) / MM_UV_TILE; a.ntiles_tex = w.ntiles;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;
     a.order = nullptr;
@@ -227,8 +200,7 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     // 8-pixel bins: the bin is the tile, nothing to compact -> the per-batch walk, no face flags (every face gets its sweep items)
     const bool queue = walk_queue_mode(a);
     if (!queue) a.fflag = nullptr;
-    const BwdArgs nob = {};
-#define MM_LAUNCH_RASTER(NM, BL, QU) hipLaunchKernelGGL((raster_fwd_kernel<NM, BL, QU, false>), grid, dim3(BL ? 256 : 64), 0, s, a, nob)
+#define MM_LAUNCH_RASTER(NM, BL, QU) hipLaunchKernelGGL((raster_fwd_kernel<NM, BL, QU>), grid, dim3(BL ? 256 : 64), 0, s, a)
     if (block) {
         if (queue) { if (d->no_mask) MM_LAUNCH_RASTER(true, true, true); else MM_LAUNCH_RASTER(false, true, true); }
         else { if (d->no_mask) MM_LAUNCH_RASTER(true, true, false); else MM_LAUNCH_RASTER(false, true, false); }
@@ -238,40 +210,6 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     }
 #undef MM_LAUNCH_RASTER
     return launch_ok("raster_fwd");
-}
-
-// mm_render_step: can the pixel pass ride in the walk kernel?  Fused loss, per-batch walk in the 256-thread shape with a tile order (every shape of the
-// reference's templates up to 256x256); otherwise the step is forward + backward as two calls' worth of launches.
-bool step_fusable(const MMRenderDesc* d, const Workspace& w) {
-#ifdef MM_NO_STEP_FUSION
-    return false;
-#else
-    if (!d->fused_gt || d->geometry_only) return false;
-    RasterArgs a = make_raster_args(d, w);
-    const int nslot = 4 * a.blocks_per_image;
-    if (nslot > MM_ORDER_MAX_SLOTS || nslot > 0x7FFF) return false;
-    a.order = w.order;                                           // (walk_block_mode looks at "is there an order")
-    return walk_block_mode(a) && !walk_queue_mode(a);
-#endif
-}
-
-int launch_raster_step(const MMRenderDesc* d, const MMRenderGrads* g, const Workspace& w, hipStream_t s) {
-    RasterArgs a = make_raster_args(d, w);
-    a.order = launch_order(a, w.order, w.nheavy, w.bincount, d->B, d->prof_events, s);
-    a.spread = walk_spread(a);
-    a.nheavy = w.nheavy;
-    a.fflag = nullptr;
-    BwdArgs ab = make_bwd_args(d, g, w);
-    a.walk_groups = (int)walk_grid(a, true);
-    const dim3 grid((unsigned)a.walk_groups + (unsigned)(ab.plan_wgs * d->B));
-    {
-        ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
-        if (d->no_mask) hipLaunchKernelGGL((raster_fwd_kernel<true, true, false, true>), grid, dim3(256), 0, s, a, ab);
-        else hipLaunchKernelGGL((raster_fwd_kernel<false, true, false, true>), grid, dim3(256), 0, s, a, ab);
-    }
-    if (launch_ok("raster_step") != MM_OK) return MM_ERR_LAUNCH;
-    { ProfScope pp(d->prof_events, MM_PROF_PIXEL_BWD, s); }      // (an empty bracket: the slot stays readable)
-    return launch_gather_bwd(ab, d, w, s);
 }
 
 }  // namespace mm

@@ -24,10 +24,10 @@ struct RasterArgs {
     float2* soft;                           // per pixel {soft-mask product state, id of the knum-th face taken (int bits)}
     int* fflag;                             // (B,F,2) [0] set for a face that wins a pixel, [1] for one taken into an uncovered pixel's silhouette product (nullptr: not wanted)
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
+    int* trcnt; int ntx_tex, ntiles_tex;     // (B,ntiles) covered pixels per 32x32-texel tile under their bilinear footprint: sizes the backward's record lists
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     const int* nheavy;                      // (B,4) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty
     int spread;                             // sorted order: eight consecutive workgroups = eight ranks of one image (walk_image_rank); 2: the four tiles of a block on one XCD
-    int walk_groups;                        // mm_render_step: workgroups of the walk proper; the ones behind them plan the backward's face sweep
     int block_sort;                         // the order kernel sorts 16x16 blocks, a block's four tiles stay together (bins of 16 pixels or more)
     const int* bincount;                    // (B,nbins) candidates per screen bin, or nullptr (small screens: the order kernel counts the mask bits itself)
     // outputs
@@ -434,6 +434,7 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
         n0 = nn[0]; n1 = nn[1]; n2 = nn[2];
     }
     float nx = 0.f, ny = 0.f, nz = 0.f;
+    int fpx0 = -1, fpy0 = 0, fpx1 = 0, fpy1 = 0;                 // texel footprint of a covered in-image pixel (fpx0 < 0: none)
     float out[4];
     float L[9];                                                  // lights in the order of sh_bands (x, z, y): MM_OPT_SH_ORDER_XYZ pairs
 #pragma unroll                                                   // the user's lights 2 / 3 with the y / z bands instead
@@ -468,6 +469,7 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
         const Bilin s = bilin_setup(u, v, a.Ht, a.Wt);
         const bool inw = s.x0 < a.Wt && s.y0 < a.Ht, ine = s.x1 < a.Wt && s.y0 < a.Ht;
         const bool isw = s.x0 < a.Wt && s.y1 < a.Ht, ise = s.x1 < a.Wt && s.y1 < a.Ht;
+        if (h.f >= 0 && t.in_img) { fpx0 = s.x0; fpy0 = s.y0; fpx1 = s.x1; fpy1 = s.y1; }
         // ---- trip 2: twelve loads in flight together
         const int cx0 = min(max(s.x0, 0), a.Wt - 1), cx1 = min(max(s.x1, 0), a.Wt - 1);
         const int cy0 = min(max(s.y0, 0), a.Ht - 1), cy1 = min(max(s.y1, 0), a.Ht - 1);
@@ -530,6 +532,28 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
             if (up != 0.f) atomicAdd(row + 1, fixed32(up));
             if (down != 0.f) atomicAdd(row + 2, fixed32(down));
         }
+    }
+    // Last (nothing waits for these): the texture tiles under the covered pixels' bilinear footprints, one non-returning add per (wave, tile) -- the
+    // lengths (an upper bound: a pixel with no texture gradient appends nothing) of the backward's record lists, which it packs by their prefix sums.
+    // The same tiles, from the same footprint, as the pixel backward's rtile[] (mm_pixel_bwd.hip).
+    if (any && a.trcnt) {
+        const bool has = fpx0 >= 0;
+        const int tcx0 = fpx0 / MM_UV_TILE, tcy0 = fpy0 / MM_UV_TILE;
+        const int tcx1 = (fpx1 < a.Wt ? fpx1 : fpx0) / MM_UV_TILE, tcy1 = (fpy1 < a.Ht ? fpy1 : fpy0) / MM_UV_TILE;
+        auto count_corner = [&](int rt) {
+            unsigned long long pending = __ballot(rt >= 0);
+            while (pending) {
+                const int ld = __ffsll((unsigned long long)pending) - 1;
+                const int tile = __builtin_amdgcn_readlane(rt, ld);
+                const unsigned long long m = __ballot(rt == tile);
+                if (t.lane == ld) atomicAdd(a.trcnt + (size_t)t.b * a.ntiles_tex + tile, __popcll(m));
+                pending &= ~m;
+            }
+        };
+        count_corner(has ? tcy0 * a.ntx_tex + tcx0 : -1);
+        count_corner(has && tcx1 != tcx0 ? tcy0 * a.ntx_tex + tcx1 : -1);
+        count_corner(has && tcy1 != tcy0 ? tcy1 * a.ntx_tex + tcx0 : -1);
+        count_corner(has && tcx1 != tcx0 && tcy1 != tcy0 ? tcy1 * a.ntx_tex + tcx1 : -1);
     }
 }
 

@@ -131,7 +131,7 @@ struct VertexBwdArgs {
     float* dTpart;          // (B,groups,12) per-workgroup partial sums of dL/dT
     unsigned* ticket;       // (B) zeroed arrival counter
     int* tcnt; int ntcnt;   // texture-record counters, consumed by the gather before this kernel: cleared for the next backward
-    const float* dl_part;   // (B,4*blocks,12) partial dL/dlights of the pixel backward, one row per 8x8 tile slot
+    const float* dl_part;   // (B,blocks,12) partial dL/dlights of the pixel backward
     int geometry_only;      // nothing was rasterised (MMRenderDesc.geometry_only): no face has sweep items, no light gradient is written
     int blocks_per_image;
     float* grad_lights;
@@ -550,7 +550,7 @@ int launch_vertex_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     a.faces = d->faces; a.vertices = d->vertices;
     a.azim = d->azimuths; a.elev = d->elevations; a.dist = d->distances; a.bias = d->biases;
     a.T = w.T; a.cam = w.cam; a.geo = w.geo; a.face_normals = d->face_normals;
-    a.tcnt = w.tcnt; a.ntcnt = w.ntcnt + d->B;                  // (+ the status words: cleared by the forward only)
+    a.tcnt = w.tcnt; a.ntcnt = w.ntcnt + d->B + d->B * w.ntiles;   // (+ the status words and the forward's per-tile counts: cleared by the forward only)
     a.ltot = w.ltot; a.nltot = d->B * MM_LSUB * 4;
     a.bin_shift = w.bin_shift; a.nbx = w.nbx; a.nby = w.nby; a.words = w.words;
     a.mask = d->geometry_only ? nullptr : w.binmask; a.fflag = w.fflag;      // (geometry only: nothing walks the screen bins)
@@ -570,7 +570,7 @@ int launch_vertex_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.T = w.T; a.cam = w.cam; a.chunkmap = w.chunkmap; a.part = w.part; a.item_cap = w.item_cap; a.gfn = g->grad_face_normals;
     a.dTpart = w.dTpart; a.ticket = w.ticket;
     a.tcnt = w.tcnt; a.ntcnt = w.ntcnt;
-    a.dl_part = w.dl_part; a.blocks_per_image = 4 * w.blocks_per_image; a.grad_lights = g->grad_lights;   // (rows of dl_part: tile slots)
+    a.dl_part = w.dl_part; a.blocks_per_image = w.blocks_per_image; a.grad_lights = g->grad_lights;
     a.grad_vertices = g->grad_vertices;
     a.grad_azim = g->grad_azimuths; a.grad_elev = g->grad_elevations; a.grad_dist = g->grad_distances; a.grad_bias = g->grad_biases;
     a.faces = d->faces; a.geometry_only = d->geometry_only;

@@ -87,7 +87,6 @@ class RenderLossStep:
             self.d.fused_image_weight = float(dr.image_weight)
             self.d.fused_loss = N.ptr(self.loss)
             self.d.fused_grad_loss = N.ptr(self.loss_scale)
-        self.one_call = True                                     # fused: run() = mm_render_step (False: mm_render_forward + mm_render_backward)
         self.graph = None
         self.ev_render = self.ev_recon = None
 
@@ -114,13 +113,9 @@ class RenderLossStep:
             d.fused_gt = N.ptr(self.gt)
 
     def run(self, stream=None):
-        """Enqueue one full step on ``stream`` (a torch.cuda.Stream; default: the current stream).  Fused loss: ONE ABI call, mm_render_step
-        (render + recon_data + backward; the library folds the backward's pixel pass into the forward's walk kernel: five launches)."""
+        """Enqueue one full step on ``stream`` (a torch.cuda.Stream; default: the current stream)."""
         L = N.lib()
         s = ctypes.c_void_p((stream or torch.cuda.current_stream(self.dev)).cuda_stream)
-        if self.fused and self.one_call:
-            N.check(L.mm_render_step(ctypes.byref(self.d), ctypes.byref(self.g), s), "mm_render_step")
-            return
         N.check(L.mm_render_forward(ctypes.byref(self.d), s), "mm_render_forward")
         if not self.fused:
             N.check(L.mm_recon_data_forward(ctypes.byref(self.r), s), "mm_recon_data_forward")

@@ -152,13 +152,6 @@ typedef struct MMRenderGrads {
 size_t mm_query_workspace(const MMRenderDesc* desc);
 int mm_render_forward(const MMRenderDesc* desc, mm_stream_t stream);
 int mm_render_backward(const MMRenderDesc* desc, const MMRenderGrads* grads, mm_stream_t stream);
-/* render + fused recon_data + backward as ONE call: what mm_render_forward followed by mm_render_backward do for a descriptor with fused_gt set
- * (same outputs: rgba, face_idx, face_normals, imnormal, the loss value in fused_loss, every gradient of MMRenderGrads), with fused_grad_loss read
- * at launch.  Knowing that the backward follows lets the library fold the backward's pixel pass into the forward's walk kernel (operands still in
- * the caches) and plan the face sweep in the same grid: five launches per step instead of six, one pass over the screen less.  Shapes outside
- * that fast path (screen bins larger than a tile: very fine meshes / large screens) run the two calls' launches.  Same results either way to
- * rounding of the fixed-point sums' scales; bitwise reproducible run to run. */
-int mm_render_step(const MMRenderDesc* desc, const MMRenderGrads* grads, mm_stream_t stream);
 /* After mm_render_backward and before the next mm_render_forward on the same workspace: copies the per-image counts of dropped
  * texture-gradient records to dropped_host (B ints, may be NULL) and returns MM_OK if all are zero, MM_ERR_WORKSPACE otherwise
  * (a NULL desc / workspace: MM_ERR_NULL_POINTER; a bad shape, a workspace below the minimum or misaligned: MM_ERR_BAD_SHAPE).
@@ -469,7 +462,7 @@ const char* mm_last_error_detail(void);
 size_t mm_struct_size(int which);
 /* Bumped whenever a struct or the meaning of a field changes (2: op boundary added, reserved uv-tile fields and profiling slot
  * MM_PROF_BIN removed, options bits defined; 3: MMRenderDesc takes the fixed-stride vertex -> corner table instead of the CSR,
- * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, MMTexMapGrads.workspace, mm_chamfer_nearest, mm_build_vertex_corner_csr_device, mm_render_step).  Bindings must refuse a library whose
+ * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, MMTexMapGrads.workspace, mm_chamfer_nearest, mm_build_vertex_corner_csr_device).  Bindings must refuse a library whose
  * version differs from what they mirror. */
 #define MM_ABI_VERSION 4
 int mm_abi_version(void);

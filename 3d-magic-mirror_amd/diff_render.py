@@ -108,6 +108,7 @@ class _RenderFn(torch.autograd.Function):
             if gt is not None:
                 N.check(N.lib().mm_render_fused_loss(ctypes.byref(d), N.current_stream(dev)), "mm_render_fused_loss")
         ctx.dr, ctx.no_mask, ctx.fused = dr, bool(no_mask), gt is not None
+        ctx.options = int(d.options)                              # the backward uses the FORWARD's option bits (which walk form set the face flags), whatever dr.options says by then
         ctx.ws_holder = holder                                   # returned to the pool when this node dies
         ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt)
         # (the image is not saved: the backward re-forms the prediction per pixel, bit for bit, and the caller may overwrite rgba)
@@ -148,6 +149,7 @@ class _RenderFn(torch.autograd.Function):
         st = dr._static(dev)
         g_fn = None if g_fn is None else g_fn.to(torch.float32).contiguous()
         d = dr._desc(st, B, ctx.no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases, None, face_idx, fn, None)   # (rgba: not read by the backward)
+        d.options = ctx.options
         if ctx.fused:
             # None = the loss output took no part in what is being differentiated (materialize_grads is off): its gradient is ZERO,
             # never one -- e.g. reg.backward() through attributes['face_normals'] after loss.backward(retain_graph=True)

@@ -412,6 +412,32 @@ def test_graphed_step_replays_the_eager_path_bit_for_bit(pkg):
         assert torch.equal(gs.grads[k], d3[k].grad), k
 
 
+def test_large_batches_take_the_per_image_vertex_backward_and_agree_with_small_ones(pkg):
+    """B >= 128 (small templates): the vertex backward runs as one workgroup per image (vertex_image_bwd_kernel: face-major -> LDS -> vertex-major,
+    no ticket); smaller batches run the 8-lanes-per-vertex grid.  An image's gradients do not depend on the batch it is rendered in: one call of
+    136 images against the same images in two calls of 68, every input gradient to 2e-6 of its largest entry; and the large call is bitwise
+    reproducible."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "sphere", 136, 32, seed=91)
+    w = torch.linspace(-1.0, 1.0, 136 * 4 * H * W, device=dev).reshape(136, 4, H, W) * 1e-2
+    wf = torch.linspace(1.0, -1.0, 136 * dr.num_faces * 3, device=dev).reshape(136, dr.num_faces, 3) * 1e-3
+
+    def grads(sl):
+        lv = {k: datt[k].detach()[sl].clone().requires_grad_(True) for k in LEAVES}
+        a = dict(datt); a.update(lv)
+        rgbs, out = dr.render(no_mask=True, **a)
+        ((rgbs * w[sl]).sum() + (out["face_normals"] * wf[sl]).sum()).backward()
+        torch.cuda.synchronize()
+        return {k: lv[k].grad.clone() for k in LEAVES}
+    big = grads(slice(0, 136))
+    again = grads(slice(0, 136))
+    halves = [grads(slice(0, 68)), grads(slice(68, 136))]
+    for k in LEAVES:
+        assert torch.equal(big[k], again[k]), k
+        ref = torch.cat([halves[0][k], halves[1][k]], 0)
+        assert float(big[k].abs().max()) > 0
+        assert float((big[k] - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max())), (k, float((big[k] - ref).abs().max()))
+
+
 def test_geometry_only_render_is_the_render_without_the_image(pkg):
     """DiffRender.render_geometry (MMRenderDesc.geometry_only), for the call site that discards the image (trainer.py:367): face_normals
     are render's bit for bit, and the gradient a loss on them sends to vertices and camera is what the full render's backward gives when

@@ -35,6 +35,7 @@ def test_two_ranks_produce_one_aggregate_line():
     assert line["value"] > 0 and line["higher_is_better"] is True
     # whole-job aggregate: 2 ranks x 48 images per step over the max-over-ranks time
     assert abs(line["value"] - 2 * 48 / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.02
+    assert line["ranks_seen"] == 2 and line["dist_backend"] == "gloo"       # the line itself proves who took part (an all-reduced ones tensor)
     ga = line["config"]["grad_allreduce"]
     assert ga is not None and ga["every_k_steps"] >= 1
     assert line["ddp_encoder"] is not None and "error" not in line["ddp_encoder"], line["ddp_encoder"]

@@ -421,21 +421,11 @@ __global__ __launch_bounds__(256, MM_GATHER_LB) void gather_bwd_kernel(BwdArgs a
         if (threadIdx.x == 0)
             a.loss[0] = a.image_weight * (l1 / ((float)a.B * 3.f * (float)a.H * (float)a.W)) + 1.f * (1.f - iou / (float)a.B);
     }
-    // Texture tiles first, then the faces.  Measured alternatives (gather_bwd us at configs 2 / 3 / 5; this order 38.5 / 93.6 / 304): faces
+    // Texture tiles first, then the faces.  (r04, re-measured on today's kernel: the face workgroups that usually have items first, then the tiles,
+    //  then the rest of the face grid: 32.1 / 185.4 us against 29.7 / 176.6 at 128x128 B=48 / B=384.)  Measured alternatives (gather_bwd us at configs 2 / 3 / 5; this order 38.5 / 93.6 / 304): faces
     // first 35.9 / 104.4 / 293.5; the two kinds alternating 43.8 / 114.5 / 417 -- a CU that runs both code paths at once loses more than
     // the earlier start of the slowest workgroups gains.
-    // (dbg_skip & 4: faces first -- small screens, where every workgroup of the launch is resident at once and the launch lasts as long as its
-    //  longest workgroups, the face sweeps: they should not start behind a round of texture tiles)
-    if (dbg_skip & 4) {
-        // the face workgroups that usually have items (the first 5F/4 items of every image), the texture tiles, then the rest of the face grid
-        // (sized for the item cap: mostly workgroups that find nothing and exit)
-        const int nface = (int)gridDim.x - ntex;
-        const int nf1 = min(nface, (int)(((long long)a.B * ((a.F + a.F / 4 + MM_FPW - 1) / MM_FPW) + 3) / 4));
-        const int i = (int)blockIdx.x;
-        if (i < nf1) face_gather_block(a, i, s_stage);
-        else if (i < nf1 + ntex) texture_gather_block(a, i - nf1, s_acc);
-        else face_gather_block(a, i - ntex, s_stage);
-    } else if ((int)blockIdx.x < ntex) texture_gather_block(a, blockIdx.x, s_acc);
+    if ((int)blockIdx.x < ntex) texture_gather_block(a, blockIdx.x, s_acc);
     else face_gather_block(a, blockIdx.x - ntex, s_stage);
     MM_TIMELINE_END(gather_bwd);
 }
@@ -485,9 +475,6 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
         const long long nwaves = (long long)d->B * ((w.item_cap + MM_FPW - 1) / MM_FPW);   // (item octet, image), sized for the cap: waves
         const unsigned nface = (unsigned)((nwaves + 3) / 4);                                // beyond an image's item count exit at once
         int dbg_skip = 0;
-#ifndef MM_GATHER_TEX_FIRST
-        if ((long long)d->H * d->W <= 128 * 128) dbg_skip |= 4;    // faces first (r02: 35.9 against 38.5 us at 128x128, 104 against 94 at 256x256)
-#endif
 #ifdef MM_PHASE_PROF
         if (const char* e = getenv("MM_DBG_GATHER")) dbg_skip = atoi(e);
 #endif

@@ -27,6 +27,19 @@ HEADERS = ["mm_device.h", "mm_raster_common.h", "mm_raster_walk.h", "mm_backward
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
+# A TEST build of the same sources (tests/test_gpu_self_offsets.py): the backward's plan workgroups publish the texture-record list offsets
+# ~0.3 ms late and the pixel lanes give up waiting after four polls, so every lane takes the path that forms its offset from the forward's
+# counts -- the path that makes the backward's progress independent of the order workgroups are dispatched in.  Built by __graft_entry__.build(); never loaded by the product.
+TEST_LIB_SELF_OFFSETS = os.path.join(HERE, "lib", "libmm_render_test_self_offsets.so")
+TEST_FLAGS_SELF_OFFSETS = ["-DMM_DBG_LATE_TOFF", "-DMM_TOFF_SPIN_MAX=4"]
+
+
+def build_test_variants(force=False):
+    if force or not os.path.exists(TEST_LIB_SELF_OFFSETS) or os.path.getmtime(TEST_LIB_SELF_OFFSETS) < os.path.getmtime(build()):
+        build(out=TEST_LIB_SELF_OFFSETS, extra_flags=TEST_FLAGS_SELF_OFFSETS)
+    return TEST_LIB_SELF_OFFSETS
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -5,15 +5,23 @@
 // Shape of the work: B x (N + M) queries x the other cloud = 40 M distance evaluations at B=48, 642 x 642 -- vector-issue work, 1 MB of
 // data.  The kernel is laid out for the issue rate, not for memory:
 //   * BOTH directions (x -> y and y -> x) in one launch: the chamfer loss always needs both, and one launch fills the chip twice as well.
-//   * a workgroup owns 128 queries, two per lane, held as the two halves of packed-fp32 registers: v_pk_add / v_pk_mul do both queries'
-//     differences, squares and sums in one instruction each -- the same IEEE operations, in the same order, as the scalar form
-//     (dx*dx + dy*dy) + dz*dz without contraction.
-//   * the other cloud is staged once per workgroup in LDS as float4 {x, y, z, -}; every wave reads a point with ONE ds_read_b128 whose
-//     address is the same in all lanes (a broadcast), amortised over the wave's 128 evaluations.  The eight waves scan an eighth of the
-//     cloud each; their results are merged through LDS in index order.
-//   * the running minimum is kept per GROUP of four points (three v_min + one compare per four evaluations instead of a compare and two
-//     selects per evaluation); the winning group's four distances are recomputed once at the end to name the point.
-// Ties keep the lowest index (strict < in ascending order everywhere), NaN distances never win -- as before.
+//   * a workgroup owns 128 queries, two per lane, held as the two halves of packed-fp32 registers: v_pk_add / v_pk_mul / v_pk_fma do both
+//     queries' differences, squares and sums in one instruction each.
+//   * the points of the other cloud are WAVE-UNIFORM operands: every lane of a wave measures its queries against the same point at the
+//     same time.  They are therefore read by SCALAR loads (s_load_dwordx8 / x16 through the scalar cache, eight points = 24 dwords at a
+//     time, straight from the caller's packed x y z array) into SGPRs and enter the packed instructions as scalar operands: no LDS
+//     staging pass, no barrier before the scan, no LDS bandwidth in the loop (r04's first form read every point by a broadcast
+//     ds_read_b128: four of them per 32 packed instructions kept the CU's LDS port 80 % busy beside the vector ALUs).  The loads are
+//     issued a group AHEAD of their use (nn_sload / nn_swait: two sets of 24 scalar registers) -- left to the compiler every scalar
+//     load is followed by its wait, a trip to the scalar cache per group on a wave's critical path.
+//   * the eight waves of a workgroup scan an eighth of the cloud each (latency hiding needs waves, and 576 workgroups of one wave
+//     would be 0.6 waves per SIMD); their results are merged through LDS in index order.
+//   * the running minimum is kept per GROUP of eight points (four v_min3 / v_min + one compare per eight evaluations instead of a
+//     compare and two selects per evaluation); the winning group's eight distances are recomputed once at the end to name the point.
+// Distance expression: fma(dz, dz, fma(dy, dy, dx * dx)) -- the accumulation  dist += diff * diff  over the three coordinates as
+// pytorch3d's knn kernel writes it (csrc/knn/knn.cu, restated from its published source: the package is not in this image), which a
+// CUDA compiler contracts to exactly these two fused operations.  Ties keep the lowest index (strict < in ascending order everywhere),
+// NaN distances never win.
 #include <algorithm>
 #include "mm_device.h"
 
@@ -22,27 +30,42 @@ namespace mm {
 typedef float nn_f2 __attribute__((ext_vector_type(2)));
 
 #define MM_NN_Q 128          // queries per workgroup
-#define MM_NN_MAXPTS 2048    // points of the other cloud held in LDS per pass (32 KiB); larger clouds take several passes
+#ifndef MM_NN_WAVES
+#define MM_NN_WAVES 8        // waves per workgroup: each scans an eighth of the other cloud
+#endif
+#define MM_NN_GROUP 8        // points per step of the scan (24 dwords of scalar registers)
 
-__device__ inline nn_f2 nn_dist2(nn_f2 px, nn_f2 py, nn_f2 pz, const float4 q) {
-#pragma clang fp contract(off)
-    const nn_f2 dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-    return (dx * dx + dy * dy) + dz * dz;
+__device__ inline nn_f2 nn_dist2(nn_f2 px, nn_f2 py, nn_f2 pz, float qx, float qy, float qz) {
+    const nn_f2 dx = px - qx, dy = py - qy, dz = pz - qz;
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+typedef float nn_f16 __attribute__((ext_vector_type(16)));
+typedef float nn_f8 __attribute__((ext_vector_type(8)));
+// eight points = 24 dwords into scalar registers, WITHOUT waiting for them (the compiler's own scalar loads are followed by their wait at
+// once; here the next group's points travel while this group's are measured).  nn_swait is the wait, and because it names the registers
+// as in/out operands no use of them can be scheduled above it.
+__device__ inline void nn_sload(nn_f16& a, nn_f8& b, const float* p) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40" : "=&s"(a), "=&s"(b) : "s"(p));
+    __builtin_amdgcn_sched_barrier(0);                            // (the arithmetic of the group in hand stays BEHIND the request)
+}
+__device__ inline void nn_swait(nn_f16& a, nn_f8& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+
+__device__ inline float nn_min8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    return fminf(fminf(fminf(a0, a1), fminf(a2, a3)), fminf(fminf(a4, a5), fminf(a6, a7)));
 }
 
-#define MM_NN_WAVES 8        // waves per workgroup: each scans an eighth of the other cloud (more waves per SIMD: the loop is LDS-latency-bound with few)
 __global__ __launch_bounds__(64 * MM_NN_WAVES) void nn_pair_kernel(int N, int M, const float* __restrict__ x, const float* __restrict__ y,
                                                       float* __restrict__ dist_x, int32_t* __restrict__ idx_x,
                                                       float* __restrict__ dist_y, int32_t* __restrict__ idx_y, int nxq) {
-    extern __shared__ float4 s_pts[];                             // min(Mo, MM_NN_MAXPTS) points, padded to a multiple of 16
     __shared__ float s_best[MM_NN_WAVES][MM_NN_Q];
-    __shared__ int s_idx[MM_NN_WAVES][MM_NN_Q];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int s_grp[MM_NN_WAVES][MM_NN_Q];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wv = MM_WAVE_UNIFORM(tid >> 6);                     // (a scalar: the scan's loop counter, addresses and loads are the scalar unit's)
     // direction: the first nxq workgroups of a row search x's points in y, the others y's points in x
     const bool fwd = (int)blockIdx.x < nxq;
     const int Nq = fwd ? N : M, Mo = fwd ? M : N;                 // queries / points of the other cloud
-    const float* qs = (fwd ? x : y) + (size_t)b * Nq * 3;
-    const float* os = (fwd ? y : x) + (size_t)b * Mo * 3;
+    const float* __restrict__ qs = (fwd ? x : y) + (size_t)b * Nq * 3;
+    const float* __restrict__ os = (fwd ? y : x) + (size_t)b * Mo * 3;
     float* dist = fwd ? dist_x : dist_y;
     int32_t* idx = fwd ? idx_x : idx_y;
     const int q0 = ((int)blockIdx.x - (fwd ? 0 : nxq)) * MM_NN_Q;
@@ -54,64 +77,107 @@ __global__ __launch_bounds__(64 * MM_NN_WAVES) void nn_pair_kernel(int N, int M,
         if (qb < Nq) { px.y = qs[(size_t)qb * 3]; py.y = qs[(size_t)qb * 3 + 1]; pz.y = qs[(size_t)qb * 3 + 2]; }
     }
     nn_f2 best = {INFINITY, INFINITY};
-    int bga = 0, bgb = 0;                                         // winning group (absolute index of its first point / 4) of either query
-    for (int p0 = 0; p0 < Mo; p0 += MM_NN_MAXPTS) {               // (one pass for every cloud the reference has)
-        const int np = min(MM_NN_MAXPTS, Mo - p0), np16 = (np + 15) & ~15;
-        __syncthreads();
-        for (int k = tid; k < np16; k += 64 * MM_NN_WAVES) {
-            float4 v = make_float4(INFINITY, INFINITY, INFINITY, 0.f);   // padding: infinitely far, never nearer than a real point
-            if (k < np) { const float* p = os + (size_t)(p0 + k) * 3; v = make_float4(p[0], p[1], p[2], 0.f); }
-            s_pts[k] = v;
+    int bga = 0, bgb = 0;                                         // winning group (index of its first point / MM_NN_GROUP) of either query
+    // wave wv scans groups [g0, g1): its share of the cloud's groups, in ascending order.  Whole groups in the loop; the cloud's last, partial
+    // group (if any) is taken once, by the wave whose share ends with it, from clamped addresses.
+    const int ng = (Mo + MM_NN_GROUP - 1) / MM_NN_GROUP, nfull = Mo / MM_NN_GROUP;
+    const int per = (ng + MM_NN_WAVES - 1) / MM_NN_WAVES, g0 = wv * per, g1 = min(ng, g0 + per);
+    auto take = [&](const float (&q)[3 * MM_NN_GROUP], int g) {
+        nn_f2 d[MM_NN_GROUP];
+#pragma unroll
+        for (int k = 0; k < MM_NN_GROUP; ++k) d[k] = nn_dist2(px, py, pz, q[3 * k], q[3 * k + 1], q[3 * k + 2]);
+        const float ma = nn_min8(d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, d[6].x, d[7].x);
+        const float mb = nn_min8(d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, d[6].y, d[7].y);
+        if (ma < best.x) { best.x = ma; bga = g; }
+        if (mb < best.y) { best.y = mb; bgb = g; }
+    };
+    static_assert(MM_NN_GROUP == 8, "nn_min8");
+    auto load = [&](float (&q)[3 * MM_NN_GROUP], int g) {
+        const float* __restrict__ p = os + (size_t)g * (3 * MM_NN_GROUP);
+#pragma unroll
+        for (int k = 0; k < 3 * MM_NN_GROUP; ++k) q[k] = p[k];     // wave-uniform address, read-only memory: scalar loads
+    };
+    const int gend = min(g1, nfull);
+#if !defined(MM_NN_NO_PREFETCH)
+    if (g0 < gend) {
+        nn_f16 a16, b16; nn_f8 a8, b8;
+        auto take_v = [&](const nn_f16& v16, const nn_f8& v8, int g) {
+            float q[3 * MM_NN_GROUP];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) q[k] = v16[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[16 + k] = v8[k];
+            take(q, g);
+        };
+        nn_sload(a16, a8, os + (size_t)g0 * (3 * MM_NN_GROUP));
+        for (int g = g0; g < gend; g += 2) {
+            nn_swait(a16, a8);
+            nn_sload(b16, b8, os + (size_t)min(g + 1, gend - 1) * (3 * MM_NN_GROUP));
+            take_v(a16, a8, g);
+            nn_swait(b16, b8);
+            nn_sload(a16, a8, os + (size_t)min(g + 2, gend - 1) * (3 * MM_NN_GROUP));
+            if (g + 1 < gend) take_v(b16, b8, g + 1);
         }
-        __syncthreads();
-        // wave wv scans groups [g0, g1) of this pass: its share of them, in ascending order.  The next group's four points are requested from
-        // LDS before this group's arithmetic (the loop is a chain  read -> 40 instructions -> read  otherwise, with two waves per SIMD to hide it)
-        const int ng = np16 >> 2, per = (ng + MM_NN_WAVES - 1) / MM_NN_WAVES, g0 = wv * per, g1 = min(ng, g0 + per);
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-        if (g0 < g1) { a0 = s_pts[4 * g0]; a1 = s_pts[4 * g0 + 1]; a2 = s_pts[4 * g0 + 2]; a3 = s_pts[4 * g0 + 3]; }
-        for (int g = g0; g < g1; ++g) {
-            const float4 c0 = a0, c1 = a1, c2 = a2, c3 = a3;
-            const int gn = min(g + 1, g1 - 1);
-            a0 = s_pts[4 * gn]; a1 = s_pts[4 * gn + 1]; a2 = s_pts[4 * gn + 2]; a3 = s_pts[4 * gn + 3];
-            const nn_f2 d0 = nn_dist2(px, py, pz, c0), d1 = nn_dist2(px, py, pz, c1), d2 = nn_dist2(px, py, pz, c2), d3 = nn_dist2(px, py, pz, c3);
-            const float ma = fminf(fminf(d0.x, d1.x), fminf(d2.x, d3.x)), mb = fminf(fminf(d0.y, d1.y), fminf(d2.y, d3.y));
-            if (ma < best.x) { best.x = ma; bga = (p0 >> 2) + g; }
-            if (mb < best.y) { best.y = mb; bgb = (p0 >> 2) + g; }
+        nn_swait(a16, a8);                                        // (the last request lands before its registers are anything else's)
+    }
+#elif defined(MM_NN_PIPELINE)                                   // (the same in plain C++: the compiler puts every wait right behind its load -- measured equal to the loop below)
+    // two groups per trip through the loop, each one's points requested a group ahead (two sets of scalar registers)
+    if (g0 < gend) {
+        float qa[3 * MM_NN_GROUP], qb[3 * MM_NN_GROUP];
+        load(qa, g0);
+        for (int g = g0; g < gend; g += 2) {
+            load(qb, min(g + 1, gend - 1));
+            take(qa, g);
+            load(qa, min(g + 2, gend - 1));
+            if (g + 1 < gend) take(qb, g + 1);
         }
     }
-    // the winning point of either query: the first point of the winning group at the winning distance (re-read from memory: 4 points)
-    int ia = bga * 4, ib = bgb * 4;
-    {
-        float da[4], db[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ja = min(bga * 4 + k, Mo - 1), jb = min(bgb * 4 + k, Mo - 1);
-            const float* pa = os + (size_t)ja * 3; const float* pb = os + (size_t)jb * 3;
-            const nn_f2 d = nn_dist2(px, py, pz, make_float4(pa[0], pa[1], pa[2], 0.f)), e = nn_dist2(px, py, pz, make_float4(pb[0], pb[1], pb[2], 0.f));
-            da[k] = d.x; db[k] = e.y;
-        }
-        int ka = 0, kb = 0;
-#pragma unroll
-        for (int k = 3; k >= 0; --k) { if (da[k] == best.x) ka = k; if (db[k] == best.y) kb = k; }
-        ia += ka; ib += kb;
+#else
+    for (int g = g0; g < gend; ++g) {
+        float q[3 * MM_NN_GROUP];
+        load(q, g);
+        take(q, g);
     }
+#endif
+    if (g1 == ng && nfull < ng && g0 < g1) {                      // (wave-uniform) the partial group: points beyond the cloud are infinitely far
+        float q[3 * MM_NN_GROUP];
+#pragma unroll
+        for (int k = 0; k < MM_NN_GROUP; ++k) {
+            const int j = nfull * MM_NN_GROUP + k;
+            const float* __restrict__ p = os + (size_t)min(j, Mo - 1) * 3;
+            q[3 * k] = j < Mo ? p[0] : INFINITY; q[3 * k + 1] = p[1]; q[3 * k + 2] = p[2];
+        }
+        take(q, nfull);
+    }
+    // the waves' shares are merged in index order (strict <: the lowest group on ties); the winning POINT is then named once per query, by the
+    // thread that writes it: the first point of the winning group at the winning distance (the group's eight points re-read from memory and
+    // measured with the same expression)
     s_best[wv][lane] = best.x; s_best[wv][64 + lane] = best.y;
-    s_idx[wv][lane] = ia; s_idx[wv][64 + lane] = ib;
+    s_grp[wv][lane] = bga; s_grp[wv][64 + lane] = bgb;
     __syncthreads();
-    if (tid < MM_NN_Q && q0 + tid < Nq) {                         // merge the waves' shares in index order (strict <: the lowest index on ties)
-        float bb = s_best[0][tid]; int bi = s_idx[0][tid];
+    if (tid < MM_NN_Q && q0 + tid < Nq) {
+        float bb = s_best[0][tid]; int bg = s_grp[0][tid];
 #pragma unroll
-        for (int w = 1; w < MM_NN_WAVES; ++w) { const float c = s_best[w][tid]; if (c < bb) { bb = c; bi = s_idx[w][tid]; } }
-        if (!(bb < INFINITY)) bi = 0;                             // (nothing finite: index 0, as a plain scan from "best = inf, index 0" leaves it)
+        for (int w = 1; w < MM_NN_WAVES; ++w) { const float c = s_best[w][tid]; if (c < bb) { bb = c; bg = s_grp[w][tid]; } }
+        // (thread tid < 64 holds query q0 + tid in the first halves of its registers, thread 64 + l -- lane l of wave 1 -- query q0 + 64 + l in the second)
+        const nn_f2 qx = {tid < 64 ? px.x : px.y, 0.f}, qy = {tid < 64 ? py.x : py.y, 0.f}, qz = {tid < 64 ? pz.x : pz.y, 0.f};
+        int bi = 0;
+        if (bb < INFINITY) {                                      // (nothing finite: index 0, as a plain scan from "best = inf, index 0" leaves it)
+            int kk = 0;
+#pragma unroll
+            for (int k = MM_NN_GROUP - 1; k >= 0; --k) {
+                const float* pa = os + (size_t)min(bg * MM_NN_GROUP + k, Mo - 1) * 3;
+                if (nn_dist2(qx, qy, qz, pa[0], pa[1], pa[2]).x == bb) kk = k;
+            }
+            bi = bg * MM_NN_GROUP + kk;
+        }
         dist[(size_t)b * Nq + q0 + tid] = bb; idx[(size_t)b * Nq + q0 + tid] = min(bi, Mo - 1);
     }
 }
 
 static int launch_nn_pair(int B, int N, int M, const float* x, const float* y, float* dx, int32_t* ix, float* dy, int32_t* iy, bool both, hipStream_t s) {
     const int nxq = (N + MM_NN_Q - 1) / MM_NN_Q, nyq = both ? (M + MM_NN_Q - 1) / MM_NN_Q : 0;
-    const int pts = std::min(MM_NN_MAXPTS, std::max(N, M));
-    const size_t lds = (size_t)((pts + 15) & ~15) * sizeof(float4);
-    hipLaunchKernelGGL(nn_pair_kernel, dim3(nxq + nyq, B), dim3(64 * MM_NN_WAVES), lds, s, N, M, x, y, dx, ix, dy, iy, nxq);
+    hipLaunchKernelGGL(nn_pair_kernel, dim3(nxq + nyq, B), dim3(64 * MM_NN_WAVES), 0, s, N, M, x, y, dx, ix, dy, iy, nxq);
     return launch_ok("nearest_neighbour");
 }
 

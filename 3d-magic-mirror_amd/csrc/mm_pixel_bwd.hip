@@ -31,6 +31,9 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
     // starts in the image's packed array = exclusive scan of the forward's per-tile counts.  Stored + 1: the words are zero until now (cleared with
     // the backward's counters), which is how a pixel lane that got there first knows to ask again.
     if (q == 0) {
+#ifdef MM_DBG_LATE_TOFF                                         // (test builds: a plan workgroup that gets going ~0.3 ms late -- every pixel lane has given
+        for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(127);   //  up waiting by then and formed its offset itself; the texture gather still finds these)
+#endif
         const int nt = a.ntiles_, per4 = (nt + 255) >> 8, t0 = tid * per4;
         const int* cnt = a.trcnt + (size_t)b * nt;
         int mine = 0;
@@ -117,7 +120,7 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
 // 1. pixel-major pass
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef MM_TOFF_SPIN_MAX
-#define MM_TOFF_SPIN_MAX (1 << 17)   // polls of a tile's list offset before the group gives up (each a trip to memory: ~0.1 s in all)
+#define MM_TOFF_SPIN_MAX (1 << 12)   // polls of a tile's list offset (each a trip to memory: a few ms in all) before the lane forms the offset itself
 #endif
 #ifndef MM_PIXEL_LB
 #define MM_PIXEL_LB 5             // waves per SIMD the register allocation is held to: 96 VGPRs without spills (the light gradients are carried as scalar + normal, not
@@ -380,12 +383,18 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     for (int c = 0; c < 4; ++c) {
         if (!any_covered) break;
         // (the image's plan workgroup has a LOWER workgroup index and writes the offsets first thing: it is in flight before this wave exists,
-        //  and the wait below is the first microseconds of a launch.  It is nevertheless BOUNDED: should the offsets never arrive -- a
-        //  dispatcher that does not start workgroups in index order -- the group's records are counted as dropped, the image's texture
-        //  gradient is poisoned and mm_render_status reports it, instead of a hang.)
+        //  and the wait below is the first microseconds of a launch.  Progress does NOT depend on that order: the offset is a pure function of
+        //  the forward's per-tile counts, which are complete before this launch -- should it not arrive within the bound (a dispatcher that
+        //  does not start workgroups in index order, CU masking, a debugger), the lane adds the counts up itself: the same number, later.)
         int spins = 0;
         while (__builtin_expect(leader[c] == lane && toff[c] == 0, 0)) {
-            if (++spins > MM_TOFF_SPIN_MAX) break;
+            if (++spins > MM_TOFF_SPIN_MAX) {
+                const int* cnt = a.trcnt + (size_t)b * a.ntiles_;
+                int run = 1;                                     // (stored + 1, as the plan workgroup stores it)
+                for (int t = 0; t < rtile[c]; ++t) run += cnt[t];
+                toff[c] = run;
+                break;
+            }
             __builtin_amdgcn_s_sleep(2);
             toff[c] = __hip_atomic_load(a.toff + (size_t)b * a.ntiles_ + rtile[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -26,7 +26,7 @@ class MMRenderDesc(ctypes.Structure):
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
                 ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p),
                 ("fused_gt", c_p), ("fused_image_weight", c_f), ("fused_loss", c_p), ("fused_grad_loss", c_p),
-                ("options", c_i), ("geometry_only", c_i), ("status_flag", c_p)]
+                ("options", c_i), ("geometry_only", c_i), ("status_flag", c_p), ("fused_contour", c_f)]
 
 
 class MMRenderGrads(ctypes.Structure):
@@ -117,7 +117,7 @@ class MMMaskIouDesc(ctypes.Structure):
 
 
 PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "order")
-ABI_VERSION = 4
+ABI_VERSION = 5
 OPT_WALK_BLOCK, OPT_WALK_WAVE = 1 << 1, 1 << 2
 OPT_CULL_STRICT, OPT_SOFT_SKIP_CULLED, OPT_BBOX_HALF_OPEN, OPT_BARY_ONE_MINUS, OPT_SH_ORDER_XYZ = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9

@@ -40,6 +40,10 @@ static int check_render(const MMRenderDesc* d, bool backward) {
         if (!backward && !d->rgba) return MM_ERR_NULL_POINTER;                    // (the backward never reads the image: rgba may be NULL there)
         if (d->no_mask && !d->bg) return MM_ERR_NULL_POINTER;
     }
+    if (d->fused_gt && !d->geometry_only) {                                       // the contour term of the fused loss (include/mm_render.h)
+        if (!(d->fused_contour >= 0.f)) return MM_ERR_BAD_SHAPE;
+        if (d->fused_contour > 0.f && ((d->H & 3) || (d->W & 3))) return MM_ERR_BAD_SHAPE;
+    }
     if (backward && !d->vc_table) return MM_ERR_NULL_POINTER;
     if (backward && d->vc_stride <= 0) return MM_ERR_BAD_SHAPE;
     if (!d->workspace || d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_WORKSPACE;

@@ -33,7 +33,7 @@ struct BwdArgs {
     int* tcur; int* tdrop; const int* trcnt; int* toff; int* tstatus; TexRecord* trec; int ntiles_, trcap;   // texture records (Workspace)
     int* status_flag;                                            // MMRenderDesc.status_flag (may be pinned host memory) or nullptr
     // fused recon_data (gt == nullptr: off)
-    const float* gt; const float* rgba; const float* grad_loss; float* loss; float image_weight;
+    const float* gt; const float* rgba; const float* grad_loss; float* loss; float image_weight, contour;
     const long long* ltot;                                       // (B,MM_LSUB,4) fused loss sums of the raster waves (fixed point)
     // gather
     unsigned* gmax;                                              // (B,2) per image: max |K2 number| and max |dL/dalpha| as float bits (pixel pass -> gather)

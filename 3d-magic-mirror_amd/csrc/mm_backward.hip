@@ -398,6 +398,21 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     MM_PP_FLUSH(gather_face, wid);
 }
 
+// (this wave's part of the value; networks.py:376-389: image_weight * loss_image + 1 * (loss_mask + contour * loss_contour))
+__device__ inline float fused_loss_value(const long long* ltot, int B, int H, int W, float image_weight, float contour, int lane) {
+    float l1 = 0.f, iou = 0.f, cs = 0.f;
+    for (int bb = lane; bb < B; bb += 64) {
+        float s0, s1, s2;
+        loss_totals(ltot, bb, s0, s1, s2);
+        l1 += s0; iou += s1 / (s2 + 1e-10f);
+        if (contour > 0.f) cs += loss_contour_total(ltot, bb);
+    }
+    l1 = wave_sum(l1); iou = wave_sum(iou);
+    float loss_mask = 1.f - iou / (float)B;
+    if (contour > 0.f) loss_mask += (wave_sum(cs) / ((float)B * (float)H * (float)W)) * contour;
+    return image_weight * (l1 / ((float)B * 3.f * (float)H * (float)W)) + 1.f * loss_mask;
+}
+
 // One launch for both gathers: they only depend on the pixel pass, and each is latency-bound with a long tail, so their
 // workgroups are interleaved in a single grid (texture tiles first: they are the heavier ones).
 #ifndef MM_GATHER_LB
@@ -415,11 +430,8 @@ __global__ __launch_bounds__(256, MM_GATHER_LB) void gather_bwd_kernel(BwdArgs a
     int (*s_acc)[MM_TS * MM_TS] = reinterpret_cast<int (*)[MM_TS * MM_TS]>(s_raw);
     SweepStage* s_stage = reinterpret_cast<SweepStage*>(s_raw);
     if (a.gt && a.loss && blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {  // fused recon_data value: fixed-order sum over images
-        float l1 = 0.f, iou = 0.f;
-        for (int bb = threadIdx.x; bb < a.B; bb += 64) { float s0, s1, s2; loss_totals(a.ltot, bb, s0, s1, s2); l1 += s0; iou += s1 / (s2 + 1e-10f); }
-        l1 = wave_sum(l1); iou = wave_sum(iou);
-        if (threadIdx.x == 0)
-            a.loss[0] = a.image_weight * (l1 / ((float)a.B * 3.f * (float)a.H * (float)a.W)) + 1.f * (1.f - iou / (float)a.B);
+        const float v = fused_loss_value(a.ltot, a.B, a.H, a.W, a.image_weight, a.contour, threadIdx.x);
+        if (threadIdx.x == 0) a.loss[0] = v;
     }
     // Texture tiles first, then the faces.  (r04, re-measured on today's kernel: the face workgroups that usually have items first, then the tiles,
     //  then the rest of the face grid: 32.1 / 185.4 us against 29.7 / 176.6 at 128x128 B=48 / B=384.)  Measured alternatives (gather_bwd us at configs 2 / 3 / 5; this order 38.5 / 93.6 / 304): faces
@@ -432,15 +444,13 @@ __global__ __launch_bounds__(256, MM_GATHER_LB) void gather_bwd_kernel(BwdArgs a
 
 // the fused recon_data value on its own (mm_render_fused_loss): the same fixed-order sum over images the gather kernel's last
 // workgroup performs, for callers that need the loss before the backward
-__global__ __launch_bounds__(64) void fused_loss_kernel(const long long* ltot, int B, int H, int W, float image_weight, float* loss) {
-    float l1 = 0.f, iou = 0.f;
-    for (int bb = threadIdx.x; bb < B; bb += 64) { float s0, s1, s2; loss_totals(ltot, bb, s0, s1, s2); l1 += s0; iou += s1 / (s2 + 1e-10f); }
-    l1 = wave_sum(l1); iou = wave_sum(iou);
-    if (threadIdx.x == 0) loss[0] = image_weight * (l1 / ((float)B * 3.f * (float)H * (float)W)) + 1.f * (1.f - iou / (float)B);
+__global__ __launch_bounds__(64) void fused_loss_kernel(const long long* ltot, int B, int H, int W, float image_weight, float contour, float* loss) {
+    const float v = fused_loss_value(ltot, B, H, W, image_weight, contour, threadIdx.x);
+    if (threadIdx.x == 0) loss[0] = v;
 }
 
 int launch_fused_loss(const MMRenderDesc* d, const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(fused_loss_kernel, dim3(1), dim3(64), 0, s, w.ltot, d->B, d->H, d->W, d->fused_image_weight, d->fused_loss);
+    hipLaunchKernelGGL(fused_loss_kernel, dim3(1), dim3(64), 0, s, w.ltot, d->B, d->H, d->W, d->fused_image_weight, d->fused_contour, d->fused_loss);
     return launch_ok("fused_loss");
 }
 
@@ -461,7 +471,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.gmax = w.gmax;                                             // (B, MM_GSHARD, 8): two maxima per 32-byte sector
     a.status_flag = d->status_flag;
     a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
-    a.image_weight = d->fused_image_weight; a.ltot = w.ltot;
+    a.image_weight = d->fused_image_weight; a.contour = d->fused_gt ? d->fused_contour : 0.f; a.ltot = w.ltot;
     a.items = w.items; a.nitems = w.nitems; a.part = w.part; a.item_cap = w.item_cap;
     a.plan_chunkmap = w.chunkmap; a.plan_items = w.items; a.plan_nitems = w.nitems; a.plan_wgs = d->F > 4096 ? MM_PLAN_WGS : 1;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;

@@ -630,6 +630,14 @@ __device__ inline void loss_totals(const long long* ltot, int b, float& l1, floa
     l1 = (float)s0 * (1.f / 4294967296.f); up = (float)s1 * (1.f / 4294967296.f); un = (float)s2 * (1.f / 4294967296.f);   // one rounding each
 }
 
+// ... and the fourth: the contour term's sum of squares (MMRenderDesc.fused_contour > 0; zero otherwise)
+__device__ inline float loss_contour_total(const long long* ltot, int b) {
+    long long s3 = 0;
+#pragma unroll
+    for (int k = 0; k < MM_LSUB; ++k) s3 += ltot[((size_t)b * MM_LSUB + k) * 4 + 3];
+    return (float)s3 * (1.f / 4294967296.f);
+}
+
 // Wave-wide sum / max, the result in every lane.  Four DPP steps (VALU cross-lane operands: no LDS crossbar traffic, no
 // ds_bpermute latency chain) leave every 16-lane row holding its own total; the four row totals are read as scalars.  Fixed order.
 template <int CTRL>

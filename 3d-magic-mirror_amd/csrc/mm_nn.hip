@@ -92,11 +92,6 @@ __global__ __launch_bounds__(64 * MM_NN_WAVES) void nn_pair_kernel(int N, int M,
         if (mb < best.y) { best.y = mb; bgb = g; }
     };
     static_assert(MM_NN_GROUP == 8, "nn_min8");
-    auto load = [&](float (&q)[3 * MM_NN_GROUP], int g) {
-        const float* __restrict__ p = os + (size_t)g * (3 * MM_NN_GROUP);
-#pragma unroll
-        for (int k = 0; k < 3 * MM_NN_GROUP; ++k) q[k] = p[k];     // wave-uniform address, read-only memory: scalar loads
-    };
     const int gend = min(g1, nfull);
 #if !defined(MM_NN_NO_PREFETCH)
     if (g0 < gend) {
@@ -120,22 +115,12 @@ __global__ __launch_bounds__(64 * MM_NN_WAVES) void nn_pair_kernel(int N, int M,
         }
         nn_swait(a16, a8);                                        // (the last request lands before its registers are anything else's)
     }
-#elif defined(MM_NN_PIPELINE)                                   // (the same in plain C++: the compiler puts every wait right behind its load -- measured equal to the loop below)
-    // two groups per trip through the loop, each one's points requested a group ahead (two sets of scalar registers)
-    if (g0 < gend) {
-        float qa[3 * MM_NN_GROUP], qb[3 * MM_NN_GROUP];
-        load(qa, g0);
-        for (int g = g0; g < gend; g += 2) {
-            load(qb, min(g + 1, gend - 1));
-            take(qa, g);
-            load(qa, min(g + 2, gend - 1));
-            if (g + 1 < gend) take(qb, g + 1);
-        }
-    }
-#else
-    for (int g = g0; g < gend; ++g) {
+#else                                                            // plain C++ (the compiler's scalar loads, each followed by its wait): B=48 642x642 one direction
+    for (int g = g0; g < gend; ++g) {                            // 8.1 us against 6.6 (a hand-pipelined plain-C++ loop compiles to the same waits)
         float q[3 * MM_NN_GROUP];
-        load(q, g);
+        const float* __restrict__ p = os + (size_t)g * (3 * MM_NN_GROUP);
+#pragma unroll
+        for (int k = 0; k < 3 * MM_NN_GROUP; ++k) q[k] = p[k];     // wave-uniform address, read-only memory: scalar loads
         take(q, g);
     }
 #endif

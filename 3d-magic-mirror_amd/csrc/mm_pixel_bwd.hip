@@ -176,6 +176,24 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
             for (int c = 0; c < 3; ++c) gi3[c] = g[c * hw + pin] * gm + 1.f * (1.f - gm);
             g4.w = ka * gm + kb * (1.f - gm);
         }
+        if (a.contour > 0.f) {                                   // (wave-uniform) the contour term, networks.py:379-388 (forward: contour_term, mm_raster_common.h)
+            // d/dalpha of  kc * sum_p (|alpha_p - alpha_s(p)| - |gm_p - gm_s(p)|)^2,  s(p) = top-left pixel of p's 4x4 block = lane (lane & 0x24) of this
+            // wave: pixel p gets +g_p, its block's corner pixel -sum of the block's g (its own g is 0: |0| has gradient 0, as torch.abs has).
+            // alpha is re-formed from the saved soft-mask state exactly as shade_store formed it: covered 1, else 1 - keepprod.
+            const float kc = gs * a.contour / ((float)a.B * (float)a.H * (float)a.W);
+            float al = 0.f;
+            if (in_img) { const float sx = a.soft[pix].x; al = hf >= 0 ? 1.f : 1.f - (sx > 0.f ? sx : 0.f); }
+            const int src = lane & 0x24;
+            const float as = __shfl(al, src, 64), gms = __shfl(gmv, src, 64);
+            float gc = 0.f;
+            if (in_img) {
+                const float dd = al - as, cp = fabsf(dd), cg = fabsf(gmv - gms);
+                gc = (kc * 2.f * (cp - cg)) * (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f));
+            }
+            float bs = gc;                                       // the 4x4 block's sum, fixed order: columns (lane bits 0, 1), then rows (bits 3, 4)
+            bs += __shfl_xor(bs, 1, 64); bs += __shfl_xor(bs, 2, 64); bs += __shfl_xor(bs, 8, 64); bs += __shfl_xor(bs, 16, 64);
+            if (in_img) g4.w += lane == src ? -bs : gc;
+        }
     } else if (in_img) { g4 = *(const float4*)(a.grad_rgba + pix * 4); hf = a.face_idx[pix]; }
     const float gin[3] = {g4.x, g4.y, g4.z};
     // dL/d(colour c of this pixel) given its un-clamped value `pre`: the caller's gradient, or the fused loss's (the forward's clamp and

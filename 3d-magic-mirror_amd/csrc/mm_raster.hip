@@ -163,7 +163,7 @@ RasterArgs make_raster_args(const MMRenderDesc* d, const Workspace& w) {
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H;
     a.bincount = nullptr; a.spread = 0;
-    a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.fflag = w.fflag; a.gt = d->fused_gt; a.ltot = w.ltot;
+    a.geo = w.geo; a.binmask = w.binmask; a.soft = w.soft; a.fflag = w.fflag; a.gt = d->fused_gt; a.ltot = w.ltot; a.contour = d->fused_gt ? d->fused_contour : 0.f;
     a.trcnt = w.trcnt; a.ntx_tex = (d->Wt + MM_UV_TILE - 1) / MM_UV_TILE; a.ntiles_tex = w.ntiles;
     a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
     a.rgba = d->rgba; a.face_idx = d->face_idx; a.imnormal = d->imnormal;

@@ -24,6 +24,7 @@ struct RasterArgs {
     float2* soft;                           // per pixel {soft-mask product state, id of the knum-th face taken (int bits)}
     int* fflag;                             // (B,F,2) [0] set for a face that wins a pixel, [1] for one taken into an uncovered pixel's silhouette product (nullptr: not wanted)
     const float* gt; long long* ltot;        // fused recon_data sums (gt == nullptr: off)
+    float contour;                           // ... its contour weight (0: no contour term; > 0: H and W are multiples of 4)
     int* trcnt; int ntx_tex, ntiles_tex;     // (B,ntiles) covered pixels per 32x32-texel tile under their bilinear footprint: sizes the backward's record lists
     const unsigned short* order;            // (B, 4*blocks) tile slots, heavy first; nullptr: natural order
     const int* nheavy;                      // (B,4) plan kernel: how many of an image's first tiles are walked cooperatively; how many tiles are not empty
@@ -393,6 +394,19 @@ __device__ inline unsigned long long fixed32(float x) {
 
 struct SoftState { float qnz; int zeros, lastf; };
 
+// recon_data's contour term of one pixel (networks.py:379-387): contour(m) = |m - up4(down4(m))| for the rendered and the ground-truth mask,
+// term = (contour(pred) - contour(gt))^2.  The two nearest-neighbour resamplings of F.interpolate pick, for H and W multiples of 4, the
+// top-left pixel of the pixel's 4x4 block (index 4 * (y >> 2): down4 takes row floor(j * 4.0) = 4 j, up4 takes floor(y * 0.25) = y >> 2, both
+// exact in torch's float arithmetic) -- a pixel of the same 8x8 tile, i.e. lane (lane & 0x24) of this wave (lane = 8 * row + column).
+// Every lane of the wave must call.
+__device__ inline float contour_term(float alpha, float gm, bool in_img, int lane) {
+    const int src = lane & 0x24;
+    const float as = __shfl(alpha, src, 64), gs = __shfl(gm, src, 64);
+    if (!in_img) return 0.f;
+    const float cp = fabsf(alpha - as), cg = fabsf(gm - gs);
+    return (cp - cg) * (cp - cg);
+}
+
 // ---- shading (a9-a11), stores, fused recon_data partial sums.  Uncovered pixels carry zero features exactly like kaolin's
 // interpolated_features.  key = the pixel's depth key after the walk (0: uncovered).
 // (lanes outside a ragged image only stay for the fused loss reduction: they address a clamped pixel and store nothing)
@@ -514,7 +528,7 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
         if (a.imnormal) { a.imnormal[pix * 3] = nx; a.imnormal[pix * 3 + 1] = ny; a.imnormal[pix * 3 + 2] = nz; }
     }
     if (a.gt) {                                                  // recon_data terms of this tile (networks.py:370-377)
-        float l1 = 0.f, up = 0.f, down = 0.f;
+        float l1 = 0.f, up = 0.f, down = 0.f, cs = 0.f;
         if (t.in_img) {
             const float gm = gtv[3];
 #pragma unroll
@@ -525,12 +539,15 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
             }
             up = out[3] * gm; down = (out[3] + gm) - up;
         }
+        if (a.contour > 0.f) cs = contour_term(out[3], gtv[3], t.in_img, t.lane);   // (wave-uniform branch: every lane takes part in the exchange)
         l1 = wave_sum(l1); up = wave_sum(up); down = wave_sum(down);
+        if (a.contour > 0.f) cs = wave_sum(cs);
         if (t.lane == 0) {                                       // exact in 2^-32 fixed point; integer adds commute: deterministic totals
             unsigned long long* row = (unsigned long long*)(a.ltot + ((size_t)t.b * MM_LSUB + ((t.blk * 4 + t.wave) & (MM_LSUB - 1))) * 4);
             atomicAdd(row + 0, fixed32(l1));
             if (up != 0.f) atomicAdd(row + 1, fixed32(up));
             if (down != 0.f) atomicAdd(row + 2, fixed32(down));
+            if (cs != 0.f) atomicAdd(row + 3, fixed32(cs));
         }
     }
     // Last (nothing waits for these): the texture tiles under the covered pixels' bilinear footprints, one non-returning add per (wave, tile) -- the
@@ -584,9 +601,10 @@ __device__ inline void shade_empty_tiles(const RasterArgs& a, int b, int e0, int
 #pragma unroll
         for (int c = 0; c < 4; ++c) gtv[q][c] = a.gt ? a.gt[((size_t)b * 4 + c) * hw + pin[q]] : 0.f;
     }
-    float l1 = 0.f, down = 0.f;
+    float l1 = 0.f, down = 0.f, cs = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        if (a.gt && a.contour > 0.f) cs += contour_term(0.f, gtv[q][3], in[q], lane);   // (alpha = 0 everywhere here: the ground truth's contour alone)
         float out[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -612,10 +630,12 @@ __device__ inline void shade_empty_tiles(const RasterArgs& a, int b, int e0, int
     }
     if (a.gt) {
         l1 = wave_sum(l1); down = wave_sum(down);
+        if (a.contour > 0.f) cs = wave_sum(cs);
         if (lane == 0) {
             unsigned long long* row = (unsigned long long*)(a.ltot + ((size_t)b * MM_LSUB + (sl[0] & (MM_LSUB - 1))) * 4);
             if (l1 != 0.f) atomicAdd(row + 0, fixed32(l1));
             if (down != 0.f) atomicAdd(row + 2, fixed32(down));
+            if (cs != 0.f) atomicAdd(row + 3, fixed32(cs));
         }
     }
 }

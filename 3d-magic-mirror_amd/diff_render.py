@@ -68,7 +68,7 @@ class _RenderFn(torch.autograd.Function):
     fifth output; the image is then an output without gradient (its only consumer, the loss, is already inside)."""
 
     @staticmethod
-    def forward(ctx, dr, no_mask, want_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases):
+    def forward(ctx, dr, no_mask, want_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases, contour=0.0):
         dev, B, H, W, vertices, textures, lights, bg, azimuths, elevations, distances, biases = _render_inputs(
             dr, no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases)
         st = dr._static(dev)
@@ -99,6 +99,7 @@ class _RenderFn(torch.autograd.Function):
                 raise RuntimeError("gt_data must be (B,4,%d,%d), got %s" % (H, W, tuple(gt.shape)))
             loss = torch.empty((), device=dev, dtype=torch.float32)
             d.fused_gt, d.fused_image_weight, d.fused_loss = N.ptr(gt), float(dr.image_weight), N.ptr(loss)
+            d.fused_contour = float(contour)
         nbytes = dr.workspace_bytes(d)
         holder = _PooledWorkspace(dr._ws_pool, (str(dev), nbytes), nbytes, dev)
         ws = holder.buf
@@ -107,7 +108,7 @@ class _RenderFn(torch.autograd.Function):
             N.check(N.lib().mm_render_forward(ctypes.byref(d), N.current_stream(dev)), "mm_render_forward")
             if gt is not None:
                 N.check(N.lib().mm_render_fused_loss(ctypes.byref(d), N.current_stream(dev)), "mm_render_fused_loss")
-        ctx.dr, ctx.no_mask, ctx.fused = dr, bool(no_mask), gt is not None
+        ctx.dr, ctx.no_mask, ctx.fused, ctx.contour = dr, bool(no_mask), gt is not None, float(contour)
         ctx.options = int(d.options)                              # the backward uses the FORWARD's option bits (which walk form set the face flags), whatever dr.options says by then
         ctx.ws_holder = holder                                   # returned to the pool when this node dies
         ctx.save_for_backward(vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt)
@@ -127,7 +128,7 @@ class _RenderFn(torch.autograd.Function):
         if ctx.geometry:                                         # (g_rgba is dL/dface_normals here: the node's only output)
             vertices, textures, azimuths, elevations, distances, biases = ctx.saved_tensors
             if g_rgba is None:
-                return (None,) * 12
+                return (None,) * 13
             dr, dev, B = ctx.dr, azimuths.device, azimuths.shape[0]
             g_fn = g_rgba.to(torch.float32).contiguous()
             d = dr._desc(dr._static(dev), B, False, vertices, textures, None, None, azimuths, elevations, distances, biases, None, None, None, None)
@@ -140,7 +141,7 @@ class _RenderFn(torch.autograd.Function):
             g = N.MMRenderGrads(None, N.ptr(g_fn), N.ptr(gv), None, None, None, N.ptr(ga), N.ptr(ge), N.ptr(gd), N.ptr(gb))
             with torch.cuda.device(dev):
                 N.check(N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), N.current_stream(dev)), "mm_render_backward")
-            return None, None, None, None, gv, None, None, None, ga, ge, gd, gb
+            return None, None, None, None, gv, None, None, None, ga, ge, gd, gb, None
         vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt = ctx.saved_tensors
         ws = ctx.ws_holder.buf
         dr, dev = ctx.dr, azimuths.device
@@ -156,6 +157,7 @@ class _RenderFn(torch.autograd.Function):
             g_loss = (torch.zeros((), device=dev, dtype=torch.float32) if g_loss is None
                       else g_loss.to(device=dev, dtype=torch.float32).reshape(()).contiguous())
             d.fused_gt, d.fused_image_weight, d.fused_grad_loss = N.ptr(gt), float(dr.image_weight), N.ptr(g_loss)
+            d.fused_contour = ctx.contour
         else:
             if g_rgba is None:
                 g_rgba = torch.zeros((B, H, W, 4), device=dev, dtype=torch.float32)
@@ -169,7 +171,7 @@ class _RenderFn(torch.autograd.Function):
             N.check(N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), N.current_stream(dev)), "mm_render_backward")
             if ctx.dr.check_texture_records:                     # (synchronises: a diagnostic switch)
                 ctx.dr.check_records(d, N.current_stream(dev))
-        return None, None, None, None, gv, gt_, gl, gbg, ga, ge, gd, gb
+        return None, None, None, None, gv, gt_, gl, gbg, ga, ge, gd, gb, None
 
 
 class _ReconFn(torch.autograd.Function):
@@ -316,20 +318,21 @@ class DiffRender(object):
             self._static_cache[key] = st
         return st
 
-    def _render_node(self, no_mask, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases):
+    def _render_node(self, no_mask, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases, contour=0.0):
         """One autograd node for the render (+ the fused loss if gt is given).  With lib/mm_torch_ext.so built, the node is C++
         (csrc/mm_torch_ext.cpp: no Python in the backward); otherwise the torch.autograd.Function above issues the same ABI calls."""
         self._raise_if_records_were_dropped()                    # (an overflow of an EARLIER step's backward: a host read of pinned memory, no sync)
         ext = None if self.check_texture_records else N.torch_ext()   # (the diagnostic switch lives in the Python nodes)
         if ext is None:
-            return _RenderFn.apply(self, no_mask, self.emit_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases)
+            return _RenderFn.apply(self, no_mask, self.emit_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases,
+                                   float(contour))
         N.require_device(azimuths)
         if no_mask and bg is None:
             raise TypeError("render(no_mask=True) needs attributes['bg'] (B,3,H,W)")   # reference: None.permute fails
         if textures.dim() != 4:
             raise RuntimeError("textures must be (B,3,Ht,Wt), got %s" % (tuple(textures.shape),))
         dev = azimuths.device
-        proto, nbytes = self._proto(self._static(dev), azimuths.numel(), no_mask, textures.shape[2], textures.shape[3])
+        proto, nbytes = self._proto(self._static(dev), azimuths.numel(), no_mask, textures.shape[2], textures.shape[3], float(contour) if gt is not None else 0.0)
         return ext.render(N.fn_addr("mm_render_forward"), N.fn_addr("mm_render_fused_loss"), N.fn_addr("mm_render_backward"), proto, nbytes,
                           vertices, textures, lights, bg, azimuths, elevations, distances, biases, gt, bool(self.emit_imnormal),
                           float(self.image_weight), torch._C._cuda_getCurrentRawStream(dev.index))
@@ -373,10 +376,11 @@ class DiffRender(object):
             raise RuntimeError("mm_render_backward: the texture-record pool overflowed (records dropped per image: %s); the texture gradients of those "
                                "images are NaN. Raise DiffRender.extra_texture_records_per_pixel." % (list(dropped),))
 
-    def _proto(self, st, B, no_mask, Ht, Wt):
-        """(bytes of the MMRenderDesc prototype of this shape, its workspace size) for the C++ host path; cached like _desc's prototypes."""
+    def _proto(self, st, B, no_mask, Ht, Wt, contour=0.0):
+        """(bytes of the MMRenderDesc prototype of this shape, its workspace size) for the C++ host path; cached like _desc's prototypes.
+        contour: MMRenderDesc.fused_contour -- the C++ node copies the prototype for its forward AND its backward, so the weight travels in it."""
         key = ("bytes", id(st), B, int(bool(no_mask)), Ht, Wt, self.knum, self.sigmainv, self.boxlen, self.multiplier, self.eps, self.options,
-               float(self.extra_texture_records_per_pixel))
+               float(self.extra_texture_records_per_pixel), float(contour))
         hit = self._desc_cache.get(key)
         if hit is None:
             d = N.MMRenderDesc()
@@ -390,6 +394,7 @@ class DiffRender(object):
             d.vc_table, d.vc_stride = N.ptr(st["vc_table"]), int(st["vc_table"].shape[1])
             d.options = self.options
             d.status_flag = self._status_ptr()
+            d.fused_contour = float(contour)
             hit = (bytes(d), self.workspace_bytes(d))
             if len(self._desc_cache) > 32:
                 self._desc_cache.clear()
@@ -482,17 +487,23 @@ class DiffRender(object):
         return attributes
 
     def render_recon(self, gt_data, no_mask=False, contour=0, **attributes):
-        """render(**attributes) and recon_data(rendered, gt_data, no_mask) (contour = 0) in ONE pass over the pixels: the loss terms
+        """render(**attributes) and recon_data(rendered, gt_data, no_mask, contour) in ONE pass over the pixels: the loss terms
         are reduced while the image is shaded and its gradient is formed inside the backward kernels (no loss launches, no dL/drgba
         round trip) -- the path bench.py's `value` times, reachable from the class API.  Returns (loss, rgbs, attributes); ``rgbs``
-        carries no gradient here (use render + recon_data if the image feeds anything else that is differentiated)."""
-        if contour:
-            # the fused kernels carry recon_data's L1 + IoU terms only; the contour term (networks.py:379-387) needs the rendered mask as a whole
-            raise ValueError("render_recon folds recon_data with contour = 0 into the render kernels; for contour > 0 (opt.lambda_contour) call "
-                             "render(...) and recon_data(..., contour=%r)" % (contour,))
+        carries no gradient here (use render + recon_data if the image feeds anything else that is differentiated).
+        contour > 0 (recon_data's contour term, networks.py:379-388; trainer.py:441 passes opt.lambda_contour): folded in as well when the
+        image's height and width are multiples of 4 (then the term's two nearest-neighbour resamplings stay inside a screen tile); other
+        sizes raise -- call render(...) and recon_data(..., contour=...) for those.  (The reference also prints the term's value there.)"""
+        contour = float(contour)
+        if contour < 0:
+            contour = 0.0                                        # networks.py:379 `if contour>0`
+        if contour > 0 and (self.render_height % 4 or self.image_size % 4):
+            raise ValueError("render_recon folds the contour term in only for image sizes that are multiples of 4 (got %dx%d); call render(...) and "
+                             "recon_data(..., contour=%r)" % (self.render_height, self.image_size, contour))
         a = attributes
         rgba, fn, imn, face_idx, loss = self._render_node(bool(no_mask), gt_data, a['vertices'], a['textures'], a['lights'],
-                                                          a['bg'] if no_mask else None, a['azimuths'], a['elevations'], a['distances'], a['biases'])
+                                                          a['bg'] if no_mask else None, a['azimuths'], a['elevations'], a['distances'], a['biases'],
+                                                          contour)
         attributes['face_normals'] = fn
         attributes['imnormal'] = imn if self.emit_imnormal else None
         self.last_face_idx = face_idx

@@ -80,9 +80,11 @@ class RenderLossStep:
         self.rws = torch.empty(N.lib().mm_recon_query_workspace(ctypes.byref(r)), device=dev, dtype=torch.uint8)
         r.workspace, r.workspace_bytes = N.ptr(self.rws), self.rws.numel()
         self.r = r
-        # fused mode: recon_data (contour = 0) folded into the render kernels (MMRenderDesc.fused_*): two ABI calls per step
-        self.fused = bool(fused) and not contour
+        # fused mode: recon_data folded into the render kernels (MMRenderDesc.fused_*): two ABI calls per step.  Its contour term folds in for
+        # image sizes that are multiples of 4 (MMRenderDesc.fused_contour); other sizes with contour > 0 keep the three recon_data launches.
+        self.fused = bool(fused) and not (contour > 0 and (H % 4 or W % 4))
         if self.fused:
+            self.d.fused_contour = max(0.0, float(contour))
             self.d.fused_gt = N.ptr(self.gt)
             self.d.fused_image_weight = float(dr.image_weight)
             self.d.fused_loss = N.ptr(self.loss)

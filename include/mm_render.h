@@ -83,7 +83,7 @@ typedef struct MMRenderDesc {
     /* optional profiling: NULL, or an array of 2*MM_PROF_RENDER_SLOTS hipEvent_t created by the caller; the library
      * records events [2*slot] / [2*slot+1] on the stream immediately before / after the kernel of that slot. */
     void** prof_events;
-    /* optional FUSED reconstruction loss = DiffRender.recon_data with contour = 0 (networks.py:364-378) folded into the render
+    /* optional FUSED reconstruction loss = DiffRender.recon_data (networks.py:364-390; its contour term: fused_contour below) folded into the render
      * kernels: with fused_gt set, mm_render_forward also reduces the loss terms while it shades, and mm_render_backward
      * derives dL/d rgba on the fly from fused_gt and the prediction it re-forms per pixel, bit for bit (`rgba` is not read back: the caller
      * may already have overwritten it; MMRenderGrads.grad_rgba is then ignored and may be NULL) and writes the loss value.
@@ -104,6 +104,11 @@ typedef struct MMRenderDesc {
      * mm_render_status): 0 stays 0.  Lets a caller that never synchronises (autograd nodes, captured graphs) still turn an overflowing
      * record pool into an error one step later instead of training on NaN texture gradients. */
     int32_t* status_flag;
+    /* the fused loss's contour weight (recon_data's `contour` argument, networks.py:379-388; trainer.py:441 passes opt.lambda_contour): 0 = no
+     * contour term.  > 0 needs H % 4 == 0 and W % 4 == 0 (then F.interpolate's two nearest resamplings pick the top-left pixel of every
+     * 4x4 block, which lies in the pixel's own 8x8 screen tile; other sizes: MM_ERR_BAD_SHAPE -- use mm_recon_data_* for those).  Ignored
+     * without fused_gt. */
+    float fused_contour;
 } MMRenderDesc;
 
 /* MMRenderDesc.options / MMDibrDesc.options: 0 = the semantics of SURVEY.md 8(a) (the oracle's defaults).  The bits switch,
@@ -462,9 +467,9 @@ const char* mm_last_error_detail(void);
 size_t mm_struct_size(int which);
 /* Bumped whenever a struct or the meaning of a field changes (2: op boundary added, reserved uv-tile fields and profiling slot
  * MM_PROF_BIN removed, options bits defined; 3: MMRenderDesc takes the fixed-stride vertex -> corner table instead of the CSR,
- * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, MMTexMapGrads.workspace, mm_chamfer_nearest, mm_build_vertex_corner_csr_device).  Bindings must refuse a library whose
+ * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, MMTexMapGrads.workspace, mm_chamfer_nearest, mm_build_vertex_corner_csr_device; 5: MMRenderDesc.fused_contour).  Bindings must refuse a library whose
  * version differs from what they mirror. */
-#define MM_ABI_VERSION 4
+#define MM_ABI_VERSION 5
 int mm_abi_version(void);
 
 #ifdef __cplusplus

@@ -833,7 +833,7 @@ def test_concurrent_steps_on_four_streams_match_the_serial_result(pkg):
 
 
 @pytest.mark.parametrize("name,B,S,ratio", [("sphere", 3, 64, 1), ("smpl_uv_642", 4, 128, 2), ("sphere", 2, 36, 1)])
-def test_fused_loss_carries_the_contour_term(pkg, name, B, S, ratio):
+def test_fused_loss_carries_the_contour_term(pkg, oracle, name, B, S, ratio):
     """render_recon(..., contour=c) == render(...) + recon_data(..., contour=c) (networks.py:379-388; trainer.py:441 passes opt.lambda_contour):
     value and all eight input gradients, through the class API and through the C-ABI step object.  36x36: tiles that straddle the image edge."""
     import importlib
@@ -857,6 +857,9 @@ def test_fused_loss_carries_the_contour_term(pkg, name, B, S, ratio):
         l2.backward()
         assert torch.equal(rgbs2, rgbs.detach())
         assert abs(float(l1) - float(l2)) < 2e-6 * max(1.0, abs(float(l1)))
+        # ... and the oracle's recon_data (pinned to the reference's own value and gradient with contour 0.5: losses.npz) on the rendered image
+        lo, dpo = oracle.recon_data(rgbs.detach().cpu().numpy(), gt.cpu().numpy(), image_weight=dr.image_weight, contour=c, want_grad=True)
+        assert abs(float(l2) - float(lo)) < 2e-6 * max(1.0, abs(float(lo)))
         l0 = dr.recon_data(rgbs.detach(), gt, no_mask=True, contour=0)
         assert abs(float(l1) - float(l0)) > 1e-5                 # the term is there
         for k in leaves:

@@ -49,13 +49,17 @@ for case in range(ncase):
     api = str(rng.choice(["render+recon_data", "render_recon", "shim operators"], p=[0.4, 0.3, 0.3]))
     if optbit and api == "shim operators":
         api = "render_recon"                                     # (the kaolin-shaped operators take no option bits through their signatures)
-    tag += " | " + api
+    # recon_data's contour term (networks.py:379-388): un-fused at any size, folded into the render kernels at sizes that are multiples of 4
+    contour = float(rng.choice([0.0, 0.0, 0.5, 2.0]))
+    if api == "render_recon" and (H % 4 or W % 4):
+        contour = 0.0
+    tag += " | " + api + (" contour=%g" % contour if contour else "")
     try:
         if api == "render+recon_data":
             rgbs, out = dr.render(no_mask=no_mask, **datt)
-            dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask).backward()
+            dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask, contour=contour).backward()
         elif api == "render_recon":
-            loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=no_mask, **datt)
+            loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=no_mask, contour=contour, **datt)
             loss.backward()
         else:                                                    # the reference's own composition of the kaolin-shaped operators
             Tt = torch.from_numpy(oracle.camera(inp["distances"], inp["elevations"], inp["azimuths"], inp["biases"])).to(dev).requires_grad_(True)
@@ -70,7 +74,7 @@ for case in range(ncase):
             image = (texcolor * texmask + datt["bg"].permute(0, 2, 3, 1) * (1 - texmask)) * coef.unsqueeze(-1) if no_mask else \
                 texcolor * texmask * coef.unsqueeze(-1) + torch.ones_like(texcolor) * (1 - texmask)
             rgbs = torch.cat([torch.clamp(image, 0, 1), soft_t[..., None]], -1).permute(0, 3, 1, 2)
-            dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask).backward()
+            dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask, contour=contour).backward()
             dr.last_face_idx = fidx_t.int()
             # the camera chain is the oracle's here (T is a leaf): push dL/dT through it so that all eight gradients can be compared
             dd, de, da, db = oracle.camera_backward(inp["distances"], inp["elevations"], inp["azimuths"], inp["biases"], Tt.grad.cpu().numpy())
@@ -80,7 +84,7 @@ for case in range(ncase):
         kw = dict(knum=knum, boxlen=boxlen, sigmainv=sigmainv)
         with oracle.options(optbit):
             rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj, **kw)
-            loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+            loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, contour=contour, want_grad=True)
             g_o = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None, **kw)
         nf = int((dr.last_face_idx.cpu().numpy() != fidx_o).sum())
         errs = {"rgba": float(np.abs(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy() - rgba_o).max())}

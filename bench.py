@@ -191,6 +191,11 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # The gradient all-reduce shares the GPU with the render kernels it overlaps: a RCCL channel is one workgroup pinned to a CU for the
+        # whole reduction, and the library's default for a 135 MB message is dozens of them -- a fifth of the chip taken from a path that is
+        # bound by how many of its own waves are in flight.  Eight channels (3 % of the CUs) still move a ring step per xGMI link; the cadence
+        # below adapts to whatever the reduction then takes.  (A caller's own setting wins.)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -581,6 +586,7 @@ def main():
                        "grad_allreduce": None if reducer is None else
                                          {"mb_per_reduction_per_rank": round(reducer.bytes_per_step() / 1e6, 1), "every_k_steps": every_k,
                                           "launched_in_timed_region": launched_timed, "alone_ms": allreduce_ms, "overlapped": True,
+                                          "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS"),
                                           "policy": "one reduction in flight at all times, back to back on a side stream, concurrent with the render "
                                                     "streams: K = ceil(1.25 x reduction alone / step alone), agreed on from max-over-ranks timings"}},
             "value_one_stream": one_stream, "value_four_streams": round(total_images / elapsed, 1) if args.mode == "eager" else None,

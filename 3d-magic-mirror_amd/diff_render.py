@@ -68,7 +68,7 @@ class _RenderFn(torch.autograd.Function):
     fifth output; the image is then an output without gradient (its only consumer, the loss, is already inside)."""
 
     @staticmethod
-    def forward(ctx, dr, no_mask, want_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases, contour=0.0):
+    def forward(ctx, dr, no_mask, want_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases, contour):
         dev, B, H, W, vertices, textures, lights, bg, azimuths, elevations, distances, biases = _render_inputs(
             dr, no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases)
         st = dr._static(dev)
@@ -482,7 +482,7 @@ class DiffRender(object):
         self._raise_if_records_were_dropped()
         N.require_device(a['azimuths'])
         attributes['face_normals'] = _RenderFn.apply(self, False, "geometry", None, a['vertices'], a['textures'], a['lights'], None,
-                                                     a['azimuths'], a['elevations'], a['distances'], a['biases'])
+                                                     a['azimuths'], a['elevations'], a['distances'], a['biases'], 0.0)
         attributes['imnormal'] = None
         return attributes
 

@@ -678,12 +678,16 @@ inline bool walk_block_sort(const RasterArgs& a) {
 #ifdef MM_NO_BLOCK_SORT
     return false;
 #else
+#ifdef MM_BLOCK_SORT_IN_BLOCK_SHAPE                             // (A/B: the bin's four tiles as the four waves of ONE workgroup -- one CU, one L1)
+    return a.bin_shift >= 4;
+#else
     return a.bin_shift >= 4 && !(a.options & MM_OPT_WALK_BLOCK);
+#endif
 #endif
 }
 inline int walk_spread(const RasterArgs& a) {
     if (a.order == nullptr || 4 * a.blocks_per_image < 1024) return 0;
-    return a.block_sort ? 2 : 1;
+    return a.block_sort && !walk_block_mode(a) ? 2 : 1;
 }
 inline unsigned walk_grid(const RasterArgs& a, bool block) {
     if (!a.order) return (unsigned)a.B * (unsigned)a.blocks_per_image * (block ? 1u : 4u);

@@ -12,7 +12,7 @@ LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "dis
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
-bad = 0
+bad = 0; ncond = 0
 only = os.environ.get("MM_FUZZ_ONLY")
 for case in range(ncase):
     name = rng.choice(["sphere", "smpl_uv_642", "ellipsoid", "sphere2", "smpl_uv"], p=[0.25, 0.3, 0.15, 0.15, 0.15])
@@ -95,8 +95,24 @@ for case in range(ncase):
             errs[k] = float(np.abs(datt[k].grad.cpu().numpy() - ref).max() / max(1.0, float(np.abs(ref).max())))
         worst = max(errs.values())
         ok = nf == 0 and worst <= 1e-4
-        print("%s  case %2d  %-90s face_idx diff %d, worst err %.2e (%s)" % ("ok  " if ok else "FAIL", case, tag, nf, worst, max(errs, key=errs.get)), flush=True)
-        bad += not ok
+        label = "ok  " if ok else "FAIL"
+        if not ok and nf == 0 and errs["rgba"] <= 1e-4:
+            # A gradient beyond 1e-4 of the fp32 oracle with the image itself in agreement: is fp32 the problem?  The same backward in float64 is the
+            # judge: where the fp32 ORACLE is itself far from it and the HIP result is no farther (twice its distance + 1e-4), the case is ill-conditioned
+            # in fp32 (tiny screens with huge soft margins: a few pixels carry the whole loss) -- reported as COND and counted apart, never as ok.
+            g64 = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)).astype(np.float64), None, dtype=np.float64, **kw)
+            cond = True
+            for k in LEAVES:
+                if datt.get(k) is None or (k == "bg" and not no_mask):
+                    continue
+                r64 = g64[k]; den = max(1.0, float(np.abs(r64).max()))
+                e_hip = float(np.abs(datt[k].grad.cpu().numpy().astype(np.float64) - r64).max()) / den
+                e_o32 = float(np.abs(g_o[k].astype(np.float64) - r64).max()) / den
+                cond = cond and e_hip <= 2.0 * e_o32 + 1e-4
+            if cond:
+                label = "COND"; ncond += 1
+        print("%s  case %2d  %-90s face_idx diff %d, worst err %.2e (%s)" % (label, case, tag, nf, worst, max(errs, key=errs.get)), flush=True)
+        bad += label == "FAIL"
         if not ok and os.environ.get("MM_FUZZ_DETAIL"):
             print("      all errors:", {k: "%.2e" % v for k, v in errs.items()})
             g64 = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)).astype(np.float64), None, dtype=np.float64, **kw)
@@ -108,4 +124,4 @@ for case in range(ncase):
     except Exception as e:                                          # noqa: BLE001
         print("EXC   case %2d  %s: %r" % (case, tag, e), flush=True)
         bad += 1
-print("failures:", bad)
+print("failures:", bad, "| ill-conditioned in fp32 (HIP no farther from the float64 backward than the fp32 oracle is):", ncond)

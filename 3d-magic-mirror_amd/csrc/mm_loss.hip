@@ -113,7 +113,29 @@ __global__ __launch_bounds__(256) void recon_bwd_kernel(LossArgs a) {
     a.grad_pred[po + a.ps[1] * 3] = gs * (-(1.f / (float)a.B) * (gm / U - up * (1.f - gm) / (U * U)));
 }
 
-// contour term (networks.py:379-387): runs after recon_bwd_kernel, adds into the alpha channel of grad_pred
+// contour term (networks.py:379-387): runs after recon_bwd_kernel, adds into the alpha channel of grad_pred.
+// The term couples every pixel p with the pixel s(p) that the two nearest-neighbour resamplings select for it: p receives +g_p, s(p) receives
+// -g_p.  No atomics: one thread per pixel forms EVERYTHING its pixel receives -- its own g, and, if it is the selected pixel of a cell of the
+// (H/4, W/4) grid, minus the g of every pixel of that cell, visited in row-major order -- and adds it to the gradient with one plain
+// read-modify-write (nobody else writes that element in this launch).  Bitwise reproducible; the result is the sum the reference's autograd
+// forms, in a fixed order.
+__device__ inline float contour_pixel_grad(const LossArgs& a, const float* gt, int b, int y, int x, float k2) {
+    int ys, xs;
+    contour_src(y, x, a.H, a.W, ys, xs);
+    const size_t hw = (size_t)a.H * a.W;
+    const float d = a.pred[(size_t)(a.ps[0] * b + a.ps[1] * 3 + a.ps[2] * y + a.ps[3] * x)] -
+                    a.pred[(size_t)(a.ps[0] * b + a.ps[1] * 3 + a.ps[2] * ys + a.ps[3] * xs)];
+    const float cp = fabsf(d), cg = fabsf(gt[3 * hw + (size_t)y * a.W + x] - gt[3 * hw + (size_t)ys * a.W + xs]);
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    return k2 * (cp - cg) * sg;
+}
+// the cell of the (in/4) grid whose selected pixel is `v`, or -1: near_src(c, in, in4) == v for at most one c (the map is strictly increasing)
+__device__ inline int contour_cell_of_source(int v, int in, int in4) {
+    const int c0 = (int)floorf((float)v * ((float)in4 / (float)in));
+    for (int c = max(c0 - 1, 0); c <= min(c0 + 2, in4 - 1); ++c)
+        if (near_src(c, in, in4) == v) return c;
+    return -1;
+}
 __global__ __launch_bounds__(256) void recon_contour_bwd_kernel(LossArgs a) {
     const int b = blockIdx.y;
     const int hw = a.H * a.W;
@@ -122,16 +144,26 @@ __global__ __launch_bounds__(256) void recon_contour_bwd_kernel(LossArgs a) {
     const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
     const float* gt = a.gt + (size_t)b * 4 * hw;
     const int y = i / a.W, x = i - y * a.W;
-    int ys, xs;
-    contour_src(y, x, a.H, a.W, ys, xs);
-    const size_t pa = (size_t)(a.ps[0] * b + a.ps[1] * 3 + a.ps[2] * y + a.ps[3] * x);
-    const size_t pb = (size_t)(a.ps[0] * b + a.ps[1] * 3 + a.ps[2] * ys + a.ps[3] * xs);
-    const float d = a.pred[pa] - a.pred[pb];
-    const float cp = fabsf(d), cg = fabsf(gt[3 * hw + i] - gt[3 * hw + ys * a.W + xs]);
-    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
     const float n = (float)a.B * (float)a.H * (float)a.W;
-    const float g = gs * a.contour * 2.f * (cp - cg) / n * sg;
-    if (g != 0.f) { atomicAdd(a.grad_pred + pa, g); atomicAdd(a.grad_pred + pb, -g); }
+    const float k2 = gs * a.contour * 2.f / n;
+    float acc = contour_pixel_grad(a, gt, b, y, x, k2);
+    const int h4 = a.H / 4, w4 = a.W / 4;
+    const int cy = contour_cell_of_source(y, a.H, h4), cx = contour_cell_of_source(x, a.W, w4);
+    if (cy >= 0 && cx >= 0) {
+        // the cell's pixels: rows / columns r with near_src(r, in4, in) == c -- a contiguous run around c * in / in4
+        const int y0 = max((int)floorf((float)cy * ((float)a.H / (float)h4)) - 2, 0), y1 = min((int)ceilf((float)(cy + 1) * ((float)a.H / (float)h4)) + 2, a.H);
+        const int x0 = max((int)floorf((float)cx * ((float)a.W / (float)w4)) - 2, 0), x1 = min((int)ceilf((float)(cx + 1) * ((float)a.W / (float)w4)) + 2, a.W);
+        float minus = 0.f;
+        for (int yy = y0; yy < y1; ++yy) {
+            if (near_src(yy, h4, a.H) != cy) continue;
+            for (int xx = x0; xx < x1; ++xx) {
+                if (near_src(xx, w4, a.W) != cx) continue;
+                minus += contour_pixel_grad(a, gt, b, yy, xx, k2);
+            }
+        }
+        acc -= minus;
+    }
+    if (acc != 0.f) a.grad_pred[(size_t)(a.ps[0] * b + a.ps[1] * 3 + a.ps[2] * y + a.ps[3] * x)] += acc;
 }
 
 static LossArgs make_loss_args(const MMReconDesc* d) {

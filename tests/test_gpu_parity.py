@@ -887,3 +887,27 @@ def test_fused_contour_needs_sizes_that_are_multiples_of_four(pkg):
     loss, _, _ = dr.render_recon(gt.to(dev), no_mask=True, contour=0, **datt)     # contour = 0: any size
     rgbs, _ = dr.render(no_mask=True, **datt)
     assert abs(float(loss) - float(dr.recon_data(rgbs, gt.to(dev), no_mask=True))) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 30, 30), (2, 64, 48), (2, 37, 21), (1, 8, 8)])
+def test_unfused_contour_backward_matches_the_oracle_and_is_bitwise_reproducible(pkg, oracle, B, H, W):
+    """recon_data(contour > 0) on its own (networks.py:379-388) at sizes that are NOT multiples of 4 too (the two nearest-neighbour resamplings then
+    select pixels outside a pixel's own 4x4 block): value and dL/dpred against the oracle (pinned to the reference's own numbers in losses.npz), and
+    the backward twice -- it gathers per selected pixel in a fixed order, no floating-point atomics."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H * 100 + W)
+    pred = torch.rand(B, 4, H, W, generator=g)
+    gt = torch.rand(B, 4, H, W, generator=g)
+    gt[:, 3] = (gt[:, 3] > 0.5).float()
+    pred[:, 3] = torch.where(torch.rand(B, H, W, generator=g) > 0.5, pred[:, 3], torch.ones(B, H, W))   # flat regions: |0| gradients
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "sphere.npz"), 32)
+    grads = []
+    for _ in range(3):
+        p = pred.to(dev).clone().requires_grad_(True)
+        loss = dr.recon_data(p, gt.to(dev), no_mask=True, contour=0.7)
+        loss.backward()
+        grads.append(p.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    lo, dpo = oracle.recon_data(pred.numpy(), gt.numpy(), image_weight=dr.image_weight, contour=0.7, want_grad=True)
+    assert abs(float(loss) - lo) < 2e-6 * max(1.0, abs(lo))
+    np.testing.assert_allclose(grads[0].cpu().numpy(), dpo, rtol=1e-4, atol=1e-9)

@@ -472,7 +472,15 @@ def main():
                 for k, v in step.kernel_times_ms().items():
                     acc.setdefault(k, []).append(v * 1e3)
         step.disable_profiling()
-        kernels_us = {k: float(np.mean(v)) for k, v in acc.items() if np.isfinite(np.mean(v))}
+        # the mean over the profiled steps, without the rare sample that a host or clock hiccup stretched beyond three times the kernel's median
+        # (one such step among thirty used to move a kernel's "average" by its whole duration); how many were dropped is reported
+        dropped = 0
+        for k, v in acc.items():
+            v = np.asarray(v, dtype=np.float64)
+            keep = v <= 3.0 * np.median(v) if np.all(np.isfinite(v)) else np.ones(len(v), bool)
+            dropped += int((~keep).sum())
+            if np.isfinite(np.mean(v[keep])):
+                kernels_us[k] = float(np.mean(v[keep]))
         dom = max(kernels_us, key=kernels_us.get)
         nbytes = algorithmic_bytes(dom, B, dr.num_faces, dr.num_vertices, H * W, Ht * Wt, fused=not args.unfused, imnormal=True)
         achieved = nbytes / (kernels_us[dom] * 1e-6) / 1e9
@@ -486,6 +494,7 @@ def main():
                     "traffic_formula": "2*FETCH_SIZE + WRITE_SIZE (KiB x 1024), separate --pmc passes; per-pattern factors measured on this path's "
                                        "access patterns: profiles/r04_fetch_calibration.json",
                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(kernels_us[dom], 3),
+                    "avg_over": "%d profiled steps, %d kernel samples beyond 3x their kernel's median dropped" % (args.profile_steps, dropped),
                     "duration_source": "hip_events (recorded by the library around the launch on its own stream; ~2.5 us longer per kernel than "
                                        "rocprofv3's kernel-trace durations, which profiles/*_kernel_stats.md quote)",
                     "algorithmic_includes": "face records 52F, texture 12T, rgba 16HW, face_idx 4HW, ground truth 16HW (fused loss), imnormal 12HW",

@@ -125,7 +125,10 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
 #ifndef MM_PIXEL_LB
 #define MM_PIXEL_LB 5             // waves per SIMD the register allocation is held to: 96 VGPRs without spills (the light gradients are carried as scalar + normal, not
 #endif                            // as nine products); 5 workgroups of 28.9 KB LDS (the plan workgroups' staging) fit a CU as well
-template <bool kNoMask>
+// kContour: the fused loss carries recon_data's contour term (MMRenderDesc.fused_contour > 0).  The reference's default is --lambda_contour 0
+// (train.py:115, trainer.py:441): the default caller gets the instantiation without the term's code (24 vector instructions per wave and its
+// registers), chosen by the host.
+template <bool kNoMask, bool kContour>
 __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) {
     MM_TIMELINE_BEGIN();
     __shared__ float s_dl[MM_BLOCK_WAVES][9];
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
             for (int c = 0; c < 3; ++c) gi3[c] = g[c * hw + pin] * gm + 1.f * (1.f - gm);
             g4.w = ka * gm + kb * (1.f - gm);
         }
-        if (a.contour > 0.f) {                                   // (wave-uniform) the contour term, networks.py:379-388 (forward: contour_term, mm_raster_common.h)
+        if (kContour) {                                          // the contour term, networks.py:379-388 (forward: contour_term, mm_raster_common.h)
             // d/dalpha of  kc * sum_p (|alpha_p - alpha_s(p)| - |gm_p - gm_s(p)|)^2,  s(p) = top-left pixel of p's 4x4 block = lane (lane & 0x24) of this
             // wave: pixel p gets +g_p, its block's corner pixel -sum of the block's g (its own g is 0: |0| has gradient 0, as torch.abs has).
             // alpha is re-formed from the saved soft-mask state exactly as shade_store formed it: covered 1, else 1 - keepprod.
@@ -451,8 +454,9 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
 int launch_pixel_bwd(const BwdArgs& a, const MMRenderDesc* d, hipStream_t s) {
     ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
     dim3 grid(a.blocks_per_image * d->B + a.plan_wgs * d->B);    // + the plan workgroups, in front
-    if (d->no_mask) hipLaunchKernelGGL(pixel_bwd_kernel<true>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(pixel_bwd_kernel<false>, grid, dim3(256), 0, s, a);
+    const bool contour = a.gt != nullptr && a.contour > 0.f;
+    if (d->no_mask) { if (contour) hipLaunchKernelGGL((pixel_bwd_kernel<true, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((pixel_bwd_kernel<true, false>), grid, dim3(256), 0, s, a); }
+    else { if (contour) hipLaunchKernelGGL((pixel_bwd_kernel<false, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((pixel_bwd_kernel<false, false>), grid, dim3(256), 0, s, a); }
     return MM_OK;
 }
 

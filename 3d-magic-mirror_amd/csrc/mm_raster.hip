@@ -40,7 +40,8 @@ namespace mm {
 #define MM_RASTER_WPE 5
 #endif
 // kQueue: the compacting walk (tile_walk) for screen bins larger than a tile; otherwise the per-batch walk (tile_walk_batch)
-template <bool kNoMask, bool kBlock, bool kQueue>
+// kContour: the fused loss carries recon_data's contour term (host: fused_gt && fused_contour > 0)
+template <bool kNoMask, bool kBlock, bool kQueue, bool kContour>
 __global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_eu(MM_RASTER_WPE, MM_RASTER_WPE))) void raster_fwd_kernel(RasterArgs a) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
     MM_TIMELINE_BEGIN();
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_
         if (j >= W1) {                                           // (interleaving the two kinds of workgroup evenly was measured: no gain at 512x512,
             if (j - W1 >= W2) return;                            //  slower at 128x128, where every walking workgroup is resident from the start)
             const int e0 = nne + (j - W1) * per + wv * 4, ne = min(4, 4 * a.blocks_per_image - e0);
-            if (ne > 0) shade_empty_tiles<kNoMask>(a, b, e0, ne, threadIdx.x & 63);
+            if (ne > 0) shade_empty_tiles<kNoMask, kContour>(a, b, e0, ne, threadIdx.x & 63);
             return;
         }
         rank = j;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_
         if (kQueue) tile_walk(a, t, &s_stage[wv], key, ss MM_PP_PASS);
         else tile_walk_batch(a, t, &s_stage[wv], key, ss MM_PP_PASS);
     }
-    shade_store<kNoMask>(a, t, key, ss);
+    shade_store<kNoMask, kContour>(a, t, key, ss);
     flush_taken_last(a, t, &s_stage[(kBlock && coop) ? 0 : wv]);
     MM_PP_MARK(5);
     MM_PP_FLUSH(raster_fwd, (long long)blockIdx.x * (kBlock ? 4 : 1) + wv);
@@ -200,7 +201,8 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     // 8-pixel bins: the bin is the tile, nothing to compact -> the per-batch walk, no face flags (every face gets its sweep items)
     const bool queue = walk_queue_mode(a);
     if (!queue) a.fflag = nullptr;
-#define MM_LAUNCH_RASTER(NM, BL, QU) hipLaunchKernelGGL((raster_fwd_kernel<NM, BL, QU>), grid, dim3(BL ? 256 : 64), 0, s, a)
+#define MM_LAUNCH_RASTER2(NM, BL, QU, CO) hipLaunchKernelGGL((raster_fwd_kernel<NM, BL, QU, CO>), grid, dim3(BL ? 256 : 64), 0, s, a)
+#define MM_LAUNCH_RASTER(NM, BL, QU) do { if (a.contour > 0.f) MM_LAUNCH_RASTER2(NM, BL, QU, true); else MM_LAUNCH_RASTER2(NM, BL, QU, false); } while (0)
     if (block) {
         if (queue) { if (d->no_mask) MM_LAUNCH_RASTER(true, true, true); else MM_LAUNCH_RASTER(false, true, true); }
         else { if (d->no_mask) MM_LAUNCH_RASTER(true, true, false); else MM_LAUNCH_RASTER(false, true, false); }
@@ -208,6 +210,7 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
         if (queue) { if (d->no_mask) MM_LAUNCH_RASTER(true, false, true); else MM_LAUNCH_RASTER(false, false, true); }
         else { if (d->no_mask) MM_LAUNCH_RASTER(true, false, false); else MM_LAUNCH_RASTER(false, false, false); }
     }
+#undef MM_LAUNCH_RASTER2
 #undef MM_LAUNCH_RASTER
     return launch_ok("raster_fwd");
 }

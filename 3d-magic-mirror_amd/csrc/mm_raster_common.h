@@ -416,7 +416,8 @@ __device__ inline float contour_term(float alpha, float gm, bool in_img, int lan
 //   trip 1  everything that depends on the winner's id alone: its geometry, normal and corner uvs, plus background / ground truth
 //   trip 2  the twelve texels, from clamped (always valid) addresses, unconditionally; a corner outside contributes an exact zero
 // The arithmetic (expressions, order, roundings) is unchanged.
-template <bool kNoMask>
+// kContour: the fused loss carries recon_data's contour term (a.contour > 0; chosen by the host -- the reference's default is none, train.py:115)
+template <bool kNoMask, bool kContour>
 __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsigned long long key, const SoftState& ss) {
     if (!t.in_img && !a.gt) return;
     const int cpx = min(t.px, a.W - 1), cpy = min(t.py, a.H - 1);
@@ -539,15 +540,15 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
             }
             up = out[3] * gm; down = (out[3] + gm) - up;
         }
-        if (a.contour > 0.f) cs = contour_term(out[3], gtv[3], t.in_img, t.lane);   // (wave-uniform branch: every lane takes part in the exchange)
+        if (kContour) cs = contour_term(out[3], gtv[3], t.in_img, t.lane);   // (every lane takes part in the exchange)
         l1 = wave_sum(l1); up = wave_sum(up); down = wave_sum(down);
-        if (a.contour > 0.f) cs = wave_sum(cs);
+        if (kContour) cs = wave_sum(cs);
         if (t.lane == 0) {                                       // exact in 2^-32 fixed point; integer adds commute: deterministic totals
             unsigned long long* row = (unsigned long long*)(a.ltot + ((size_t)t.b * MM_LSUB + ((t.blk * 4 + t.wave) & (MM_LSUB - 1))) * 4);
             atomicAdd(row + 0, fixed32(l1));
             if (up != 0.f) atomicAdd(row + 1, fixed32(up));
             if (down != 0.f) atomicAdd(row + 2, fixed32(down));
-            if (cs != 0.f) atomicAdd(row + 3, fixed32(cs));
+            if (kContour && cs != 0.f) atomicAdd(row + 3, fixed32(cs));
         }
     }
     // Last (nothing waits for these): the texture tiles under the covered pixels' bilinear footprints, one non-returning add per (wave, tile) -- the
@@ -578,7 +579,7 @@ __device__ inline void shade_store(const RasterArgs& a, const TileCtx& t, unsign
 // tile of its own wave pays the wave's fixed costs (launch, two dependent trips to memory, the store drain) for ~40 instructions of
 // work.  Here the four tiles' loads are in flight together.  Per pixel exactly what shade_store's uncovered-tile path computes
 // (m = 0, n = 0, soft-mask state "nothing taken"); the four tiles' recon_data terms go to ltot as one exact integer add per sum.
-template <bool kNoMask>
+template <bool kNoMask, bool kContour>
 __device__ inline void shade_empty_tiles(const RasterArgs& a, int b, int e0, int ne, int lane) {
     const int nslot = 4 * a.blocks_per_image;
     const size_t hw = (size_t)a.H * a.W;
@@ -604,7 +605,7 @@ __device__ inline void shade_empty_tiles(const RasterArgs& a, int b, int e0, int
     float l1 = 0.f, down = 0.f, cs = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if (a.gt && a.contour > 0.f) cs += contour_term(0.f, gtv[q][3], in[q], lane);   // (alpha = 0 everywhere here: the ground truth's contour alone)
+        if (kContour && a.gt) cs += contour_term(0.f, gtv[q][3], in[q], lane);   // (alpha = 0 everywhere here: the ground truth's contour alone)
         float out[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -630,12 +631,12 @@ __device__ inline void shade_empty_tiles(const RasterArgs& a, int b, int e0, int
     }
     if (a.gt) {
         l1 = wave_sum(l1); down = wave_sum(down);
-        if (a.contour > 0.f) cs = wave_sum(cs);
+        if (kContour) cs = wave_sum(cs);
         if (lane == 0) {
             unsigned long long* row = (unsigned long long*)(a.ltot + ((size_t)b * MM_LSUB + (sl[0] & (MM_LSUB - 1))) * 4);
             if (l1 != 0.f) atomicAdd(row + 0, fixed32(l1));
             if (down != 0.f) atomicAdd(row + 2, fixed32(down));
-            if (cs != 0.f) atomicAdd(row + 3, fixed32(cs));
+            if (kContour && cs != 0.f) atomicAdd(row + 3, fixed32(cs));
         }
     }
 }

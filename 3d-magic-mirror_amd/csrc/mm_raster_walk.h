@@ -74,6 +74,9 @@ __device__ inline void flush_taken_last(const RasterArgs& a, const TileCtx& t, W
 #ifndef MM_TAKEN_EXACT
 #define MM_TAKEN_EXACT 1
 #endif
+#ifndef MM_WALK_TWICE
+#define MM_WALK_TWICE 0
+#endif
 // Work of a 256-thread workgroup: FOUR tiles, one per wave (nothing shared), or ONE heavy tile walked by its four waves together
 // (tile_walk_coop).  With the plan kernel's order (tiles of an image by decreasing candidate count, the first nheavy of them heavy):
 // workgroup j of image b takes heavy tile j, or -- behind the heavy ones -- the four tiles nheavy + 4 (j - nheavy) + wave.  Launch
@@ -289,12 +292,32 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
     key = 0ull;
     ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
     if (t.empty) return;                                         // wave-uniform: more than half of all tiles are empty
+    const float s2 = a.sigmainv / (a.mult * a.mult);
+#if MM_WALK_TWICE
+    // BOUND EXPERIMENT (profiles/r05_depth_order_bound.md; never in the product): the tile is walked twice by the same code (a loop, not a second
+    // call site).  1: the second walk starts from the FIRST walk's winners -- every pixel already holds its final depth, the tile's depth floor is
+    // final, only truly uncovered pixels take silhouette faces: what a perfect nearest-first order of the candidates could at best leave of the
+    // colour pairs.  2: the second walk starts from nothing (calibration: the cost of one whole walk).  Results are those of the second walk,
+    // which are the first's (the winner is an idempotent maximum; the silhouette state is reset).
+    unsigned long long seed = 0ull;
+    int lastf = 0x7FFFFFFF;
+    for (int rep = 0; rep < 2; ++rep) {
+    st->key[t.lane] = MM_WALK_TWICE == 1 ? seed : 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0; st->takenw[t.lane] = 0ull;
+    wave_lds_sync();
+    int cnt = 0, cbase = 0;
+    lastf = 0x7FFFFFFF;
+    bool open = t.in_img && (MM_WALK_TWICE == 1 ? seed == 0ull : true);
+    unsigned zfloor = MM_WALK_TWICE == 1 ? wave_min_u32(t.in_img ? (unsigned)(seed >> 32) : 0xFFFFFFFFu) : 0u;
+#ifdef MM_PHASE_PROF
+    if (rep == 1) { pp_.c0 = 0; pp_.c1 = 0; for (int i = 1; i <= 4; ++i) pp_.acc[i] = 0; }   // the counters and walk phases of the second walk alone
+#endif
+#else
     st->key[t.lane] = 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0; st->takenw[t.lane] = 0ull;
     wave_lds_sync();
-    const float s2 = a.sigmainv / (a.mult * a.mult);
     int cnt = 0, lastf = 0x7FFFFFFF, cbase = 0;
     bool open = t.in_img;
     unsigned zfloor = 0;                                         // smallest depth_ord held by an in-image pixel of the tile (wave-uniform; 0: some pixel holds nothing)
+#endif
     scan_candidates(a, t, st, zfloor, cbase, [&]() { return __ballot(open && cnt < a.knum) != 0; }, [&](int n) {
         wave_lds_sync();                                         // the queue's stores
         const uint64_t mh = t.lane < n ? st->qm[0][t.lane] : 0ull, ms = t.lane < n ? st->qm[1][t.lane] : 0ull;
@@ -363,6 +386,11 @@ __device__ inline void tile_walk(const RasterArgs& a, const TileCtx& t, WaveStag
         wave_lds_sync();                                         // the queue is free again
     } MM_PP_PASS);
     wave_lds_sync();
+#if MM_WALK_TWICE
+    seed = st->key[t.lane];
+    wave_lds_sync();
+    }
+#endif
     key = st->key[t.lane];
     ss.zeros = st->zeros[t.lane];
     ss.qnz = exp2f((float)((double)st->logsum[t.lane] * (1.0 / 4294967296.0)));

@@ -1,10 +1,11 @@
 """Randomised HIP-vs-oracle parity over templates, batch sizes, screen sizes, camera distances and dibr constants (face_idx bit-exact, RGBA
-and all gradients 1e-4): a hunt for corner cases the fixed parity cases miss (many windows / chunks of candidates in one tile, cooperative
+1e-4 absolute, every gradient within 1e-4 of ITS OWN maximum -- no floor of 1, tests/parity_bar.py): a hunt for corner cases the fixed parity cases miss (many windows / chunks of candidates in one tile, cooperative
 tiles with more than one window, ragged screens, far and near cameras).   python profiles/tools/fuzz_parity.py [cases] [seed]"""
 import sys, importlib, os, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle
+from parity_bar import rel_errors
 pkg = importlib.import_module("3d-magic-mirror_amd")
 sys.path.insert(0, os.path.join(ROOT, "3d-magic-mirror_amd", "shim"))
 import kaolin as kal
@@ -92,7 +93,7 @@ for case in range(ncase):
             if datt.get(k) is None or (k == "bg" and not no_mask):
                 continue
             ref = g_o[k]
-            errs[k] = float(np.abs(datt[k].grad.cpu().numpy() - ref).max() / max(1.0, float(np.abs(ref).max())))
+            errs[k] = rel_errors(datt[k].grad, ref)[0]          # max|got - ref| / max|ref|: no floor
         worst = max(errs.values())
         ok = nf == 0 and worst <= 1e-4
         label = "ok  " if ok else "FAIL"
@@ -105,9 +106,7 @@ for case in range(ncase):
             for k in LEAVES:
                 if datt.get(k) is None or (k == "bg" and not no_mask):
                     continue
-                r64 = g64[k]; den = max(1.0, float(np.abs(r64).max()))
-                e_hip = float(np.abs(datt[k].grad.cpu().numpy().astype(np.float64) - r64).max()) / den
-                e_o32 = float(np.abs(g_o[k].astype(np.float64) - r64).max()) / den
+                e_hip = rel_errors(datt[k].grad, g64[k])[0]; e_o32 = rel_errors(g_o[k], g64[k])[0]
                 cond = cond and e_hip <= 2.0 * e_o32 + 1e-4
             if cond:
                 label = "COND"; ncond += 1
@@ -120,7 +119,7 @@ for case in range(ncase):
                 got = datt[k].grad.cpu().numpy().astype(np.float64); r32 = g_o[k].astype(np.float64); r64 = g64[k]
                 i = np.unravel_index(np.abs(got - r32).argmax(), got.shape)
                 print("      %s worst at %s: hip %.6e oracle32 %.6e oracle64 %.6e | max|ref| %.3e | hip-vs-64 %.2e, o32-vs-64 %.2e (relative to max)" % (
-                    k, i, got[i], r32[i], r64[i], np.abs(r32).max(), np.abs(got - r64).max() / max(1, np.abs(r64).max()), np.abs(r32 - r64).max() / max(1, np.abs(r64).max())))
+                    k, i, got[i], r32[i], r64[i], np.abs(r32).max(), np.abs(got - r64).max() / np.abs(r64).max(), np.abs(r32 - r64).max() / np.abs(r64).max()))
     except Exception as e:                                          # noqa: BLE001
         print("EXC   case %2d  %s: %r" % (case, tag, e), flush=True)
         bad += 1

@@ -9,8 +9,10 @@ import bench
 cfg = sys.argv[1] if len(sys.argv) > 1 else "config2"
 name, B, S, ratio = bench.CONFIGS[cfg]
 bn = importlib.import_module("3d-magic-mirror_amd.build_native")
-var = os.path.join(os.path.dirname(bn.LIB), "libmm_pp.so")
-if not os.path.exists(var) or any(os.path.getmtime(os.path.join(bn.CSRC, f)) > os.path.getmtime(var) for f in os.listdir(bn.CSRC)):
+var = os.environ.get("MM_PP_LIB") or os.path.join(os.path.dirname(bn.LIB), "libmm_pp.so")   # MM_PP_LIB: a prebuilt -DMM_PHASE_PROF variant (e.g. + -DMM_WALK_TWICE=1)
+if os.environ.get("MM_PP_LIB"):
+    assert os.path.exists(var), var
+elif not os.path.exists(var) or any(os.path.getmtime(os.path.join(bn.CSRC, f)) > os.path.getmtime(var) for f in os.listdir(bn.CSRC)):
     bn.build(out=var, extra_flags=["-DMM_PHASE_PROF"])          # (prebuilt in the build container when possible: hipcc minutes are GPU-box minutes)
 pkg = importlib.import_module("3d-magic-mirror_amd"); stepmod = importlib.import_module("3d-magic-mirror_amd.step")
 pkg._native.LIB_PATH = var

@@ -1,5 +1,6 @@
 """Parity proper: the HIP path (through the C ABI, via the DiffRender mirror) against the CPU oracle on the same seeded
-inputs.  Bar (BASELINE.json north_star): face_idx bit-exact; RGBA and every input gradient within 1e-4 (fp32)."""
+inputs.  Bar (BASELINE.json north_star): face_idx bit-exact; RGBA within 1e-4 (absolute: image values are O(1)); every input gradient
+within 1e-4 OF THE GRADIENT'S OWN MAXIMUM (max|got - ref| <= 1e-4 * max|ref|, no floor: tests/parity_bar.py)."""
 import os
 
 import numpy as np
@@ -7,6 +8,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, TEMPLATES
+from parity_bar import grad_close, rel_errors
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,9 +28,16 @@ def _setup(pkg, name, B, S, ratio=1, ell=1, seed=0, no_mask=True, imn=True):
 
 
 def _close(got, ref, tol=1e-4):
+    """FORWARD values (image channels, normals: O(1) quantities): absolute bar, as north_star states it for RGBA."""
     scale = max(1.0, float(np.abs(ref).max()))
     err = float(np.abs(got - ref).max())
     assert err <= tol * scale, (err, scale)
+
+
+def _gclose(got, ref, tol=1e-4, what=""):
+    """GRADIENTS: max|got - ref| <= tol * max|ref|, NO floor of 1 (tests/parity_bar.py says why): a zero, a mis-scaled or a partly
+    missing gradient fails whatever the gradient's magnitude."""
+    grad_close(got, ref, rtol=tol, what=what)
 
 
 @pytest.mark.parametrize("name,B,S,ratio,no_mask,seed", [
@@ -67,8 +76,71 @@ def test_render_loss_backward_matches_oracle(pkg, oracle, name, B, S, ratio, no_
         if k == "bg" and not no_mask:
             assert datt[k].grad is None
             continue
-        _close(datt[k].grad.cpu().numpy(), g_o[k])
+        _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
         assert np.abs(g_o[k]).max() > 0
+
+
+@pytest.mark.parametrize("label,name,B,S,seed", [
+    ("config 1", "sphere", 4, 64, 0),
+    ("config 2 (full size)", "smpl_uv_642", 48, 128, 0),
+    ("config 5 (one image)", "smpl_uv", 1, 512, 0),
+])
+def test_fused_backward_under_a_unit_scale_upstream_gradient_matches_oracle(pkg, oracle, label, name, B, S, seed):
+    """The product path's backward (pixel_bwd -> gather_bwd -> vertex_bwd through mm_render_backward) driven by an O(1) upstream gradient --
+    (rgbs * w).sum() + (face_normals * wfn).sum(), w and wfn ~ N(0,1) -- instead of the batch-mean loss, whose gradients are 1e-8 ... 1e-2
+    large: every one of the eight input gradients is O(1) ... O(1e4) here and must agree with the oracle's to 1e-4 of its own maximum.
+    (A case the fp32 oracle itself cannot hold against its float64 form would be decided by the float64 backward and pass as 'cond':
+    none does -- profiles/r05_parity_relative.md.)"""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, seed=seed)
+    rng = np.random.default_rng(seed + 77)
+    w = rng.normal(size=(B, H, W, 4)).astype(np.float32)
+    wfn = rng.normal(size=(B, dr.num_faces, 3)).astype(np.float32)
+    rgbs, out = dr.render(no_mask=True, **datt)
+    ((rgbs.permute(0, 2, 3, 1) * torch.from_numpy(w).to(dev)).sum() + (out["face_normals"] * torch.from_numpy(wfn).to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, True, proj)
+    assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
+    g_o = oracle.render_backward(inp, H, W, True, proj, w, wfn)
+    g64 = {}
+
+    def ref64(k):
+        if not g64:
+            g64.update(oracle.render_backward(inp, H, W, True, proj, w.astype(np.float64), wfn.astype(np.float64), dtype=np.float64))
+        return g64[k]
+    verdicts = {}
+    for k in LEAVES:
+        assert float(np.abs(g_o[k]).max()) > 0.5, (k, "the upstream gradient was meant to make every input gradient O(1) or larger")
+        verdicts[k] = grad_close(datt[k].grad, g_o[k], rtol=1e-4, what="%s, %s" % (label, k), ref64=lambda k=k: ref64(k))
+    assert all(v == "ok" for v in verdicts.values()), verdicts      # (a 'cond' here would be news: say so instead of passing silently)
+
+
+def test_the_gradient_bar_rejects_zero_scaled_and_partly_missing_gradients(pkg, oracle):
+    """Mutation check of the bar itself at BASELINE config 2 (the bench's batch), for every one of the eight inputs: fed zeros, the reference
+    scaled by 1 + 1e-3, or the true HIP gradient with ONE image's share removed, the comparison must FAIL -- and it must pass the true HIP
+    gradient.  The bar of rounds 1-4 (1e-4 * max(1, max|ref|)) is evaluated beside it: it accepts the zero gradient for four of the eight
+    inputs of this batch, which is why it was replaced."""
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 48, 128, seed=0)
+    rgbs, out = dr.render(no_mask=True, **datt)
+    dr.recon_data(rgbs, gt.to(dev), no_mask=True).backward()
+    torch.cuda.synchronize()
+    rgba_o, fidx_o, _, _ = oracle.render_forward(inp, H, W, True, proj)
+    _, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+    g_o = oracle.render_backward(inp, H, W, True, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None)
+    old_bar_accepts_zero = {}
+    for k in LEAVES:
+        ref = g_o[k]; got = datt[k].grad.cpu().numpy()
+        assert grad_close(got, ref, what=k) == "ok"
+        with pytest.raises(AssertionError):
+            grad_close(np.zeros_like(ref), ref, what=k + " (zeros)")
+        with pytest.raises(AssertionError):
+            grad_close(ref * np.float32(1.001), ref, what=k + " (scaled)")
+        worst = int(np.abs(ref.reshape(48, -1)).max(1).argmax())
+        part = got.copy(); part[worst] = 0
+        with pytest.raises(AssertionError):
+            grad_close(part, ref, what=k + " (one image missing)")
+        old_bar_accepts_zero[k] = float(np.abs(ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    # the whole texture / background / light / azimuth gradient of this batch-mean loss is smaller than 1e-4: the old bar could not fail for them
+    assert all(old_bar_accepts_zero[k] for k in ("textures", "bg", "lights", "azimuths")), old_bar_accepts_zero
 
 
 @pytest.mark.parametrize("name,B,S,ratio,no_mask,seed,dist", [
@@ -127,7 +199,7 @@ def test_soft_mask_truncation_and_margins_match_oracle(pkg, oracle, knum, boxlen
     assert ((alpha > 0.01) & (alpha < 0.99)).mean() > 0.005          # there is a silhouette band to get wrong
     _close(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
     for k in LEAVES:
-        _close(datt[k].grad.cpu().numpy(), g_o[k])
+        _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
 
 
 @pytest.mark.parametrize("name,B,S,dist", [("sphere", 6, 128, 1.45), ("smpl_uv_642", 4, 200, 1.6)])
@@ -150,7 +222,7 @@ def test_close_camera_huge_face_boxes_match_oracle(pkg, oracle, name, B, S, dist
     assert int(((ext[..., 0] * ext[..., 1]) > 512).sum()) > 10
     _close(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
     for k in LEAVES:
-        _close(datt[k].grad.cpu().numpy(), g_o[k])
+        _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
 
 
 def test_texture_record_pool_overflow_is_loud_and_a_larger_workspace_holds_it(pkg, oracle):
@@ -183,7 +255,7 @@ def test_texture_record_pool_overflow_is_loud_and_a_larger_workspace_holds_it(pk
     assert torch.isnan(datt["textures"].grad).all()                # loud, in every texel of every image that lost records
     for k in LEAVES:
         if k != "textures":
-            _close(datt[k].grad.cpu().numpy(), g_o[k])
+            _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
     # ... and loud WITHOUT a diagnostic switch or a synchronisation of the caller's: the backward added the dropped records to the object's pinned
     # status word (MMRenderDesc.status_flag), and the next render of this object -- any node flavour -- raises
     assert dr.poll_dropped_records(reset=False) > 0
@@ -199,7 +271,7 @@ def test_texture_record_pool_overflow_is_loud_and_a_larger_workspace_holds_it(pk
     loss.backward()
     assert np.abs(g_o["textures"]).max() > 0
     for k in LEAVES:
-        _close(datt[k].grad.cpu().numpy(), g_o[k])
+        _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
 
 
 @pytest.mark.parametrize("bit", ["OPT_CULL_STRICT", "OPT_SOFT_SKIP_CULLED", "OPT_BBOX_HALF_OPEN", "OPT_BBOX_MIN_CLOSED_MAX_OPEN", "OPT_BARY_ONE_MINUS", "OPT_SH_ORDER_XYZ",
@@ -230,7 +302,7 @@ def test_appendix_c_switches_match_the_oracle(pkg, oracle, bit):
     assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
     _close(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
     for k in LEAVES:
-        _close(datt[k].grad.cpu().numpy(), g_o[k])
+        _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
     if bit in ("OPT_SOFT_SKIP_CULLED", "OPT_SH_ORDER_XYZ", "ALL"):             # these change every silhouette pixel / every lit pixel
         assert float((base_rgbs - rgbs.detach()).abs().max()) > 1e-3
     # (2)
@@ -285,7 +357,7 @@ def test_fuzz_regressions_pixel_pass_recomputes_the_forward_bit_for_bit(pkg, ora
     for k in LEAVES:
         if k == "bg" and not no_mask:
             continue
-        _close(datt[k].grad.cpu().numpy(), g_o[k], 2e-5)
+        _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
 
 
 def test_backward_twice_after_one_forward(pkg):
@@ -297,7 +369,7 @@ def test_backward_twice_after_one_forward(pkg):
     first = {k: datt[k].grad.clone() for k in LEAVES}
     loss.backward()
     for k in LEAVES:
-        _close(datt[k].grad.cpu().numpy(), 2.0 * first[k].cpu().numpy(), 1e-6)
+        _gclose(datt[k].grad.cpu().numpy(), 2.0 * first[k].cpu().numpy(), 1e-6)
         assert float(first[k].abs().max()) > 0
 
 
@@ -330,7 +402,7 @@ def test_render_recon_is_render_plus_recon_data(pkg):
         got.append((float(loss), rgbs.detach().clone(), {k: datt[k].grad.clone() for k in LEAVES}))
     assert abs(got[0][0] - got[1][0]) < 2e-6 and torch.equal(got[0][1], got[1][1])
     for k in LEAVES:
-        _close(got[1][2][k].cpu().numpy(), got[0][2][k].cpu().numpy(), 2e-5)
+        _gclose(got[1][2][k].cpu().numpy(), got[0][2][k].cpu().numpy(), 2e-5)
         assert float(got[1][2][k].abs().max()) > 0
 
 
@@ -455,7 +527,7 @@ def test_geometry_only_render_is_the_render_without_the_image(pkg):
     tot = (out_g["face_normals"] * w).sum()
     tot.backward(retain_graph=True)
     for k, r in ref.items():
-        _close(lv[k].grad.cpu().numpy(), r.cpu().numpy(), 1e-6)
+        _gclose(lv[k].grad.cpu().numpy(), r.cpu().numpy(), 1e-6)
     assert lv["textures"].grad is None and lv["lights"].grad is None and lv["bg"].grad is None
     first = {k: lv[k].grad.clone() for k in ref}
     tot.backward()                                               # a second backward on the same workspace: the arrival counter was left clean
@@ -682,7 +754,7 @@ def test_stress_size_batch_independence_and_four_images_against_oracle(pkg, orac
         # and for the IoU term alike (both are means of per-image terms)
         dr.recon_data(r1, gt[k:k + 1].to(dev), no_mask=True).backward()
         for kk in LEAVES:
-            _close(datt[kk].grad[k].cpu().numpy() * B, one[kk].grad[0].cpu().numpy(), 2e-5)
+            _gclose(datt[kk].grad[k].cpu().numpy() * B, one[kk].grad[0].cpu().numpy(), 2e-5)
         # the oracle on that one image
         inp1 = {kk: (v[k:k + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for kk, v in inp.items()}
         rgba_o, fidx_o, _, _ = oracle.render_forward(inp1, H, W, True, proj)
@@ -690,7 +762,7 @@ def test_stress_size_batch_independence_and_four_images_against_oracle(pkg, orac
         _close(r1[0].detach().permute(1, 2, 0).cpu().numpy(), rgba_o[0])
         loss_o, g_o = oracle.step(inp1, gt[k:k + 1].numpy(), H, W, True, proj, image_weight=dr.image_weight)
         for kk in LEAVES:
-            _close(one[kk].grad.cpu().numpy(), g_o[kk])
+            _gclose(one[kk].grad.cpu().numpy(), g_o[kk], what=kk)
 
 
 @pytest.mark.parametrize("use_ext", [True, False])
@@ -767,8 +839,8 @@ def test_fused_step_matches_oracle_and_unfused(pkg, oracle, name, B, S, seed):
     assert abs(float(fused.loss) - loss_o) < 2e-5 and abs(float(unfused.loss) - loss_o) < 2e-5
     assert torch.equal(fused.face_idx, unfused.face_idx) and torch.equal(fused.rgba, unfused.rgba)
     for k in LEAVES:
-        _close(fused.grads[k].cpu().numpy() / 0.5, g_o[k])
-        _close(unfused.grads[k].cpu().numpy() / 0.5, g_o[k])
+        _gclose(fused.grads[k].cpu().numpy() / 0.5, g_o[k], what='fused ' + k)
+        _gclose(unfused.grads[k].cpu().numpy() / 0.5, g_o[k], what='unfused ' + k)
 
 
 def test_chamfer_matches_bruteforce(pkg):
@@ -828,7 +900,7 @@ def test_concurrent_steps_on_four_streams_match_the_serial_result(pkg):
         assert float(st.loss) == loss            # the fused loss is a sum of exact integer (fixed-point) sums: bitwise repeatable under overlap
         assert torch.equal(st.face_idx, fidx) and torch.equal(st.rgba, rgba)
         for k, g in grads.items():
-            _close(st.grads[k].cpu().numpy(), g.cpu().numpy(), 2e-6)
+            _gclose(st.grads[k].cpu().numpy(), g.cpu().numpy(), 2e-6)
 
 
 @pytest.mark.parametrize("name,B,S,ratio", [("sphere", 3, 64, 1), ("smpl_uv_642", 4, 128, 2), ("sphere", 2, 36, 1)])

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as Fnn
 
 from conftest import ROOT, TEMPLATES, make_inputs
+from parity_bar import grad_close
 
 pytestmark = pytest.mark.gpu
 SHIM = os.path.join(ROOT, "3d-magic-mirror_amd", "shim")
@@ -26,10 +27,16 @@ def kal():
 
 
 def _close(got, ref, tol=1e-4):
+    """forward values (O(1) quantities): absolute bar"""
     got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
     scale = max(1.0, float(np.abs(ref).max()))
     err = float(np.abs(got - ref).max())
     assert err <= tol * scale, (err, scale)
+
+
+def _gclose(got, ref, tol=1e-4, what=""):
+    """gradients: relative to the reference gradient's own maximum, no floor (tests/parity_bar.py)"""
+    grad_close(got, ref, rtol=tol, what=what)
 
 
 def _dev(a, grad=False):
@@ -57,14 +64,14 @@ def test_prepare_vertices(kal, oracle, name, B):
     d1, d2, d3 = (rng.normal(size=s).astype(np.float32) for s in (fvc_o.shape, fvi_o.shape, fn_o.shape))
     (fvc * _dev(d1)).sum().add((fvi * _dev(d2)).sum()).add((fn * _dev(d3)).sum()).backward()
     dv_o, dT_o = oracle.prepare_vertices_backward(inp["vertices"], inp["faces"], T, proj, d1, d2, d3)
-    _close(v.grad, dv_o)
-    _close(Tt.grad, dT_o)
+    _gclose(v.grad, dv_o)
+    _gclose(Tt.grad, dT_o)
     # only one of the three outputs used (the others arrive as None)
     v2 = _dev(inp["vertices"], True)
     _, fvi2, _ = kal.render.mesh.prepare_vertices(v2, faces, cam_proj, camera_transform=_dev(T))
     (fvi2 * _dev(d2)).sum().backward()
     dv2, _ = oracle.prepare_vertices_backward(inp["vertices"], inp["faces"], T, proj, None, d2, None)
-    _close(v2.grad, dv2)
+    _gclose(v2.grad, dv2)
     # camera_rot / camera_trans form = (p - t) @ R^T
     R = torch.linalg.qr(torch.randn(B, 3, 3))[0]
     t = torch.randn(B, 3) * 0.1 + torch.tensor([0., 0., 3.])
@@ -91,7 +98,7 @@ def test_face_normals(kal, oracle, unit):
     w = torch.randn(n.shape, dtype=torch.double)
     (n * w).sum().backward()
     (out * w.float().cuda()).sum().backward()
-    _close(fv.grad, ref_in.grad.numpy())
+    _gclose(fv.grad, ref_in.grad.numpy())
 
 
 @pytest.mark.parametrize("name,B,S,kw", [
@@ -129,14 +136,14 @@ def test_dibr_rasterization(kal, oracle, name, B, S, kw):
     (torch.cat([texmask, texcoord, imnormal], -1) * _dev(g_i)).sum().add((soft * _dev(g_s)).sum()).backward()
     dfvi_o, dfeat_o = oracle.rasterize_backward(g_i, fidx_o, fvi_o, cat)
     dfvi_o = dfvi_o + oracle.soft_mask_backward(g_s, fidx_o, fvi_o, prob, idx, typ, sigmainv=kw.get("sigmainv", 7000.0))
-    _close(fvi.grad, dfvi_o)
-    _close(torch.cat([f.grad for f in feats], -1), dfeat_o)
+    _gclose(fvi.grad, dfvi_o)
+    _gclose(torch.cat([f.grad for f in feats], -1), dfeat_o)
     # a single tensor instead of a list comes back as a single tensor; the soft mask alone back-propagates too
     fvi2 = _dev(fvi_o, True)
     one, soft2, fidx2 = kal.render.mesh.dibr_rasterization(S, S, _dev(fvc_o[..., 2]), fvi2, _dev(cat), _dev(fn_o[..., 2]), **kw)
     assert torch.is_tensor(one) and one.shape == (B, S, S, 6) and torch.equal(fidx2, fidx) and torch.equal(soft2, soft.detach())
     (soft2 * _dev(g_s)).sum().backward()
-    _close(fvi2.grad, oracle.soft_mask_backward(g_s, fidx_o, fvi_o, prob, idx, typ, sigmainv=kw.get("sigmainv", 7000.0)))
+    _gclose(fvi2.grad, oracle.soft_mask_backward(g_s, fidx_o, fvi_o, prob, idx, typ, sigmainv=kw.get("sigmainv", 7000.0)))
 
 
 def test_texture_mapping(kal, oracle):
@@ -154,8 +161,8 @@ def test_texture_mapping(kal, oracle):
     assert np.array_equal(out.detach().cpu().numpy().reshape(B, -1, C), ref)                 # same expressions as the oracle
     out.backward(dout.cuda())
     duv, dtex = oracle.texture_mapping_backward(uv.reshape(B, -1, 2).numpy(), tex.numpy(), dout.reshape(B, -1, C).numpy())
-    _close(uvd.grad.reshape(B, -1, 2), duv)
-    _close(texd.grad, dtex)
+    _gclose(uvd.grad.reshape(B, -1, 2), duv)
+    _gclose(texd.grad, dtex)
     # (B,N,2) coordinates and nearest mode vs torch's own grid_sample
     uv2 = uv.reshape(B, -1, 2)
     near = kal.render.mesh.texture_mapping(uv2.cuda(), tex.cuda())                          # default mode is 'nearest', as upstream
@@ -180,8 +187,8 @@ def test_spherical_harmonic_lighting(kal, oracle):
     dc = torch.randn(B, H, W, generator=g)
     out.backward(dc.cuda())
     dn, dl = oracle.sh_lighting_backward(n.reshape(B, -1, 3).numpy(), lights.numpy(), dc.reshape(B, -1).numpy())
-    _close(nd.grad.reshape(B, -1, 3), dn)
-    _close(ld.grad, dl)
+    _gclose(nd.grad.reshape(B, -1, 3), dn)
+    _gclose(ld.grad, dl)
 
 
 def test_mask_iou(kal, oracle):
@@ -196,7 +203,7 @@ def test_mask_iou(kal, oracle):
     ref = 1.0 - torch.mean(mul.reshape(B, -1).sum(1) / (((a2 + b2) - mul).reshape(B, -1).sum(1) + 1e-10))
     assert abs(float(loss) - float(ref)) < 1e-6
     (loss * 3.0).backward(); (ref * 3.0).backward()
-    _close(ad.grad, a2.grad.numpy()); _close(bd.grad, b2.grad.numpy())
+    _gclose(ad.grad, a2.grad.numpy()); _gclose(bd.grad, b2.grad.numpy())
     # the oracle's recon_data with image_weight 0 is exactly this term
     m = np.zeros((B, 4, H, W), np.float32); m[:, 3] = a.numpy()
     t = np.zeros((B, 4, H, W), np.float32); t[:, 3] = b.numpy()
@@ -282,12 +289,12 @@ def test_operators_composed_like_the_reference_match_the_fused_render(pkg, kal, 
     for k in ("vertices", "textures", "lights", "bg"):
         if k == "bg" and not no_mask:
             continue
-        _close(A1[k].grad, A2[k].grad.cpu().numpy(), 2e-4)
+        _gclose(A1[k].grad, A2[k].grad.cpu().numpy(), 2e-4)
         assert float(A2[k].grad.abs().max()) > 0
     dd, de, da, db = oracle.camera_backward(att["distances"].numpy(), att["elevations"].numpy(), att["azimuths"].numpy(), att["biases"].numpy(),
                                             T.grad.cpu().numpy())
     for k, ref in (("distances", dd), ("elevations", de), ("azimuths", da), ("biases", db)):
-        _close(A2[k].grad, ref, 2e-4)
+        _gclose(A2[k].grad, ref, 2e-4)
 
 
 @pytest.mark.parametrize("name", ["sphere", "smpl_uv"])

@@ -4,7 +4,9 @@ Flags that matter:
   --offload-arch=gfx950   CDNA4 only; no other targets, no compatibility layers
   -ffp-contract=off       every fp32 expression rounds as written (face_idx bit-parity with the CPU oracle); HIP's default
                           correctly rounded fp32 '/' and sqrtf are kept for the same reason
-  -munsafe-fp-atomics     atomicAdd(float) lowers to the hardware global_atomic_add_f32 (no CAS loop)
+  -munsafe-fp-atomics     atomicAdd(float) lowers to the hardware global_atomic_add_f32 / ds_add_f32 (no CAS loop) -- ONLY for the three translation units
+                          that still hold a float atomic (FP_ATOMICS below: the un-fused operators' fallback forms, README "float atomics"); the render
+                          path, recon_data and every other 8(f) kernel are compiled without it and contain none
 Per file: the gathers of the backward (mm_backward.hip) are held to 1e-4, not to the bit, and bound by instruction issue, so they are
 compiled with fma contraction and the 2.5-ulp division/sqrt sequences (about a third fewer vector instructions).  The pixel pass of the
 backward (mm_pixel_bwd.hip) recomputes the forward's per-pixel quantities and is compiled like the forward (see csrc/mm_backward.h).
@@ -21,10 +23,12 @@ LIB = os.path.join(HERE, "lib", "libmm_render.so")
 # (measured: same instruction count, +2 % images/s without it; the exact files lose 7 % instructions without it and keep it).
 EXACT = ["-ffp-contract=off"]
 RELAXED = ["-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
-SOURCES = {"mm_abi.hip": EXACT, "mm_reg.hip": EXACT, "mm_texflow.hip": EXACT, "mm_attloss.hip": EXACT, "mm_vertex.hip": EXACT, "mm_raster.hip": EXACT,
-           "mm_backward.hip": RELAXED, "mm_pixel_bwd.hip": EXACT, "mm_loss.hip": EXACT, "mm_nn.hip": EXACT, "mm_dibr.hip": EXACT, "mm_ops.hip": EXACT}
+FP_ATOMICS = ["-munsafe-fp-atomics"]     # mm_dibr.hip (features of more than 8 channels: LDS adds within one wave), mm_ops.hip (texture_mapping backward WITHOUT a
+                                        # workspace), mm_texflow.hip (gradient to the sampled image): tests/test_gpu_float_atomics.py pins their run-to-run spread
+SOURCES = {"mm_abi.hip": EXACT, "mm_reg.hip": EXACT, "mm_texflow.hip": EXACT + FP_ATOMICS, "mm_attloss.hip": EXACT, "mm_vertex.hip": EXACT, "mm_raster.hip": EXACT,
+           "mm_backward.hip": RELAXED, "mm_pixel_bwd.hip": EXACT, "mm_loss.hip": EXACT, "mm_nn.hip": EXACT, "mm_dibr.hip": EXACT + FP_ATOMICS, "mm_ops.hip": EXACT + FP_ATOMICS}
 HEADERS = ["mm_device.h", "mm_raster_common.h", "mm_raster_walk.h", "mm_backward.h", "mm_order.h", os.path.join("..", "..", "include", "mm_render.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
 # A TEST build of the same sources (tests/test_gpu_self_offsets.py): the backward's plan workgroups publish the texture-record list offsets

@@ -304,18 +304,22 @@ __host__ __device__ inline size_t texmap_acc_offset(int B) { return align256((si
 __global__ __launch_bounds__(256) void texmap_max_kernel(MMTexMapDesc d, const float* grad_out, unsigned* gmax) {
     const int b = blockIdx.y;
     const size_t n = (size_t)d.N * d.C;
-    float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(grad_out[(size_t)b * n + i]));
-    __shared__ float s_m[4];
-    m = wave_max(m);
+    // The maximum is taken over the BIT PATTERNS of |grad_out| (an unsigned max): finite < inf < NaN in that order, so a single non-finite
+    // upstream value survives the reduction (fmaxf would drop a NaN) and the image's texture gradient is poisoned below -- as ATen's
+    // grid_sampler backward and the float-atomic path propagate it -- instead of silently coming out as zeros.
+    unsigned m = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = max(m, __float_as_uint(grad_out[(size_t)b * n + i]) & 0x7FFFFFFFu);
+    __shared__ unsigned s_m[4];
+    m = (unsigned)wave_max_i32((int)m);                            // (31-bit values: the signed maximum is the unsigned one)
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
     // ONE atomic per workgroup (a few per image: thousands of waves on 48 words queued at the memory side took 60 us)
     if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-        if (m > 0.f) atomicMax(gmax + b, __float_as_uint(m));      // (non-negative floats order like their bits; NaN / inf: an inf scale below)
+        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m != 0u) atomicMax(gmax + b, m);
     }
 }
+__device__ inline bool texmap_nonfinite(unsigned maxbits) { return maxbits >= 0x7F800000u; }   // some upstream value of the image is inf or NaN
 // every contribution is |grad_out| * weight with weight <= 1: the image's largest is placed at 2^40, 2^22 of them fit a 63-bit sum
 __device__ inline float texmap_scale(unsigned maxbits, float& inv) {
     const float M = __uint_as_float(maxbits);
@@ -331,6 +335,8 @@ __global__ __launch_bounds__(256) void texmap_finish_kernel(MMTexMapDesc d, cons
     const size_t n = (size_t)d.C * d.Ht * d.Wt;
     float inv;
     (void)texmap_scale(gmax[b], inv);
+    // a non-finite upstream gradient: no fixed-point scale exists -- every texel of the image says so (NaN), never a silent zero
+    if (texmap_nonfinite(gmax[b])) inv = __builtin_nanf("");
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) grad_textures[(size_t)b * n + i] = (float)acc[(size_t)b * n + i] * inv;
 }
 
@@ -346,8 +352,8 @@ __global__ __launch_bounds__(256) void texmap_bwd_kernel(MMTexMapDesc d, MMTexMa
     }
     // one contribution to texel `idx` of the (B,C,Ht,Wt) gradient: a 64-bit integer add (exact, commutative) or a float atomic
     auto scatter = [&](size_t idx, float v) {
-        if (kFixed) atomicAdd((unsigned long long*)(acc64 + idx), (unsigned long long)__float2ll_rn(v * scale));
-        else atomicAdd(g.grad_textures + idx, v);
+        if (kFixed) { if (scale != 0.f) atomicAdd((unsigned long long*)(acc64 + idx), (unsigned long long)__float2ll_rn(v * scale)); }   // (scale 0: all-zero or non-finite
+        else atomicAdd(g.grad_textures + idx, v);                                                                                       //  upstream -- nothing to convert; finish writes 0 / NaN)
     };
     const size_t p = (size_t)b * d.N + n;
     const float u = d.uv[p * 2], v = d.uv[p * 2 + 1];

@@ -146,6 +146,29 @@ def test_dibr_rasterization(kal, oracle, name, B, S, kw):
     _gclose(fvi2.grad, oracle.soft_mask_backward(g_s, fidx_o, fvi_o, prob, idx, typ, sigmainv=kw.get("sigmainv", 7000.0)))
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), -float("inf")])
+def test_texture_mapping_backward_propagates_non_finite_upstream_gradients(kal, bad):
+    """The deterministic texture-gradient scatter (64-bit fixed point at a scale taken from the image's largest |upstream value|) has no scale for
+    a NaN / inf upstream gradient: the image's WHOLE texture gradient then comes out as NaN -- loud, as ATen's grid_sampler backward and kaolin
+    propagate it at the texels touched -- never as zeros (a training loop's NaN / inf check on the gradients must keep working).  The other
+    images of the batch are unaffected, and so is the coordinate gradient's own propagation."""
+    g = torch.Generator().manual_seed(7)
+    B, N, C, Ht, Wt = 3, 500, 3, 32, 16
+    uv = torch.rand(B, N, 2, generator=g)
+    tex = torch.rand(B, C, Ht, Wt, generator=g)
+    dout = torch.randn(B, N, C, generator=g)
+    clean_uv, clean_tex = uv.cuda().requires_grad_(True), tex.cuda().requires_grad_(True)
+    kal.render.mesh.texture_mapping(clean_uv, clean_tex, mode='bilinear').backward(dout.cuda())
+    dout_bad = dout.clone(); dout_bad[1, 137, 2] = bad
+    uvd, texd = uv.cuda().requires_grad_(True), tex.cuda().requires_grad_(True)
+    kal.render.mesh.texture_mapping(uvd, texd, mode='bilinear').backward(dout_bad.cuda())
+    assert torch.isnan(texd.grad[1]).all()
+    assert torch.equal(texd.grad[0], clean_tex.grad[0]) and torch.equal(texd.grad[2], clean_tex.grad[2])
+    assert not torch.isfinite(uvd.grad[1, 137]).all() and torch.equal(uvd.grad[0], clean_uv.grad[0])
+    keep = torch.ones(N, dtype=torch.bool); keep[137] = False
+    assert torch.equal(uvd.grad[1][keep.cuda()], clean_uv.grad[1][keep.cuda()])
+
+
 def test_texture_mapping(kal, oracle):
     g = torch.Generator().manual_seed(5)
     B, H, W, C, Ht, Wt = 3, 20, 24, 3, 32, 16

@@ -1,5 +1,5 @@
-// mm_order.h -- the tile sort of the forward walk (gfx950), shared by the stand-alone order kernel (mm_raster.hip) and by the per-image
-// vertex stage that sorts its own image (mm_vertex.hip: vertex_image_fwd_kernel).
+// mm_order.h -- the tile sort of the forward walk (gfx950), used by the order kernel (mm_raster.hip).  (A per-image vertex stage that sorted its
+// own image was built in round 4, measured slower and removed: profiles/r04_per_image_stages_ab.md; the sort stayed in this header.)
 //
 // Orders the tile slots (16x16 block * 4 + quadrant) of ONE image by their candidate count, descending: a counting sort in LDS (keys clipped
 // to 1023), linear in the slots.  Only the launch ORDER of raster_fwd depends on it -- slots with equal counts may come out in any order,

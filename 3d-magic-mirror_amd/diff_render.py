@@ -509,23 +509,24 @@ class DiffRender(object):
         self.last_face_idx = face_idx
         return loss, rgba.permute(0, 3, 1, 2), attributes
 
-    def graphed_step(self, example_attributes, gt_data, no_mask=False, fast_leaf_grads=False):
+    def graphed_step(self, example_attributes, gt_data, no_mask=False, fast_leaf_grads=False, copy_leaf_grads=False):
         """A captured (HIP-graph) render + recon_data + backward for attribute tensors of the example's shapes: returns a callable
         ``g(gt_data, **attributes) -> (loss, rgbs, attributes)`` with the semantics of ``render_recon`` whose forward and backward are one
         graph launch each (step.GraphedRenderRecon: static input slots ``g.inputs`` / ``g.gt``, static outputs).  The call sites it
-        serves: trainer.py:276 (render), :441 (recon_data), :509-518 (backward).  ``fast_leaf_grads``: opt-in, leaf attributes get the
-        static gradient buffers as ``.grad`` without going through the engine (step._graphed_input_grads)."""
+        serves: trainer.py:276 (render), :441 (recon_data), :509-518 (backward).  Gradients go through the autograd engine; a leaf attribute's
+        ``.grad`` IS the object's static gradient memory until the next call (no copy; ``copy_leaf_grads=True`` hands private copies instead, as do
+        leaves with hooks).  ``fast_leaf_grads``: opt-in, leaves get the static buffers as ``.grad`` without the engine (step._graphed_input_grads)."""
         from .step import GraphedRenderRecon
         N.require_device(*[v for k, v in example_attributes.items() if torch.is_tensor(v)], gt_data)
-        return GraphedRenderRecon(self, example_attributes, gt_data, no_mask=no_mask, fast_leaf_grads=fast_leaf_grads)
+        return GraphedRenderRecon(self, example_attributes, gt_data, no_mask=no_mask, fast_leaf_grads=fast_leaf_grads, copy_leaf_grads=copy_leaf_grads)
 
-    def graphed_render(self, example_attributes, no_mask=False, fast_leaf_grads=False):
+    def graphed_render(self, example_attributes, no_mask=False, fast_leaf_grads=False, copy_leaf_grads=False):
         """A captured (HIP-graph) ``render`` + backward for attribute tensors of the example's shapes: a callable ``g(**attributes) -> (rgbs,
         attributes)`` like ``render`` (step.GraphedRender).  For the renders of an iteration whose images feed a loss outside this class
         (trainer.py:345-367); one object per such render -- its outputs are static memory."""
         from .step import GraphedRender
         N.require_device(*[v for k, v in example_attributes.items() if torch.is_tensor(v)])
-        return GraphedRender(self, example_attributes, no_mask=no_mask, fast_leaf_grads=fast_leaf_grads)
+        return GraphedRender(self, example_attributes, no_mask=no_mask, fast_leaf_grads=fast_leaf_grads, copy_leaf_grads=copy_leaf_grads)
 
     # ---- networks.py:364-390 -------------------------------------------------------------------------------------
     def recon_data(self, pred_data, gt_data, no_mask=False, contour=0):

@@ -33,24 +33,40 @@ def _f32(t, dev):
     return N.as_f32(t, dev)
 
 
-_STATUS = None            # one pinned int32 the device adds vertex ids outside the cloud to (mm_build_vertex_corner_csr_device); polled, never waited for
+_STATUS = {}              # per DEVICE: one pinned int32 the device adds vertex ids outside the cloud to (mm_build_vertex_corner_csr_device); polled, never waited for
 _CSR_MAX_V = 12288        # MM_CSR_MAX_V (csrc/mm_ops.hip)
 
 
-def _status_word():
-    global _STATUS
-    if _STATUS is None:
-        _STATUS = torch.zeros(1, dtype=torch.int32).pin_memory()
-    return _STATUS
+def _status_word(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _STATUS:
+        _STATUS[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return _STATUS[key]
 
 
-def _raise_on_reported_faces():
-    """An EARLIER prepare_vertices saw vertex ids outside its cloud (reported by the device without a synchronisation; the ids were left out of
-    the gradient gather and clamped in the forward, never dereferenced)."""
-    if _STATUS is not None and int(_STATUS[0]) != 0:
-        n = int(_STATUS[0])
-        _STATUS[0] = 0
-        raise RuntimeError("prepare_vertices: an earlier call's faces held %d vertex ids outside [0, V)" % n)
+def poll_reported_faces(device=None, synchronize=False):
+    """DEFERRED ERROR of ``prepare_vertices``.  The call itself never waits for the device, so it cannot validate ``faces`` against V on the spot:
+    the device-side CSR builder counts vertex ids outside [0, V) into a pinned status word (one per device) -- such ids are clamped in the forward
+    and left out of the gradient gather, never dereferenced -- and the RuntimeError is raised by whoever looks at the word next: the next
+    ``prepare_vertices`` on that device, the backward of the offending call, or this function.  ``synchronize=True`` waits for the device first,
+    i.e. reports everything enqueued so far (use it once after set-up, or in tests); without it the poll costs nothing.  Returns None if clean."""
+    devs = list(_STATUS) if device is None else [(torch.device(device).type, torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())]
+    for key in devs:
+        w = _STATUS.get(key)
+        if w is None:
+            continue
+        if synchronize:
+            torch.cuda.synchronize(key[1])
+        n = int(w[0])
+        if n != 0:
+            w[0] = 0
+            raise RuntimeError("prepare_vertices: an earlier call's faces held %d vertex ids outside [0, V) (device %s:%d)" % (n, key[0], key[1]))
+    return None
+
+
+def _raise_on_reported_faces(dev):
+    """An EARLIER prepare_vertices on this device saw vertex ids outside its cloud (poll_reported_faces)."""
+    poll_reported_faces(dev)
 
 
 def _faces_tables(faces, V, dev):
@@ -64,7 +80,7 @@ def _faces_tables(faces, V, dev):
     off = torch.empty(V + 1, device=dev, dtype=torch.int32)
     items = torch.empty(3 * F, device=dev, dtype=torch.int32)
     if V <= _CSR_MAX_V:
-        N.check(N.lib().mm_build_vertex_corner_csr_device(V, F, N.ptr(fi), N.ptr(off), N.ptr(items), _status_word().data_ptr(), N.current_stream(dev)),
+        N.check(N.lib().mm_build_vertex_corner_csr_device(V, F, N.ptr(fi), N.ptr(off), N.ptr(items), _status_word(dev).data_ptr(), N.current_stream(dev)),
                 "mm_build_vertex_corner_csr_device")
     else:                                                        # (huge clouds: the host builder, with its read-back)
         fh = faces.detach().to("cpu", torch.int64)
@@ -100,6 +116,7 @@ class _PrepareFn(torch.autograd.Function):
     def backward(ctx, g_fvc, g_fvi, g_fn):
         vertices, transform, faces_i32, vc_off, vc_items, proj = ctx.saved_tensors
         dev = vertices.device
+        _raise_on_reported_faces(dev)                            # the forward's CSR builder has long finished by the time a backward runs on the host
         B, V, _ = vertices.shape
         c = lambda g: None if g is None else g.to(torch.float32).contiguous()
         g_fvc, g_fvi, g_fn = c(g_fvc), c(g_fvi), c(g_fn)
@@ -121,7 +138,8 @@ def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans
     """kaolin.render.mesh.prepare_vertices: (face_vertices_camera (B,F,3,3), face_vertices_image (B,F,3,2), face_normals (B,F,3)).
 
     ``camera_transform`` (B,4,3) is what the reference passes (networks.py:284-287).  With ``camera_rot`` (B,3,3) /
-    ``camera_trans`` (B,3) instead, kaolin's ``rotate_translate_points`` ((p - t) @ R^T) is folded into the same transform."""
+    ``camera_trans`` (B,3) instead, kaolin's ``rotate_translate_points`` ((p - t) @ R^T) is folded into the same transform.
+    NOTE -- deferred error: vertex ids of ``faces`` outside [0, V) are reported by a LATER call (``poll_reported_faces``), not by this one."""
     N.require_device(vertices)
     dev = vertices.device
     if camera_transform is None:
@@ -133,7 +151,7 @@ def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans
         raise RuntimeError("camera_transform must be (B,4,3), got %s" % (tuple(camera_transform.shape),))
     if faces.dim() != 2 or faces.shape[1] != 3:
         raise RuntimeError("faces must be (F,3), got %s" % (tuple(faces.shape),))
-    _raise_on_reported_faces()
+    _raise_on_reported_faces(dev)                                # (deferred: see poll_reported_faces)
     faces_i32, off, items = _faces_tables(faces, int(vertices.shape[1]), dev)
     proj = camera_proj.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()       # stays on the device: read by the kernels
     if proj.numel() != 3:

@@ -182,13 +182,26 @@ class RenderLossStep:
         return out
 
 
+def _leaf_has_hooks(t):
+    """A tensor hook or a post-accumulate-grad hook is registered on the leaf: its gradient must reach the engine as a tensor of its own."""
+    return bool(getattr(t, "_backward_hooks", None)) or bool(getattr(t, "_post_accumulate_grad_hooks", None))
+
+
 def _graphed_input_grads(owner, leaf_inputs, shapes, g):
     """What a graphed node hands back for its eight attribute inputs after the backward graph has run (g: the static gradient buffers).
-    Default: every input gets its gradient THROUGH THE ENGINE in the input's own shape -- a private copy for a leaf, a view of the static
-    buffer for a non-leaf (whose producer consumes it within this backward pass) -- so hooks fire, torch.autograd.grad works, and nothing the
-    caller holds aliases memory the next replay overwrites.  ``owner.fast_leaf_grads`` (opt-in): a LEAF input's ``.grad`` is assigned the static buffer itself (or accumulated
-    into) and the engine gets None -- eight copy launches fewer per step, for loops that only ever call ``loss.backward()`` and reset
-    ``.grad`` to None between steps; hooks do not fire and ``torch.autograd.grad`` sees no gradient on that path."""
+    Every input gets its gradient THROUGH THE ENGINE in the input's own shape:
+      * a non-leaf input: a view of the static buffer (its producer consumes it within this backward pass);
+      * a LEAF without hooks (what ``loss.backward()`` of a training loop meets: the consumer is the leaf's AccumulateGrad): a view of the static
+        buffer as well -- AccumulateGrad takes a gradient tensor nobody else holds as ``.grad`` without copying it, so ``.grad`` is the static
+        memory until the next replay, exactly as the class docstrings say (and as torch.cuda.make_graphed_callables behaves); a ``.grad`` that
+        is KEPT across steps is copied out before the next replay (``_GraphedFn.backward``), so accumulation keeps its meaning;
+      * a leaf WITH a tensor hook / post-accumulate hook, or every leaf of an object built with ``copy_leaf_grads=True``: a private copy (the hook
+        may keep or modify what it is handed; with the flag nothing the caller holds ever aliases static memory -- round 4's default).
+    Round 4 cloned for every leaf: eight copy launches per step (30 MB at B=48, 128x128) that made the captured path the slowest way to call
+    the class.  ``torch.autograd.grad(loss, leaf)`` through this node returns the view: static memory, overwritten by the next call -- the
+    contract of every output of a graphed object.
+    ``owner.fast_leaf_grads`` (opt-in) bypasses the engine altogether: a leaf's ``.grad`` is assigned the static buffer (or accumulated into) and
+    the engine gets None -- hooks do not fire and ``torch.autograd.grad`` sees no gradient on that path."""
     out = []
     for k, leaf, shp in zip(LEAVES, leaf_inputs, shapes):
         if g[k] is None or shp is None:
@@ -196,8 +209,8 @@ def _graphed_input_grads(owner, leaf_inputs, shapes, g):
         elif leaf is None:
             out.append(g[k].reshape(shp))                        # a non-leaf input: consumed by the producer's backward inside this pass
         elif not owner.fast_leaf_grads:
-            out.append(g[k].reshape(shp).clone())                # (a view would be STOLEN by AccumulateGrad -- its tensor object has one owner -- and
-                                                                 #  .grad would alias the static buffer after all: the copy is what keeps the caller's)
+            gk = g[k].reshape(shp)
+            out.append(gk.clone() if (owner.copy_leaf_grads or _leaf_has_hooks(leaf)) else gk)
         else:
             gk = g[k].reshape(shp)
             if leaf.grad is None:
@@ -253,11 +266,12 @@ class GraphedRenderRecon:
     The ``.grad`` of an attribute that is an autograd leaf IS that static memory until then (reset it to None between steps, as
     ``optimizer.zero_grad()`` does by default; a ``.grad`` that is kept is copied out first, so accumulation over steps stays correct).  Results are bit-identical to the eager path (same kernels, same launch order)."""
 
-    def __init__(self, dr, example_attributes, gt, no_mask=True, fast_leaf_grads=False):
+    def __init__(self, dr, example_attributes, gt, no_mask=True, fast_leaf_grads=False, copy_leaf_grads=False):
         dev = example_attributes["azimuths"].device
         f32 = lambda t: t.detach().to(torch.float32).contiguous().clone()
         self.dr, self.dev, self.no_mask = dr, dev, bool(no_mask)
         self.fast_leaf_grads = bool(fast_leaf_grads)             # see _graphed_input_grads
+        self.copy_leaf_grads = bool(copy_leaf_grads)
         self.inputs = {k: (f32(example_attributes[k]) if example_attributes.get(k) is not None and (k != "bg" or no_mask) else None) for k in LEAVES}
         self.gt = f32(gt)
         self.step = RenderLossStep(dr, self.inputs, self.gt, no_mask=no_mask, emit_imnormal=dr.emit_imnormal, fused=True)
@@ -363,11 +377,12 @@ class GraphedRender:
     the static gradient buffers as ``.grad``.  The upstream gradient of the image is copied into a static slot (50 MB at B=48, 256x256: the one
     copy this path cannot avoid -- the loss lives outside).  Bit-identical to the eager render."""
 
-    def __init__(self, dr, example_attributes, no_mask=True, fast_leaf_grads=False):
+    def __init__(self, dr, example_attributes, no_mask=True, fast_leaf_grads=False, copy_leaf_grads=False):
         dev = example_attributes["azimuths"].device
         f32 = lambda t: t.detach().to(torch.float32).contiguous().clone()
         self.dr, self.dev, self.no_mask = dr, dev, bool(no_mask)
         self.fast_leaf_grads = bool(fast_leaf_grads)             # see _graphed_input_grads
+        self.copy_leaf_grads = bool(copy_leaf_grads)
         self.inputs = {k: (f32(example_attributes[k]) if example_attributes.get(k) is not None and (k != "bg" or no_mask) else None) for k in LEAVES}
         B, H, W = self.inputs["azimuths"].shape[0], dr.render_height, dr.image_size
         self.step = RenderLossStep(dr, self.inputs, torch.zeros((B, 4, H, W), device=dev), no_mask=no_mask, emit_imnormal=dr.emit_imnormal, fused=False)

@@ -22,6 +22,8 @@ steps, each repetition bracketed by barrier + synchronize: the driver's short --
   value_api_graphed   the same step through DiffRender.graphed_step: forward and backward one captured HIP graph each behind one autograd node;
                       _slots: the caller writes its attributes into the graph's static input slots (no copies inside the call) and opts in to
                       fast_leaf_grads (leaf attributes get the static gradient buffers as .grad, not through the engine).
+  host_us_per_step    host time per step of each API flavour (and of the C-ABI step): 60 steps enqueued on an idle device, clock stopped before the
+                      device is waited for -- value_api* are host-bound, so they are comparable between boxes only next to this figure.
   value_shim          the UN-FUSED compatibility path: the kaolin-shaped operators of the import boundary called in the order of the reference's
                       DiffRender.render (networks.py:278-317; shim_chain.py) + recon_data + backward -- what a maintainer gets who only switches sys.path.
 Every stream rotates through --rotate distinct synthetic batches (default 8 per stream: > 256 MiB of inputs in total, more than
@@ -242,6 +244,19 @@ def main():
         torch.cuda.synchronize(dev); barrier()
         return par.max_over_ranks(time.perf_counter() - t0, dev)
 
+    def host_us(fn, n=60):
+        """Host time per call of fn: n calls enqueued back to back on an idle device, clock stopped BEFORE the device is waited for.  What a box's
+        host costs the class API per step (value_api* are host-bound: comparable between boxes only next to this figure); the median of 3."""
+        vals = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            vals.append((time.perf_counter() - t0) / n * 1e6)
+            torch.cuda.synchronize(dev)
+        return round(float(np.median(vals)), 1)
+
     def timed_median(fn, n, reps=None):
         """The timed region repeated: median over the repetitions (every one bracketed like timed()), and all of them."""
         ts_ = [timed(fn, n) for _ in range(max(1, reps or args.reps))]
@@ -378,6 +393,7 @@ def main():
     loss_value = float(step.loss) if args.mode != "torch" else None
 
     one_stream = api_value = api_fused_value = api_graphed_value = api_graphed_slots_value = shim_value = no_imn_value = None
+    host_us_per_step = {}
     e1, e1_all = elapsed, elapsed_all
     if args.mode == "eager":
         if reducer is not None:
@@ -404,10 +420,13 @@ def main():
             one_api()
         e2, _ = timed_median(one_api, args.api_steps, reps=3)
         api_value = round(world * B * args.api_steps / e2, 1)
+        host_us_per_step["c_abi_one_stream"] = host_us(one_single)
+        host_us_per_step["api"] = host_us(one_api)
         for _ in range(10):
             one_api_fused()
         e2f, _ = timed_median(one_api_fused, args.api_steps, reps=3)
         api_fused_value = round(world * B * args.api_steps / e2f, 1)
+        host_us_per_step["api_fused"] = host_us(one_api_fused)
         # DiffRender.graphed_step: (a) attributes arrive as fresh tensors and are copied into the static slots; (b) the caller writes into the slots
         gs = dr_api.graphed_step(batches[0][0][0], batches[0][0][1], no_mask=True)     # gradients through the autograd engine (default)
         gs_fast = dr_api.graphed_step(batches[0][0][0], batches[0][0][1], no_mask=True, fast_leaf_grads=True)   # opt-in: leaves get the static buffers as .grad
@@ -423,6 +442,7 @@ def main():
             one_api_graphed()
         e2g, _ = timed_median(one_api_graphed, args.api_steps, reps=3)
         api_graphed_value = round(world * B * args.api_steps / e2g, 1)
+        host_us_per_step["api_graphed"] = host_us(one_api_graphed)
         slot_leaves = {k: gs_fast.inputs[k].requires_grad_(True) for k in stepmod.LEAVES}
         slot_att = dict(batches[0][0][0]); slot_att.update(slot_leaves)
 
@@ -434,6 +454,7 @@ def main():
             one_api_graphed_slots()
         e2s, _ = timed_median(one_api_graphed_slots, args.api_steps, reps=3)
         api_graphed_slots_value = round(world * B * args.api_steps / e2s, 1)
+        host_us_per_step["api_graphed_slots"] = host_us(one_api_graphed_slots)
     if args.shim_steps > 0 and rank == 0:
         # the un-fused kaolin-shaped operator chain in the reference's order (networks.py:278-317): ~40 launches per render, float atomics
         try:
@@ -475,18 +496,22 @@ def main():
         # the mean over the profiled steps, without the rare sample that a host or clock hiccup stretched beyond three times the kernel's median
         # (one such step among thirty used to move a kernel's "average" by its whole duration); how many were dropped is reported
         dropped = 0
+        kernels_us_unfiltered = {}
         for k, v in acc.items():
             v = np.asarray(v, dtype=np.float64)
             keep = v <= 3.0 * np.median(v) if np.all(np.isfinite(v)) else np.ones(len(v), bool)
             dropped += int((~keep).sum())
             if np.isfinite(np.mean(v[keep])):
                 kernels_us[k] = float(np.mean(v[keep]))
+                kernels_us_unfiltered[k] = float(np.mean(v))
         dom = max(kernels_us, key=kernels_us.get)
-        nbytes = algorithmic_bytes(dom, B, dr.num_faces, dr.num_vertices, H * W, Ht * Wt, fused=not args.unfused, imnormal=True)
+        # what the TIMED step really moves: the loss is fused unless --unfused, and imnormal is counted iff the profiled step emits it
+        step_emits_imnormal = step.imnormal is not None
+        nbytes = algorithmic_bytes(dom, B, dr.num_faces, dr.num_vertices, H * W, Ht * Wt, fused=step.fused, imnormal=step_emits_imnormal)
         achieved = nbytes / (kernels_us[dom] * 1e-6) / 1e9
         traffic_all, tnote = load_counters("traffic", args.config)
         traffic_rw, _ = load_counters("traffic", args.config, suffix="_rw")
-        step_bytes = (140 * dr.num_faces + 36 * Ht * Wt + 56 * H * W + 12 * H * W) * B      # SURVEY 8(d)'s A + the imnormal output the step writes
+        step_bytes = (140 * dr.num_faces + 36 * Ht * Wt + 56 * H * W + (12 * H * W if step_emits_imnormal else 0)) * B   # SURVEY 8(d)'s A + the imnormal output the step writes
         step_us_one = (1e6 * B * world / one_stream) if one_stream else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": (traffic_all or {}).get(dom), "traffic_note": tnote,
@@ -494,10 +519,13 @@ def main():
                     "traffic_formula": "2*FETCH_SIZE + WRITE_SIZE (KiB x 1024), separate --pmc passes; per-pattern factors measured on this path's "
                                        "access patterns: profiles/r04_fetch_calibration.json",
                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(kernels_us[dom], 3),
+                    "avg_launch_us_unfiltered": round(kernels_us_unfiltered[dom], 3),
+                    "frac_unfiltered": round(nbytes / (kernels_us_unfiltered[dom] * 1e-6) / 1e9 / PEAK_HBM_GBPS, 5),
                     "avg_over": "%d profiled steps, %d kernel samples beyond 3x their kernel's median dropped" % (args.profile_steps, dropped),
                     "duration_source": "hip_events (recorded by the library around the launch on its own stream; ~2.5 us longer per kernel than "
                                        "rocprofv3's kernel-trace durations, which profiles/*_kernel_stats.md quote)",
-                    "algorithmic_includes": "face records 52F, texture 12T, rgba 16HW, face_idx 4HW, ground truth 16HW (fused loss), imnormal 12HW",
+                    "algorithmic_includes": "face records 52F, texture 12T, rgba 16HW, face_idx 4HW" + (", ground truth 16HW (fused loss)" if step.fused else "")
+                                            + (", imnormal 12HW" if step_emits_imnormal else ""),
                     "whole_step": {"algorithmic_bytes": step_bytes,
                                    "frac_overlapped": round(step_bytes / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBPS, 5),
                                    "frac_one_stream": round(step_bytes / (step_us_one * 1e-6) / 1e9 / PEAK_HBM_GBPS, 5) if step_us_one else None}}
@@ -602,7 +630,7 @@ def main():
             "ms_per_step_four_streams": round(elapsed / args.steps * 1e3, 4) if args.mode == "eager" else None,
             "value_without_imnormal": no_imn_value,
             "value_api": api_value, "value_api_fused": api_fused_value, "value_api_graphed": api_graphed_value,
-            "value_api_graphed_slots": api_graphed_slots_value, "value_shim": shim_value, "ddp_encoder": ddp_info,
+            "value_api_graphed_slots": api_graphed_slots_value, "host_us_per_step": host_us_per_step, "value_shim": shim_value, "ddp_encoder": ddp_info,
             "value_config3": None if not config3 else config3.get("images_per_s"), "config3": config3,
             "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},
             "loss": loss_value,

@@ -536,11 +536,13 @@ def test_geometry_only_render_is_the_render_without_the_image(pkg):
 
 
 def test_graphed_step_keeps_autograd_semantics(pkg):
-    """The graphed node's gradients go through the engine by default: torch.autograd.grad returns them, tensor hooks fire, a leaf of another
-    (reshapeable) shape is served, and a gradient the caller keeps is not overwritten by the next replay.  fast_leaf_grads is opt-in and
-    gives the same numbers; run() does not inherit the upstream slots of an earlier autograd backward."""
+    """The graphed node's gradients go through the engine: torch.autograd.grad returns them, tensor hooks fire, a leaf of another (reshapeable)
+    shape is served.  With copy_leaf_grads=True a gradient the caller keeps is never overwritten by a later replay; by DEFAULT a hook-less leaf's
+    .grad is the object's static gradient memory (no copy: the contract of torch.cuda.make_graphed_callables), a leaf with a hook gets a private
+    copy, and a .grad KEPT on the same leaf across steps accumulates correctly.  fast_leaf_grads is opt-in and gives the same numbers; run() does
+    not inherit the upstream slots of an earlier autograd backward."""
     dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 4, 64, seed=71)
-    gs = dr.graphed_step(datt, gt.to(dev), no_mask=True)
+    gs = dr.graphed_step(datt, gt.to(dev), no_mask=True, copy_leaf_grads=True)
     lv = {k: datt[k].detach().clone().requires_grad_(True) for k in LEAVES}
     lv["azimuths"] = datt["azimuths"].detach().clone().reshape(-1, 1).requires_grad_(True)       # (B,1) instead of (B)
     a = dict(datt); a.update(lv)
@@ -576,6 +578,22 @@ def test_graphed_step_keeps_autograd_semantics(pkg):
     torch.cuda.synchronize()
     for k in LEAVES:
         assert torch.equal(gs.grads[k].reshape(snap[k].shape), snap[k]), k
+    # the DEFAULT: no copies for hook-less leaves -- .grad is static memory; a leaf with a hook gets its own tensor; accumulation over steps is exact
+    gd = dr.graphed_step(datt, gt.to(dev), no_mask=True)
+    lv4 = {k: datt[k].detach().clone().requires_grad_(True) for k in LEAVES}
+    seen = []
+    lv4["lights"].register_hook(lambda g: seen.append(g.data_ptr()))
+    a4 = dict(datt); a4.update(lv4)
+    gd(gt.to(dev), **a4)[0].backward()
+    for k in LEAVES:
+        assert torch.equal(lv4[k].grad, snap[k].reshape(lv4[k].shape)), k
+        assert (lv4[k].grad.data_ptr() == gd.grads[k].data_ptr()) == (k != "lights"), k       # static memory, except the hooked leaf's copy
+    assert len(seen) == 1 and seen[0] != gd.grads["lights"].data_ptr()
+    gd(gt.to(dev), **a4)[0].backward()                            # .grad kept: copied out before the replay, then accumulated into
+    torch.cuda.synchronize()
+    for k in LEAVES:
+        assert torch.equal(lv4[k].grad, 2.0 * snap[k].reshape(lv4[k].shape)), k
+        assert lv4[k].grad.data_ptr() != gd.grads[k].data_ptr(), k
     # the opt-in fast path: same numbers, .grad is the static buffer
     gf = dr.graphed_step(datt, gt.to(dev), no_mask=True, fast_leaf_grads=True)
     lv3 = {k: datt[k].detach().clone().requires_grad_(True) for k in LEAVES}

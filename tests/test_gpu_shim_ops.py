@@ -356,6 +356,17 @@ def test_vertex_ids_outside_the_cloud_are_reported_not_dereferenced(kal):
     with pytest.raises(RuntimeError, match="outside"):
         kal.render.mesh.prepare_vertices(verts, faces, proj, camera_transform=T)
     kal.render.mesh.prepare_vertices(verts, faces, proj, camera_transform=T)       # reported once
+    # ... or by the offending call's own backward (the device has long finished the forward's table builder by then), or by the poll function
+    v2 = verts.clone().requires_grad_(True)
+    fvc, fvi, fn = kal.render.mesh.prepare_vertices(v2, bad, proj, camera_transform=T)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="outside"):
+        fvi.sum().backward()
+    assert ops.poll_reported_faces("cuda:0", synchronize=True) is None                # (reported once)
+    kal.render.mesh.prepare_vertices(verts, bad, proj, camera_transform=T)
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.poll_reported_faces("cuda:0", synchronize=True)                           # waits for the device: no later call needed
+    assert ops.poll_reported_faces() is None
 
 
 def test_the_unfused_operator_chain_is_bitwise_reproducible(pkg, kal):

@@ -71,11 +71,46 @@ def search(oracle, fx):
     return [(names, bits) for names, bits in _combos(oracle) if _matches(oracle, fx, bits)]
 
 
+def _micro_sh(oracle, fx, bits):
+    with oracle.options(bits):
+        return oracle.sh_lighting(fx["sh_axis_normals"], fx["sh_axis_lights"])
+
+
+def _micro_backface(oracle, fx, bits):
+    """soft mask of the fixture's one back-facing triangle under `bits` (16x16)."""
+    fvi, fz, nz = fx["bf_fvi"], fx["bf_fz"], fx["bf_nz"]
+    with oracle.options(bits):
+        valid = ((nz > 0) if (bits & oracle.OPT_CULL_STRICT) else (nz >= 0)).astype(np.uint8)
+        fidx, _, _ = oracle.rasterize(16, 16, fz, fvi, np.ones((1, 1, 3, 1), np.float32), valid)
+        soft, _, _, _ = oracle.soft_mask(16, 16, fvi, fidx, valid=valid)
+    return fidx, soft
+
+
+def diagnose(oracle, fx):
+    """The two recalled choices that matter, each read off its own micro-case of the fixture (tools/mint_kaolin_fixture.py): True / False = the
+    option bit IS / IS NOT what the fixture's author (real kaolin) does, None = the micro-case is missing or matches neither form."""
+    out = {"OPT_SH_ORDER_XYZ": None, "OPT_SOFT_SKIP_CULLED": None}
+    close = lambda a, b: a.shape == b.shape and float(np.abs(a - b).max()) <= 1e-5 * max(1.0, float(np.abs(b).max()))
+    if "sh_axis_coef" in fx:
+        d0, d1 = close(_micro_sh(oracle, fx, 0), fx["sh_axis_coef"]), close(_micro_sh(oracle, fx, oracle.OPT_SH_ORDER_XYZ), fx["sh_axis_coef"])
+        out["OPT_SH_ORDER_XYZ"] = None if d0 == d1 else d1
+    if "bf_soft" in fx:
+        s0, s1 = _micro_backface(oracle, fx, 0)[1], _micro_backface(oracle, fx, oracle.OPT_SOFT_SKIP_CULLED)[1]
+        d0, d1 = close(s0, fx["bf_soft"]), close(s1, fx["bf_soft"])
+        out["OPT_SOFT_SKIP_CULLED"] = None if d0 == d1 else d1
+    return out
+
+
 @pytest.mark.skipif(not os.path.exists(FIXTURE), reason="tests/golden/kaolin_v0_12.npz not minted yet (needs real kaolin v0.12.0 + CUDA: tools/mint_kaolin_fixture.py)")
 def test_oracle_reproduces_real_kaolin_under_some_option_combination(oracle):
     fx = dict(np.load(FIXTURE))
+    verdict = diagnose(oracle, fx)
+    print("micro-cases: kaolin %s -> %s" % (fx["kaolin_version"], verdict))
     found = search(oracle, fx)
-    assert found, "no combination of the Appendix C option bits reproduces kaolin %s: the restated semantics are wrong somewhere else" % fx["kaolin_version"]
+    assert found, "no combination of the Appendix C option bits reproduces kaolin %s: the restated semantics are wrong somewhere else (micro-cases: %s)" % (fx["kaolin_version"], verdict)
+    for name, is_set in verdict.items():                          # the micro-cases and the full search must tell the same story
+        if is_set is not None:
+            assert all((name in names) == is_set for names, _ in found), (name, is_set, found)
     print("kaolin %s is reproduced by: %s" % (fx["kaolin_version"], [" | ".join(n) or "defaults" for n, _ in found]))
     # the library's defaults must be among them (flip MMRenderDesc.options' default otherwise)
     assert any(bits == 0 for _, bits in found), "the defaults do not reproduce kaolin; these do: %s" % ([" | ".join(n) for n, _ in found],)
@@ -101,13 +136,20 @@ def _self_fixture(pkg, oracle, bits, seed=7):
     fx["in_azimuths"][0] = 0.0; fx["in_elevations"][0] = 0.0; fx["in_biases"][0] = 0.0; fx["in_distances"][0] = 2.5
     fx["transform"] = oracle.camera(fx["in_distances"], fx["in_elevations"], fx["in_azimuths"], fx["in_biases"])
     fx["face_idx"], fx["soft_mask"], fx["rgba"], fx["face_normals"], fx["imnormal"] = _forward(oracle, fx, bits)
+    # the two micro-cases, as the mint tool records them
+    fx["sh_axis_normals"] = np.array([[[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]]], np.float32)
+    fx["sh_axis_lights"] = (0.1 * np.arange(1, 10, dtype=np.float32)).reshape(1, 9)
+    fx["sh_axis_coef"] = _micro_sh(oracle, fx, bits)
+    fx["bf_fvi"] = np.array([[[[-0.5, -0.4], [0.1, 0.6], [0.5, -0.3]]]], np.float32)
+    fx["bf_fz"] = np.full((1, 1, 3), -3.0, np.float32); fx["bf_nz"] = np.array([[-1.0]], np.float32)
+    fx["bf_face_idx"], fx["bf_soft"] = _micro_backface(oracle, fx, bits)
     g = _gradients(oracle, fx, bits)
     for k in ("vertices", "textures", "lights", "bg"):
         fx["grad_" + k] = g[k]
     return fx
 
 
-@pytest.mark.parametrize("names", [(), ("OPT_BBOX_MIN_CLOSED_MAX_OPEN", "OPT_BARY_ONE_MINUS"), ("OPT_CULL_STRICT", "OPT_SH_ORDER_XYZ")])
+@pytest.mark.parametrize("names", [(), ("OPT_BBOX_MIN_CLOSED_MAX_OPEN", "OPT_BARY_ONE_MINUS"), ("OPT_CULL_STRICT", "OPT_SH_ORDER_XYZ"), ("OPT_SOFT_SKIP_CULLED",)])
 def test_the_search_finds_the_combination_a_fixture_was_minted_under(pkg, oracle, names):
     bits = sum(getattr(oracle, n) for n in names)
     fx = _self_fixture(pkg, oracle, bits)
@@ -119,3 +161,20 @@ def test_the_search_finds_the_combination_a_fixture_was_minted_under(pkg, oracle
     # every combination it reports really is indistinguishable on this fixture (forward bits)
     for _, b in found:
         assert np.array_equal(_forward(oracle, fx, b)[0], fx["face_idx"])
+    # the micro-cases read the two bits that matter off directly, whatever else is set
+    verdict = diagnose(oracle, fx)
+    assert verdict["OPT_SH_ORDER_XYZ"] == ("OPT_SH_ORDER_XYZ" in names), verdict
+    assert verdict["OPT_SOFT_SKIP_CULLED"] == ("OPT_SOFT_SKIP_CULLED" in names), verdict
+
+
+def test_the_micro_cases_discriminate(pkg, oracle):
+    """The six axis normals under nine distinct lights separate the two SH band orders, and one back-facing triangle separates the two soft-mask
+    rules (a silhouette blob against an all-zero mask): the fixture's micro-cases cannot come out the same under both forms."""
+    fx = _self_fixture(pkg, oracle, 0)
+    assert float(np.abs(_micro_sh(oracle, fx, 0) - _micro_sh(oracle, fx, oracle.OPT_SH_ORDER_XYZ)).max()) > 1e-2
+    f0, s0 = _micro_backface(oracle, fx, 0)
+    f1, s1 = _micro_backface(oracle, fx, oracle.OPT_SOFT_SKIP_CULLED)
+    assert (f0 == -1).all() and (f1 == -1).all()                     # culled from the colour pass either way
+    assert float(s0.max()) > 0.5 and float(s1.max()) == 0.0             # (a band along the edges: a pixel takes exp(-sigma d^2) of its distance to the nearest edge)
+    fx2 = _self_fixture(pkg, oracle, oracle.OPT_SOFT_SKIP_CULLED)
+    assert diagnose(oracle, fx2) == {"OPT_SH_ORDER_XYZ": False, "OPT_SOFT_SKIP_CULLED": True}

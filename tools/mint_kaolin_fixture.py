@@ -12,6 +12,15 @@ and input gradients to 1e-4 -- and fails if there is none.  The combination it r
 What is recorded: the inputs (seeded, numpy) and, from kaolin's own operators called in the order of the reference's DiffRender.render
 (networks.py:278-317): face_idx, soft mask, rgba, face_normals, and the gradients of a fixed scalar of the outputs with respect to
 vertices, textures, lights and the camera transform.  Nothing of kaolin's source is stored -- numbers only.
+
+Plus two MICRO-CASES that settle, each by itself, the two recalled choices that matter (profiles/r04_appendix_c_table.md: they move 3.5 % / 12-25 %
+of the pixels and the vertex / light gradients by 27-75 %; the other four bits change nothing beyond 4e-5 on the BASELINE inputs):
+  sh_axis_*   kaolin.render.mesh.spherical_harmonic_lighting on the six axis normals (+-x, +-y, +-z) under nine DISTINCT light coefficients: which
+              light multiplies which band (MM_OPT_SH_ORDER_XYZ) is read off directly (networks.py:306);
+  bf_*        kaolin.render.mesh.dibr_rasterization of ONE triangle that faces away from the camera (face_normals_z < 0): whether the soft mask
+              runs over culled faces too (MM_OPT_SOFT_SKIP_CULLED) is the difference between a silhouette blob and an all-zero mask
+              (networks.py:297-299).
+tests/test_kaolin_pinning.py reads both (``diagnose``) and prints the verdict per bit next to the full search.
 """
 import argparse
 import os
@@ -95,6 +104,19 @@ def main():
            "face_idx": fidx.cpu().numpy().astype(np.int32), "soft_mask": soft.detach().cpu().numpy(), "rgba": rgba.detach().cpu().numpy(),
            "face_normals": fn.detach().cpu().numpy(), "imnormal": imnormal.detach().cpu().numpy(),
            "grad_transform": T.grad.cpu().numpy()}
+    # ---- micro-case 1: SH band <-> light pairing on the six axis normals
+    axis = torch.tensor([[1., 0, 0], [-1., 0, 0], [0, 1., 0], [0, -1., 0], [0, 0, 1.], [0, 0, -1.]], device=dev).reshape(1, 6, 3)
+    sh_lights = (0.1 * torch.arange(1, 10, device=dev, dtype=torch.float32)).reshape(1, 9)
+    out["sh_axis_normals"] = axis.cpu().numpy(); out["sh_axis_lights"] = sh_lights.cpu().numpy()
+    out["sh_axis_coef"] = kal.render.mesh.spherical_harmonic_lighting(axis, sh_lights).cpu().numpy()
+    # ---- micro-case 2: one triangle facing away from the camera
+    bf_fvi = torch.tensor([[[[-0.5, -0.4], [0.1, 0.6], [0.5, -0.3]]]], device=dev)      # (1,1,3,2) NDC; its orientation is irrelevant: the cull flag is face_normals_z
+    bf_fz = torch.full((1, 1, 3), -3.0, device=dev)
+    bf_feat = torch.ones((1, 1, 3, 1), device=dev)
+    bf_nz = torch.tensor([[-1.0]], device=dev)
+    bf_interp, bf_soft, bf_fidx = kal.render.mesh.dibr_rasterization(16, 16, bf_fz, bf_fvi, bf_feat, bf_nz)
+    out["bf_fvi"] = bf_fvi.cpu().numpy(); out["bf_fz"] = bf_fz.cpu().numpy(); out["bf_nz"] = bf_nz.cpu().numpy()
+    out["bf_soft"] = bf_soft.cpu().numpy(); out["bf_face_idx"] = bf_fidx.cpu().numpy().astype(np.int32)
     for k in ("vertices", "textures", "lights", "bg"):
         out["in_" + k] = inp[k]; out["grad_" + k] = t[k].grad.cpu().numpy()
     for k in ("azimuths", "elevations", "distances", "biases"):

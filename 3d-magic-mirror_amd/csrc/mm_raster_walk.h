@@ -450,7 +450,11 @@ __device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, Wa
             wave_lds_sync();
             MM_PP_MARK(2);
             if (__ballot(ph != 0)) {
+#ifdef MM_BATCH_FILTER                                          // (A/B, profiles/r05_batch_walk_ab.md: the compacting walk's two-phase pair evaluation -- packed sign filter +
+                hard_pairs(a, t, st, ph, false);                 //  early-z, then the divisions for the survivors -- in the per-batch walk; lists of <= MM_HARD_DIRECT pairs go direct)
+#else
                 pair_parallel(t, st, ph, [&](int l, int j, bool live) { hard_pair(a, t, st, st, j, l, live); });   // pixel l, candidate j
+#endif
                 const unsigned long long kk = st->key[t.lane];
                 open = t.in_img && kk == 0ull;
                 zfloor = wave_min_u32(t.in_img ? (unsigned)(kk >> 32) : 0xFFFFFFFFu);

@@ -229,6 +229,62 @@ class ReconNode : public torch::autograd::Function<ReconNode> {
     }
 };
 
+// DiffRender.render_geometry (MMRenderDesc.geometry_only: the vertex stage alone, for the render whose image trainer.py:367 discards):
+// face_normals (B,F,3) with a backward to vertices and the four camera inputs.  The prototype carries geometry_only = 1.
+class GeometryNode : public torch::autograd::Function<GeometryNode> {
+ public:
+    static at::Tensor forward(AutogradContext* ctx, int64_t f_fwd, int64_t f_bwd, std::string proto, int64_t ws_bytes, at::Tensor vertices,
+                              at::Tensor azimuths, at::Tensor elevations, at::Tensor distances, at::Tensor biases) {
+        TORCH_CHECK(azimuths.is_cuda(), "the MI355X render path needs tensors in device memory; there is no CPU fallback");
+        const c10::Device dev = azimuths.device();
+        const DeviceGuard guard(dev);
+        MMRenderDesc d = proto_desc(proto);
+        TORCH_CHECK(d.geometry_only == 1, "GeometryNode needs a geometry-only descriptor prototype");
+        vertices = dense_f32(vertices, dev, "vertices");
+        azimuths = dense_f32(azimuths, dev, "azimuths").reshape({-1}); elevations = dense_f32(elevations, dev, "elevations").reshape({-1});
+        distances = dense_f32(distances, dev, "distances").reshape({-1}); biases = dense_f32(biases, dev, "biases");
+        const int64_t B = azimuths.size(0);
+        TORCH_CHECK(B == d.B, "batch size ", B, " does not match the descriptor (", d.B, ")");
+        TORCH_CHECK(vertices.dim() == 3 && vertices.size(0) == B && vertices.size(1) == d.V && vertices.size(2) == 3, "vertices must be (B,", d.V, ",3), got ", vertices.sizes());
+        TORCH_CHECK(biases.dim() == 2 && biases.size(0) == B && biases.size(1) == 2 && elevations.size(0) == B && distances.size(0) == B,
+                    "biases (B,2), elevations/distances (B) expected");
+        at::Tensor ws = at::empty({ws_bytes}, azimuths.options().dtype(at::kByte));
+        at::Tensor fn = at::empty({B, (int64_t)d.F, 3}, vertices.options());
+        d.vertices = fptr(vertices); d.azimuths = fptr(azimuths); d.elevations = fptr(elevations); d.distances = fptr(distances); d.biases = fptr(biases);
+        d.face_normals = mptr(fn); d.workspace = ws.data_ptr(); d.workspace_bytes = (size_t)ws.numel();
+        check(((render_fwd_t)f_fwd)(&d, (void*)current_stream(dev)), "mm_render_forward (geometry only)");
+        ctx->saved_data["f_bwd"] = f_bwd; ctx->saved_data["proto"] = proto;
+        ctx->save_for_backward({vertices, azimuths, elevations, distances, biases, ws});
+        ctx->set_materialize_grads(false);
+        return fn;
+    }
+    static tensor_list backward(AutogradContext* ctx, tensor_list g) {
+        const auto sv = ctx->get_saved_variables();
+        tensor_list none(9);
+        if (!g[0].defined()) return none;                        // face_normals took no part in what is differentiated
+        const DeviceGuard guard(sv[1].device());
+        MMRenderDesc d = proto_desc(ctx->saved_data["proto"].toStringRef());
+        at::Tensor gfn = g[0].to(at::kFloat).contiguous();
+        at::Tensor ws = sv[5];
+        d.vertices = fptr(sv[0]); d.azimuths = fptr(sv[1]); d.elevations = fptr(sv[2]); d.distances = fptr(sv[3]); d.biases = fptr(sv[4]);
+        d.face_normals = mptr(gfn);                              // (a valid pointer for the argument check; the backward does not read the normals)
+        d.workspace = ws.data_ptr(); d.workspace_bytes = (size_t)ws.numel();
+        at::Tensor gv = at::empty_like(sv[0]), ga = at::empty_like(sv[1]), ge = at::empty_like(sv[2]), gd = at::empty_like(sv[3]), gb = at::empty_like(sv[4]);
+        MMRenderGrads gr;
+        std::memset(&gr, 0, sizeof gr);
+        gr.grad_face_normals = fptr(gfn); gr.grad_vertices = mptr(gv); gr.grad_azimuths = mptr(ga); gr.grad_elevations = mptr(ge);
+        gr.grad_distances = mptr(gd); gr.grad_biases = mptr(gb);
+        check(((render_bwd_t)ctx->saved_data["f_bwd"].toInt())(&d, &gr, (void*)current_stream(sv[1].device())), "mm_render_backward (geometry only)");
+        none[4] = gv; none[5] = ga; none[6] = ge; none[7] = gd; none[8] = gb;
+        return none;
+    }
+};
+
+at::Tensor geometry_node(int64_t f_fwd, int64_t f_bwd, std::string proto, int64_t ws_bytes, at::Tensor vertices, at::Tensor azimuths, at::Tensor elevations,
+                         at::Tensor distances, at::Tensor biases) {
+    return GeometryNode::apply(f_fwd, f_bwd, proto, ws_bytes, vertices, azimuths, elevations, distances, biases);
+}
+
 tensor_list render_node(int64_t f_fwd, int64_t f_loss, int64_t f_bwd, std::string proto, int64_t ws_bytes, at::Tensor vertices, at::Tensor textures,
                         at::Tensor lights, c10::optional<at::Tensor> bg, at::Tensor azimuths, at::Tensor elevations, at::Tensor distances, at::Tensor biases,
                         c10::optional<at::Tensor> gt, bool want_imnormal, double image_weight, int64_t stream) {
@@ -248,5 +304,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("recon_backward", &recon_backward);
     m.def("render", &render_node);
     m.def("recon_data", &recon_node);
+    m.def("render_geometry", &geometry_node);
     m.def("desc_bytes", []() { return (int64_t)sizeof(MMRenderDesc); });
 }

@@ -376,14 +376,15 @@ class DiffRender(object):
             raise RuntimeError("mm_render_backward: the texture-record pool overflowed (records dropped per image: %s); the texture gradients of those "
                                "images are NaN. Raise DiffRender.extra_texture_records_per_pixel." % (list(dropped),))
 
-    def _proto(self, st, B, no_mask, Ht, Wt, contour=0.0):
+    def _proto(self, st, B, no_mask, Ht, Wt, contour=0.0, geometry_only=False):
         """(bytes of the MMRenderDesc prototype of this shape, its workspace size) for the C++ host path; cached like _desc's prototypes.
         contour: MMRenderDesc.fused_contour -- the C++ node copies the prototype for its forward AND its backward, so the weight travels in it."""
         key = ("bytes", id(st), B, int(bool(no_mask)), Ht, Wt, self.knum, self.sigmainv, self.boxlen, self.multiplier, self.eps, self.options,
-               float(self.extra_texture_records_per_pixel), float(contour))
+               float(self.extra_texture_records_per_pixel), float(contour), bool(geometry_only))
         hit = self._desc_cache.get(key)
         if hit is None:
             d = N.MMRenderDesc()
+            d.geometry_only = 1 if geometry_only else 0
             d.B, d.H, d.W, d.V, d.F = B, self.render_height, self.image_size, self.num_vertices, self.num_faces
             d.Ht, d.Wt = Ht, Wt
             d.no_mask, d.knum = int(bool(no_mask)), self.knum
@@ -481,8 +482,16 @@ class DiffRender(object):
         a = attributes
         self._raise_if_records_were_dropped()
         N.require_device(a['azimuths'])
-        attributes['face_normals'] = _RenderFn.apply(self, False, "geometry", None, a['vertices'], a['textures'], a['lights'], None,
-                                                     a['azimuths'], a['elevations'], a['distances'], a['biases'], 0.0)
+        ext = None if self.check_texture_records else N.torch_ext()
+        if ext is not None and hasattr(ext, "render_geometry"):   # the C++ node (csrc/mm_torch_ext.cpp: GeometryNode): no Python in forward or backward
+            dev = a['azimuths'].device
+            tex = a['textures']
+            proto, nbytes = self._proto(self._static(dev), a['azimuths'].numel(), False, tex.shape[2], tex.shape[3], 0.0, geometry_only=True)
+            attributes['face_normals'] = ext.render_geometry(N.fn_addr("mm_render_forward"), N.fn_addr("mm_render_backward"), proto, nbytes,
+                                                             a['vertices'], a['azimuths'], a['elevations'], a['distances'], a['biases'])
+        else:
+            attributes['face_normals'] = _RenderFn.apply(self, False, "geometry", None, a['vertices'], a['textures'], a['lights'], None,
+                                                         a['azimuths'], a['elevations'], a['distances'], a['biases'], 0.0)
         attributes['imnormal'] = None
         return attributes
 
@@ -508,25 +517,6 @@ class DiffRender(object):
         attributes['imnormal'] = imn if self.emit_imnormal else None
         self.last_face_idx = face_idx
         return loss, rgba.permute(0, 3, 1, 2), attributes
-
-    def graphed_step(self, example_attributes, gt_data, no_mask=False, fast_leaf_grads=False, copy_leaf_grads=False):
-        """A captured (HIP-graph) render + recon_data + backward for attribute tensors of the example's shapes: returns a callable
-        ``g(gt_data, **attributes) -> (loss, rgbs, attributes)`` with the semantics of ``render_recon`` whose forward and backward are one
-        graph launch each (step.GraphedRenderRecon: static input slots ``g.inputs`` / ``g.gt``, static outputs).  The call sites it
-        serves: trainer.py:276 (render), :441 (recon_data), :509-518 (backward).  Gradients go through the autograd engine; a leaf attribute's
-        ``.grad`` IS the object's static gradient memory until the next call (no copy; ``copy_leaf_grads=True`` hands private copies instead, as do
-        leaves with hooks).  ``fast_leaf_grads``: opt-in, leaves get the static buffers as ``.grad`` without the engine (step._graphed_input_grads)."""
-        from .step import GraphedRenderRecon
-        N.require_device(*[v for k, v in example_attributes.items() if torch.is_tensor(v)], gt_data)
-        return GraphedRenderRecon(self, example_attributes, gt_data, no_mask=no_mask, fast_leaf_grads=fast_leaf_grads, copy_leaf_grads=copy_leaf_grads)
-
-    def graphed_render(self, example_attributes, no_mask=False, fast_leaf_grads=False, copy_leaf_grads=False):
-        """A captured (HIP-graph) ``render`` + backward for attribute tensors of the example's shapes: a callable ``g(**attributes) -> (rgbs,
-        attributes)`` like ``render`` (step.GraphedRender).  For the renders of an iteration whose images feed a loss outside this class
-        (trainer.py:345-367); one object per such render -- its outputs are static memory."""
-        from .step import GraphedRender
-        N.require_device(*[v for k, v in example_attributes.items() if torch.is_tensor(v)])
-        return GraphedRender(self, example_attributes, no_mask=no_mask, fast_leaf_grads=fast_leaf_grads, copy_leaf_grads=copy_leaf_grads)
 
     # ---- networks.py:364-390 -------------------------------------------------------------------------------------
     def recon_data(self, pred_data, gt_data, no_mask=False, contour=0):

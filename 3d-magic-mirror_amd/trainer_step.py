@@ -133,17 +133,14 @@ def default_opt():
 
 
 class TrainerStep:
-    def __init__(self, template, image_size, batch, device, ratio=1, opt=None, seed=0, graphed=False, lean=False, many=False):
-        """graphed: the four renders go through DiffRender.graphed_render (one captured forward / backward graph pair per render of the iteration:
-        their outputs are static memory) instead of the eager autograd nodes -- same bits, less host time.
-        lean: the fourth render (trainer.py:367, whose image is discarded) as DiffRender.render_geometry -- same losses, same gradients.
+    def __init__(self, template, image_size, batch, device, ratio=1, opt=None, seed=0, lean=False, many=False):
+        """lean: the fourth render (trainer.py:367, whose image is discarded) as DiffRender.render_geometry -- same losses, same gradients.
         many (with lean): the three renders whose attributes exist up front (trainer.py:276,345,347) as ONE DiffRender.render_many call of 3B
         images.  Pays where a batch of 48 does not fill the chip (128x128); at 256x256 one pass over 144 images takes as long as three over 48
         and the concatenations cost more than the launches saved (profiles/r04_render_path.md)."""
         self.opt = opt or default_opt()
         self.dev, self.B = device, batch
-        self.graphed, self._gr = bool(graphed), {}
-        self.lean = bool(lean) and not graphed                   # render #4 geometry-only
+        self.lean = bool(lean)                                   # render #4 geometry-only
         self.many = bool(many) and self.lean                     # renders #1-#3 as one render_many call
         self.dr = DiffRender(template, image_size, ratio=ratio)
         torch.manual_seed(seed)
@@ -164,13 +161,8 @@ class TrainerStep:
         self.last = {}
 
     def _render(self, slot, A):
-        """render #slot of the iteration: eager, or through that slot's captured graphs."""
-        if not self.graphed:
-            return self.dr.render(**A, no_mask=self.opt.bg)
-        g = self._gr.get(slot)
-        if g is None:
-            g = self._gr[slot] = self.dr.graphed_render(A, no_mask=self.opt.bg)
-        return g(**A)
+        """render #slot of the iteration"""
+        return self.dr.render(**A, no_mask=self.opt.bg)
 
     def _u(self, *shape, lo=0.0, hi=1.0):
         return torch.rand(*shape, device=self.dev, generator=self.gen) * (hi - lo) + lo
@@ -276,16 +268,7 @@ def bench(device, steps=8, warmup=3, template=None, image_size=256, batch=48):
     for _ in range(2):
         rp()
     t_rp = timed(rp, steps)
-    # the same step and the same render path with the four renders through DiffRender.graphed_render (same weights, same random stream)
-    tg = TrainerStep(template, image_size, batch, device, graphed=True)
-    for _ in range(warmup):
-        tg.step()
-    t_step_g = timed(tg.step, steps)
-    rpg = tg.render_path_only()
-    for _ in range(2):
-        rpg()
-    t_rp_g = timed(rpg, steps)
-    # the same step with renders #1-#3 as one render_many call and #4 geometry-only (lean)
+    # the same step with render #4 geometry-only (lean)
     tl = TrainerStep(template, image_size, batch, device, lean=True)
     for _ in range(warmup):
         tl.step()
@@ -301,8 +284,6 @@ def bench(device, steps=8, warmup=3, template=None, image_size=256, batch=48):
                            ts.dr.image_size, nparam / 1e6),
             "images_per_s": round(batch / t_step, 1), "ms_per_step": round(t_step * 1e3, 3),
             "render_path_ms": round(t_rp * 1e3, 3), "render_path_share": round(t_rp / t_step, 3),
-            "graphed_renders": {"images_per_s": round(batch / t_step_g, 1), "ms_per_step": round(t_step_g * 1e3, 3), "render_path_ms": round(t_rp_g * 1e3, 3),
-                                "loss": float(tg.last["loss"])},
             "lean": {"images_per_s": round(batch / t_step_l, 1), "ms_per_step": round(t_step_l * 1e3, 3), "render_path_ms": round(t_rp_l * 1e3, 3),
                      "loss": float(tl.last["loss"]), "what": "render #4 (image discarded, trainer.py:367) as DiffRender.render_geometry"},
             "steps": steps, "loss": loss,

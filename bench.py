@@ -19,9 +19,8 @@ steps, each repetition bracketed by barrier + synchronize: the driver's short --
   value_api           DiffRender.render -> DiffRender.recon_data -> loss.backward() through the torch.autograd wrappers (the calls
                       trainer.py makes, :276,441,509-518), one stream.
   value_api_fused     the same step through DiffRender.render_recon (loss folded into the render kernels).
-  value_api_graphed   the same step through DiffRender.graphed_step: forward and backward one captured HIP graph each behind one autograd node;
-                      _slots: the caller writes its attributes into the graph's static input slots (no copies inside the call) and opts in to
-                      fast_leaf_grads (leaf attributes get the static gradient buffers as .grad, not through the engine).
+                      (Rounds 3-4 also reported value_api_graphed*: captured class-API steps, removed in round 5 -- slower than value_api_fused on
+                      every box, profiles/r05_api_paths.md.)
   host_us_per_step    host time per step of each API flavour (and of the C-ABI step): 60 steps enqueued on an idle device, clock stopped before the
                       device is waited for -- value_api* are host-bound, so they are comparable between boxes only next to this figure.
   value_shim          the UN-FUSED compatibility path: the kaolin-shaped operators of the import boundary called in the order of the reference's
@@ -392,7 +391,7 @@ def main():
         reducer.wait(); torch.cuda.synchronize(dev)
     loss_value = float(step.loss) if args.mode != "torch" else None
 
-    one_stream = api_value = api_fused_value = api_graphed_value = api_graphed_slots_value = shim_value = no_imn_value = None
+    one_stream = api_value = api_fused_value = shim_value = no_imn_value = None
     host_us_per_step = {}
     e1, e1_all = elapsed, elapsed_all
     if args.mode == "eager":
@@ -427,34 +426,6 @@ def main():
         e2f, _ = timed_median(one_api_fused, args.api_steps, reps=3)
         api_fused_value = round(world * B * args.api_steps / e2f, 1)
         host_us_per_step["api_fused"] = host_us(one_api_fused)
-        # DiffRender.graphed_step: (a) attributes arrive as fresh tensors and are copied into the static slots; (b) the caller writes into the slots
-        gs = dr_api.graphed_step(batches[0][0][0], batches[0][0][1], no_mask=True)     # gradients through the autograd engine (default)
-        gs_fast = dr_api.graphed_step(batches[0][0][0], batches[0][0][1], no_mask=True, fast_leaf_grads=True)   # opt-in: leaves get the static buffers as .grad
-
-        def one_api_graphed():
-            k = ctr2[0] % nrot; ctr2[0] += 1
-            lv = leaves_rot[k]
-            for v in lv.values():
-                v.grad = None
-            a = dict(batches[0][k][0]); a.update(lv)
-            gs(batches[0][k][1], **a)[0].backward()
-        for _ in range(10):
-            one_api_graphed()
-        e2g, _ = timed_median(one_api_graphed, args.api_steps, reps=3)
-        api_graphed_value = round(world * B * args.api_steps / e2g, 1)
-        host_us_per_step["api_graphed"] = host_us(one_api_graphed)
-        slot_leaves = {k: gs_fast.inputs[k].requires_grad_(True) for k in stepmod.LEAVES}
-        slot_att = dict(batches[0][0][0]); slot_att.update(slot_leaves)
-
-        def one_api_graphed_slots():                              # (the networks' outputs land in the slots; here they simply stay; fast_leaf_grads)
-            for v in slot_leaves.values():
-                v.grad = None
-            gs_fast(gs_fast.gt, **slot_att)[0].backward()
-        for _ in range(10):
-            one_api_graphed_slots()
-        e2s, _ = timed_median(one_api_graphed_slots, args.api_steps, reps=3)
-        api_graphed_slots_value = round(world * B * args.api_steps / e2s, 1)
-        host_us_per_step["api_graphed_slots"] = host_us(one_api_graphed_slots)
     if args.shim_steps > 0 and rank == 0:
         # the un-fused kaolin-shaped operator chain in the reference's order (networks.py:278-317): ~40 launches per render, float atomics
         try:
@@ -629,8 +600,7 @@ def main():
             "value_one_stream": one_stream, "value_four_streams": round(total_images / elapsed, 1) if args.mode == "eager" else None,
             "ms_per_step_four_streams": round(elapsed / args.steps * 1e3, 4) if args.mode == "eager" else None,
             "value_without_imnormal": no_imn_value,
-            "value_api": api_value, "value_api_fused": api_fused_value, "value_api_graphed": api_graphed_value,
-            "value_api_graphed_slots": api_graphed_slots_value, "host_us_per_step": host_us_per_step, "value_shim": shim_value, "ddp_encoder": ddp_info,
+            "value_api": api_value, "value_api_fused": api_fused_value, "host_us_per_step": host_us_per_step, "value_shim": shim_value, "ddp_encoder": ddp_info,
             "value_config3": None if not config3 else config3.get("images_per_s"), "config3": config3,
             "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},
             "loss": loss_value,

@@ -406,6 +406,38 @@ def test_render_recon_is_render_plus_recon_data(pkg):
         assert float(got[1][2][k].abs().max()) > 0
 
 
+def test_captured_step_replays_the_eager_step_bit_for_bit(pkg):
+    """RenderLossStep.capture(): the whole C-ABI step (mm_render_forward + mm_render_backward, fused loss) captured as ONE HIP graph -- the library
+    neither allocates nor synchronises, so the capture is plain (bench.py --mode hipgraph).  Replays give the eager run's bits: loss, image,
+    face_idx and all eight gradients; the input slots may be refilled between replays."""
+    import importlib
+    stepmod = importlib.import_module("3d-magic-mirror_amd.step")
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 6, 96, seed=41)
+    plain = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in datt.items()}
+    eager = stepmod.RenderLossStep(dr, plain, gt.to(dev), no_mask=True, fused=True)
+    eager.run(); torch.cuda.synchronize()
+    ref = (float(eager.loss), eager.rgba.clone(), eager.face_idx.clone(), {k: v.clone() for k, v in eager.grads.items() if v is not None})
+    cap = stepmod.RenderLossStep(dr, plain, gt.to(dev), no_mask=True, fused=True)
+    cap.capture()
+    for rep in range(3):
+        cap.replay(); torch.cuda.synchronize()
+        assert float(cap.loss) == ref[0] and torch.equal(cap.rgba, ref[1]) and torch.equal(cap.face_idx, ref[2])
+        for k, g in ref[3].items():
+            assert torch.equal(cap.grads[k], g), k
+    # other inputs through the same slots: the graph reads the slots' memory
+    _, _, d2, gt2, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", 6, 96, seed=42)
+    with torch.no_grad():
+        for k in LEAVES:
+            cap.inp[k].copy_(d2[k].detach().reshape(cap.inp[k].shape))
+        cap.gt.copy_(gt2.to(dev))
+    cap.replay(); torch.cuda.synchronize()
+    e2 = stepmod.RenderLossStep(dr, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d2.items()}, gt2.to(dev), no_mask=True, fused=True)
+    e2.run(); torch.cuda.synchronize()
+    assert float(cap.loss) == float(e2.loss) and float(cap.loss) != ref[0]
+    for k in LEAVES:
+        assert torch.equal(cap.grads[k], e2.grads[k]), k
+
+
 def test_fused_backward_does_not_read_the_forward_image_back(pkg):
     """include/mm_render.h, fused_gt: the fused backward re-forms the prediction per pixel (bit for bit) instead of reading `rgba` back,
     so a caller may overwrite the image between forward and backward: same bits for all eight gradients either way."""
@@ -420,68 +452,6 @@ def test_fused_backward_does_not_read_the_forward_image_back(pkg):
     for k in LEAVES:
         assert torch.equal(grads[0][k], grads[1][k]), k
         assert float(grads[0][k].abs().max()) > 0
-
-
-def test_graphed_step_replays_the_eager_path_bit_for_bit(pkg):
-    """DiffRender.graphed_step: render + recon_data + backward captured as HIP graphs behind one autograd node (the call sites of
-    trainer.py:276,441,509-518).  Replays -- on new inputs copied into the static slots, on inputs written into the slots directly, with an
-    upstream gradient through face_normals, and with the loss unused -- give the bits of the eager render_recon path."""
-    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 6, 96, seed=51)
-    gs = dr.graphed_step(datt, gt.to(dev), no_mask=True)
-    for it, seed in enumerate((52, 53, 54)):
-        _, att2, d2, gt2, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", 6, 96, seed=seed)
-        w = torch.linspace(-1.0, 1.0, 6 * dr.num_faces * 3, device=dev).reshape(6, dr.num_faces, 3) * 1e-3
-        # eager reference
-        loss_e, rgbs_e, out_e = dr.render_recon(gt2.to(dev), no_mask=True, **d2)
-        tot_e = 1.7 * loss_e + (out_e["face_normals"] * w).sum() if it != 2 else (out_e["face_normals"] * w).sum()
-        tot_e.backward()
-        ref = (loss_e.detach().clone(), rgbs_e.detach().clone(), dr.last_face_idx.clone(), {k: d2[k].grad.clone() for k in LEAVES})
-        # graphed: iteration 1 writes the inputs straight into the static slots (no copy inside the call)
-        leaves = {k: d2[k].detach().clone().requires_grad_(True) for k in LEAVES}
-        if it == 1:
-            with torch.no_grad():
-                for k in LEAVES:
-                    gs.inputs[k].copy_(leaves[k])
-                gs.gt.copy_(gt2.to(dev))
-            leaves = {k: gs.inputs[k].requires_grad_(True) for k in LEAVES}
-            for v in leaves.values():
-                v.grad = None
-            a = dict(d2); a.update(leaves)
-            loss_g, rgbs_g, out_g = gs(gs.gt, **a)
-        else:
-            a = dict(d2); a.update(leaves)
-            loss_g, rgbs_g, out_g = gs(gt2.to(dev), **a)
-        tot_g = 1.7 * loss_g + (out_g["face_normals"] * w).sum() if it != 2 else (out_g["face_normals"] * w).sum()
-        tot_g.backward()
-        torch.cuda.synchronize()
-        assert torch.equal(loss_g.detach(), ref[0]) and torch.equal(rgbs_g.detach(), ref[1]) and torch.equal(dr.last_face_idx, ref[2]), it
-        for k in LEAVES:
-            assert torch.equal(leaves[k].grad, ref[3][k]), (it, k)
-        for v in gs.inputs.values():
-            v.requires_grad_(False)
-    # accumulation over steps: a .grad that is kept (not reset to None) aliases the static buffer of the last step; the next step copies it
-    # out before the replay overwrites it -- two steps on the same inputs leave exactly twice the gradient
-    _, _, d4, gt4, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", 6, 96, seed=56)
-    lv = {k: d4[k].detach().clone().requires_grad_(True) for k in LEAVES}
-    a4 = dict(d4); a4.update(lv)
-    gs(gt4.to(dev), **a4)[0].backward()
-    once = {k: lv[k].grad.clone() for k in LEAVES}
-    gs(gt4.to(dev), **a4)[0].backward()
-    for k in LEAVES:
-        assert torch.equal(lv[k].grad, once[k] + once[k]), k
-    # without autograd: forward + backward replayed on what the slots hold, dL/dloss = 1
-    _, att3, d3, gt3, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", 6, 96, seed=55)
-    loss_e, _, _ = dr.render_recon(gt3.to(dev), no_mask=True, **d3)
-    loss_e.backward()
-    with torch.no_grad():
-        for k in LEAVES:
-            gs.inputs[k].copy_(d3[k])
-        gs.gt.copy_(gt3.to(dev)); gs.g_loss.fill_(1.0); gs.g_fn.zero_()
-    loss_r = gs.run()
-    torch.cuda.synchronize()
-    assert torch.equal(loss_r, loss_e.detach())
-    for k in LEAVES:
-        assert torch.equal(gs.grads[k], d3[k].grad), k
 
 
 def test_large_batches_take_the_per_image_vertex_backward_and_agree_with_small_ones(pkg):
@@ -533,116 +503,6 @@ def test_geometry_only_render_is_the_render_without_the_image(pkg):
     tot.backward()                                               # a second backward on the same workspace: the arrival counter was left clean
     for k in ref:
         assert torch.equal(lv[k].grad, first[k] + first[k]), k
-
-
-def test_graphed_step_keeps_autograd_semantics(pkg):
-    """The graphed node's gradients go through the engine: torch.autograd.grad returns them, tensor hooks fire, a leaf of another (reshapeable)
-    shape is served.  With copy_leaf_grads=True a gradient the caller keeps is never overwritten by a later replay; by DEFAULT a hook-less leaf's
-    .grad is the object's static gradient memory (no copy: the contract of torch.cuda.make_graphed_callables), a leaf with a hook gets a private
-    copy, and a .grad KEPT on the same leaf across steps accumulates correctly.  fast_leaf_grads is opt-in and gives the same numbers; run() does
-    not inherit the upstream slots of an earlier autograd backward."""
-    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 4, 64, seed=71)
-    gs = dr.graphed_step(datt, gt.to(dev), no_mask=True, copy_leaf_grads=True)
-    lv = {k: datt[k].detach().clone().requires_grad_(True) for k in LEAVES}
-    lv["azimuths"] = datt["azimuths"].detach().clone().reshape(-1, 1).requires_grad_(True)       # (B,1) instead of (B)
-    a = dict(datt); a.update(lv)
-    loss_e, _, _ = dr.render_recon(gt.to(dev), no_mask=True, **{k: (v.detach().clone().requires_grad_(True) if k in LEAVES else v) for k, v in datt.items()})
-    fired = []
-    lv["lights"].register_hook(lambda g: fired.append(g.clone()))
-    loss, _, _ = gs(gt.to(dev), **a)
-    assert torch.equal(loss.detach(), loss_e.detach())
-    got = torch.autograd.grad(loss, [lv[k] for k in LEAVES], retain_graph=True)
-    assert all(g is not None for g in got) and got[LEAVES.index("azimuths")].shape == (4, 1)
-    assert all(lv[k].grad is None for k in LEAVES)               # autograd.grad has no side effect on .grad
-    loss.backward()
-    assert len(fired) == 2 and torch.equal(fired[0], lv["lights"].grad)
-    kept = {k: lv[k].grad for k in LEAVES}
-    snap = {k: v.clone() for k, v in kept.items()}
-    for k, g in zip(LEAVES, got):
-        assert torch.equal(g, snap[k]), k
-    # another step on other inputs: what the caller kept must not change under it
-    _, _, d2, gt2, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", 4, 64, seed=72)
-    lv2 = {k: d2[k].detach().clone().requires_grad_(True) for k in LEAVES}
-    a2 = dict(d2); a2.update(lv2)
-    out2 = gs(gt2.to(dev), **a2)
-    (out2[2]["face_normals"].sum() * 1e-3).backward()            # the loss unused: its upstream slot is zero after this
-    torch.cuda.synchronize()
-    for k in LEAVES:
-        assert torch.equal(kept[k], snap[k]), k
-    # run() after that backward: dL/dloss = 1 and no face-normal gradient, whatever the slots held
-    with torch.no_grad():
-        for k in LEAVES:
-            gs.inputs[k].copy_(datt[k].reshape(gs.inputs[k].shape))
-        gs.gt.copy_(gt.to(dev))
-    gs.run()
-    torch.cuda.synchronize()
-    for k in LEAVES:
-        assert torch.equal(gs.grads[k].reshape(snap[k].shape), snap[k]), k
-    # the DEFAULT: no copies for hook-less leaves -- .grad is static memory; a leaf with a hook gets its own tensor; accumulation over steps is exact
-    gd = dr.graphed_step(datt, gt.to(dev), no_mask=True)
-    lv4 = {k: datt[k].detach().clone().requires_grad_(True) for k in LEAVES}
-    seen = []
-    lv4["lights"].register_hook(lambda g: seen.append(g.data_ptr()))
-    a4 = dict(datt); a4.update(lv4)
-    gd(gt.to(dev), **a4)[0].backward()
-    for k in LEAVES:
-        assert torch.equal(lv4[k].grad, snap[k].reshape(lv4[k].shape)), k
-        assert (lv4[k].grad.data_ptr() == gd.grads[k].data_ptr()) == (k != "lights"), k       # static memory, except the hooked leaf's copy
-    assert len(seen) == 1 and seen[0] != gd.grads["lights"].data_ptr()
-    gd(gt.to(dev), **a4)[0].backward()                            # .grad kept: copied out before the replay, then accumulated into
-    torch.cuda.synchronize()
-    for k in LEAVES:
-        assert torch.equal(lv4[k].grad, 2.0 * snap[k].reshape(lv4[k].shape)), k
-        assert lv4[k].grad.data_ptr() != gd.grads[k].data_ptr(), k
-    # the opt-in fast path: same numbers, .grad is the static buffer
-    gf = dr.graphed_step(datt, gt.to(dev), no_mask=True, fast_leaf_grads=True)
-    lv3 = {k: datt[k].detach().clone().requires_grad_(True) for k in LEAVES}
-    a3 = dict(datt); a3.update(lv3)
-    gf(gt.to(dev), **a3)[0].backward()
-    for k in LEAVES:
-        assert torch.equal(lv3[k].grad, snap[k].reshape(lv3[k].shape)), k
-        assert lv3[k].grad.data_ptr() == gf.grads[k].data_ptr()
-
-
-def test_graphed_render_replays_the_eager_render_bit_for_bit(pkg):
-    """DiffRender.graphed_render: render alone + its backward as two HIP graphs behind one autograd node, for images whose loss lives outside
-    the class (trainer.py:345-367).  Leaves and non-leaf attributes (the gradient goes on through the engine into whatever produced them),
-    an upstream gradient that reaches the image as a permuted view, a step where only face_normals is differentiated: the eager bits."""
-    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 5, 80, seed=61)
-    gr = dr.graphed_render(datt, no_mask=True)
-    B = 5
-    for it, seed in enumerate((62, 63, 64)):
-        _, _, d2, _, _, _, _, _, _ = _setup(pkg, "smpl_uv_642", B, 80, seed=seed)
-        wi = torch.linspace(-1.0, 1.0, B * 4 * H * W, device=dev).reshape(B, 4, H, W) * 1e-2
-        wf = torch.linspace(1.0, -1.0, B * dr.num_faces * 3, device=dev).reshape(B, dr.num_faces, 3) * 1e-3
-        scale = torch.full((), 1.5, device=dev, requires_grad=True)
-
-        def total(rgbs, out, it=it, wi=wi, wf=wf):
-            t = (out["face_normals"] * wf).sum()
-            return t if it == 2 else t + (rgbs * wi).sum()
-
-        def inputs(src):
-            lv = {k: src[k].detach().clone().requires_grad_(True) for k in LEAVES}
-            a = dict(src); a.update(lv)
-            if it == 1:                                          # non-leaf attributes: vertices and lights are products of something upstream
-                a["vertices"] = lv["vertices"] * scale
-                a["lights"] = lv["lights"] + 0.0
-            return lv, a
-        lv_e, a_e = inputs(d2)
-        rgbs_e, out_e = dr.render(no_mask=True, **a_e)
-        total(rgbs_e, out_e).backward()
-        ref = (rgbs_e.detach().clone(), dr.last_face_idx.clone(), {k: lv_e[k].grad.clone() for k in LEAVES}, scale.grad.clone() if it == 1 else None)
-        scale.grad = None
-        lv_g, a_g = inputs(d2)
-        rgbs_g, out_g = gr(**a_g)
-        total(rgbs_g, out_g).backward()
-        torch.cuda.synchronize()
-        assert torch.equal(rgbs_g.detach(), ref[0]) and torch.equal(dr.last_face_idx, ref[1]), it
-        for k in LEAVES:
-            assert torch.equal(lv_g[k].grad, ref[2][k]), (it, k)
-        if it == 1:
-            assert torch.equal(scale.grad, ref[3])
-            scale.grad = None
 
 
 def test_lane_exchange_primitives_on_this_gpu():

@@ -58,24 +58,6 @@ def test_market_shaped_step_ratio2():
     assert torch.isfinite(loss)
 
 
-def test_graphed_renders_give_the_eager_step_bit_for_bit():
-    """The four renders of the iteration through DiffRender.graphed_render (captured forward / backward graphs, static outputs, non-leaf
-    attributes: the gradient goes on into the encoder through the engine): three optimisation steps give the losses and the encoder weights
-    of the eager step, bit for bit (same kernels, same launch order; cuDNN-free encoders apart, whose kernels are the same in both runs)."""
-    mod = importlib.import_module("3d-magic-mirror_amd.trainer_step")
-    path = os.path.join(TEMPLATES, "sphere.npz")
-    torch.backends.cudnn.deterministic = True
-    runs = []
-    for graphed in (False, True):
-        ts = mod.TrainerStep(path, 64, 4, torch.device("cuda:0"), graphed=graphed)
-        losses = [float(ts.step()) for _ in range(3)]
-        runs.append((losses, {k: float(v) for k, v in ts.last.items()}, [p.detach().clone() for p in ts.netE.parameters()]))
-    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
-    assert runs[0][1] == runs[1][1]
-    worst = max(float((a - b).abs().max()) for a, b in zip(runs[0][2], runs[1][2]))
-    assert worst == 0.0, worst
-
-
 def test_lean_step_is_the_step():
     """TrainerStep(lean=True, many=True): renders #1-#3 as ONE DiffRender.render_many call over 3B images and render #4 as render_geometry (its
     image is discarded, trainer.py:367).  The forward is that of the four separate calls bit for bit (an image does not depend on its batch):

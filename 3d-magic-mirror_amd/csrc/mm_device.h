@@ -616,6 +616,9 @@ __device__ inline void face_pixel_box(float ax, float ay, float bx, float by, fl
 __host__ __device__ inline int sweep_shrink(float boxlen, int n) { const int s = (int)(boxlen * (float)n * 0.5f) - 1; return s > 0 ? s : 0; }
 __host__ __device__ inline void sweep_box(unsigned org, unsigned ext, bool taken, int sx, int sy, int W, int H, int& px0, int& py0, int& bw, int& bh) {
     px0 = (int)(org & 0xFFFFu); py0 = (int)(org >> 16); bw = (int)(ext & 0xFFFFu); bh = (int)(ext >> 16);
+#ifdef MM_DBG_NO_INFLATE                                        // (timing experiment only, results WRONG: every face swept over its own box -- what the K4 sweeps of the
+    taken = false;                                               //  inflated boxes cost, profiles/r05_gather_k4_bound.md)
+#endif
     if (taken || bw <= 0 || bh <= 0) return;
     const int l = px0 > 0 ? sx : 0, r = px0 + bw < W ? sx : 0, t = py0 > 0 ? sy : 0, b = py0 + bh < H ? sy : 0;
     if (bw - l - r <= 0 || bh - t - b <= 0) return;               // (cannot happen for a face that owns a pixel; never sweep nothing on a rounding doubt)

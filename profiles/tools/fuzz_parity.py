@@ -54,9 +54,19 @@ for case in range(ncase):
     contour = float(rng.choice([0.0, 0.0, 0.5, 2.0]))
     if api == "render_recon" and (H % 4 or W % 4):
         contour = 0.0
+    # upstream gradient: the loss (a batch mean: gradients of 1e-8 ... 1e-2) or, for the un-fused class API, O(1) random weights on every output
+    # channel and on face_normals -- (rgbs * w).sum() + (face_normals * wfn).sum() -- which exercises every gradient path at full magnitude
+    w_up = wfn_up = None
+    if api == "render+recon_data" and rng.random() < 0.4:
+        w_up = rng.normal(size=(B, H, W, 4)).astype(np.float32); wfn_up = rng.normal(size=(B, dr.num_faces, 3)).astype(np.float32)
+        contour = 0.0
+        api = "render + random upstream"
     tag += " | " + api + (" contour=%g" % contour if contour else "")
     try:
-        if api == "render+recon_data":
+        if api == "render + random upstream":
+            rgbs, out = dr.render(no_mask=no_mask, **datt)
+            ((rgbs.permute(0, 2, 3, 1) * torch.from_numpy(w_up).to(dev)).sum() + (out["face_normals"] * torch.from_numpy(wfn_up).to(dev)).sum()).backward()
+        elif api == "render+recon_data":
             rgbs, out = dr.render(no_mask=no_mask, **datt)
             dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask, contour=contour).backward()
         elif api == "render_recon":
@@ -85,8 +95,12 @@ for case in range(ncase):
         kw = dict(knum=knum, boxlen=boxlen, sigmainv=sigmainv)
         with oracle.options(optbit):
             rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj, **kw)
-            loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, contour=contour, want_grad=True)
-            g_o = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None, **kw)
+            if w_up is not None:
+                dpred_nhwc, wfn_o = w_up, wfn_up
+            else:
+                loss_o, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, contour=contour, want_grad=True)
+                dpred_nhwc, wfn_o = np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None
+            g_o = oracle.render_backward(inp, H, W, no_mask, proj, dpred_nhwc, wfn_o, **kw)
         nf = int((dr.last_face_idx.cpu().numpy() != fidx_o).sum())
         errs = {"rgba": float(np.abs(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy() - rgba_o).max())}
         for k in LEAVES:
@@ -101,7 +115,7 @@ for case in range(ncase):
             # A gradient beyond 1e-4 of the fp32 oracle with the image itself in agreement: is fp32 the problem?  The same backward in float64 is the
             # judge: where the fp32 ORACLE is itself far from it and the HIP result is no farther (twice its distance + 1e-4), the case is ill-conditioned
             # in fp32 (tiny screens with huge soft margins: a few pixels carry the whole loss) -- reported as COND and counted apart, never as ok.
-            g64 = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)).astype(np.float64), None, dtype=np.float64, **kw)
+            g64 = oracle.render_backward(inp, H, W, no_mask, proj, dpred_nhwc.astype(np.float64), None if wfn_o is None else wfn_o.astype(np.float64), dtype=np.float64, **kw)
             cond = True
             for k in LEAVES:
                 if datt.get(k) is None or (k == "bg" and not no_mask):
@@ -114,7 +128,7 @@ for case in range(ncase):
         bad += label == "FAIL"
         if not ok and os.environ.get("MM_FUZZ_DETAIL"):
             print("      all errors:", {k: "%.2e" % v for k, v in errs.items()})
-            g64 = oracle.render_backward(inp, H, W, no_mask, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)).astype(np.float64), None, dtype=np.float64, **kw)
+            g64 = oracle.render_backward(inp, H, W, no_mask, proj, dpred_nhwc.astype(np.float64), None if wfn_o is None else wfn_o.astype(np.float64), dtype=np.float64, **kw)
             for k in ("vertices", "distances", "azimuths"):
                 got = datt[k].grad.cpu().numpy().astype(np.float64); r32 = g_o[k].astype(np.float64); r64 = g64[k]
                 i = np.unravel_index(np.abs(got - r32).argmax(), got.shape)

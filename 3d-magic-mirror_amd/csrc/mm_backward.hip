@@ -253,7 +253,7 @@ __device__ inline void item_finish(const BwdArgs& a, FaceSlot& fs, const ItemLoa
     const int bm = box_mode(a.options);
     const bool inbox = bm ? !(box_reject(x0, fs.box[0] - a.infl, fs.box[2] + a.infl, bm) || box_reject(y0, fs.box[1] - a.infl, fs.box[3] + a.infl, bm))
                           : !(x0 < fs.box[0] - a.infl || x0 > fs.box[2] + a.infl || y0 < fs.box[1] - a.infl || y0 > fs.box[3] + a.infl);
-    if (sq != 0.f && sq != 1.f && ga != 0.f && fs.f <= ld.lf && inbox) {
+    if (sq != 0.f && (MM_K4_KEEP_ONES || sq != 1.f) && ga != 0.f && fs.f <= ld.lf && inbox) {
         const float4 p0 = fs.p0, p1 = fs.p1;
         const f2 pp = {x0, y0}, ca = {p0.x, p0.y}, cb = {p0.z, p0.w}, cc = {p1.x, p1.y};
         SegHit h = seg_nearest(pp, ca, cb);               // edge 0: corner a -> b

@@ -128,6 +128,13 @@ __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size
 // fast or faster (B=48: 16.2 vs 16.1 us at 128x128, 28.5 vs 18.0 at 256x256 where faces have several sweep items); at B=384 it is 29.6
 // against 52.5 us (profiles/r04_per_image_stages_ab.md).
 #define MM_VIMG_BWD_MAX_FACES 1700
+// K4 (silhouette backward): a pixel whose stored product is EXACTLY 1 took only faces whose factor 1 - exp(-sigma d^2) rounds to 1 in fp32 (exp below 2^-24:
+// the forward's alpha is 0 to the last bit).  Their derivative terms are not zero, only < 6e-8 of a term at exp ~ 0.5.  Rounds 1-4 skipped such pixels
+// (MM_K4_KEEP_ONES 0); since round 5 they are evaluated like any other: in an image that shows NOTHING ELSE -- a far-away mesh on an 8x8 screen -- they are the
+// whole geometry gradient, which the scale-aware parity bar sees (fuzz case 82 of seed 6106), and the skip bought no time (profiles/r05_k4_ones_ab.md).
+#ifndef MM_K4_KEEP_ONES
+#define MM_K4_KEEP_ONES 1
+#endif
 #ifndef MM_VIMG_BWD_MIN_B
 #define MM_VIMG_BWD_MIN_B 128
 #endif

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void dibr_bwd_kernel(DibrBwdArgs a) {
             const int lf = __float_as_int(st.y);
             const int bm = box_mode(a.options);
             const bool inbox = !(box_reject(x0, xmin - a.infl, xmax + a.infl, bm) || box_reject(y0, ymin - a.infl, ymax + a.infl, bm));
-            if (sq != 0.f && sq != 1.f && ga != 0.f && f <= lf && inbox) {
+            if (sq != 0.f && (MM_K4_KEEP_ONES || sq != 1.f) && ga != 0.f && f <= lf && inbox) {
                 float qx, qy, d2, qx1, qy1, d21;
                 float t = seg_nearest_t(x0, y0, p0.x, p0.y, p0.z, p0.w, qx, qy, d2);        // edge 0: a -> b
                 int e = 0;

@@ -80,35 +80,41 @@ def test_render_loss_backward_matches_oracle(pkg, oracle, name, B, S, ratio, no_
         assert np.abs(g_o[k]).max() > 0
 
 
-@pytest.mark.parametrize("label,name,B,S,seed", [
-    ("config 1", "sphere", 4, 64, 0),
-    ("config 2 (full size)", "smpl_uv_642", 48, 128, 0),
-    ("config 5 (one image)", "smpl_uv", 1, 512, 0),
+@pytest.mark.parametrize("label,name,B,S,ratio,no_mask,seed", [
+    ("config 1", "sphere", 4, 64, 1, True, 0),
+    ("config 2 (full size)", "smpl_uv_642", 48, 128, 1, True, 0),
+    ("config 5 (one image)", "smpl_uv", 1, 512, 1, True, 0),
+    ("config 3's render (full size)", "ellipsoid", 48, 256, 1, True, 8),
+    ("config 4, Market 128x64 (full size)", "smpl_uv_642", 48, 64, 2, True, 7),
+    ("white background", "sphere", 3, 50, 1, False, 4),
 ])
-def test_fused_backward_under_a_unit_scale_upstream_gradient_matches_oracle(pkg, oracle, label, name, B, S, seed):
+def test_fused_backward_under_a_unit_scale_upstream_gradient_matches_oracle(pkg, oracle, label, name, B, S, ratio, no_mask, seed):
     """The product path's backward (pixel_bwd -> gather_bwd -> vertex_bwd through mm_render_backward) driven by an O(1) upstream gradient --
     (rgbs * w).sum() + (face_normals * wfn).sum(), w and wfn ~ N(0,1) -- instead of the batch-mean loss, whose gradients are 1e-8 ... 1e-2
     large: every one of the eight input gradients is O(1) ... O(1e4) here and must agree with the oracle's to 1e-4 of its own maximum.
     (A case the fp32 oracle itself cannot hold against its float64 form would be decided by the float64 backward and pass as 'cond':
     none does -- profiles/r05_parity_relative.md.)"""
-    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, seed=seed)
+    dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, name, B, S, ratio=ratio, seed=seed, no_mask=no_mask)
     rng = np.random.default_rng(seed + 77)
     w = rng.normal(size=(B, H, W, 4)).astype(np.float32)
     wfn = rng.normal(size=(B, dr.num_faces, 3)).astype(np.float32)
-    rgbs, out = dr.render(no_mask=True, **datt)
+    rgbs, out = dr.render(no_mask=no_mask, **datt)
     ((rgbs.permute(0, 2, 3, 1) * torch.from_numpy(w).to(dev)).sum() + (out["face_normals"] * torch.from_numpy(wfn).to(dev)).sum()).backward()
     torch.cuda.synchronize()
-    rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, True, proj)
+    rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj)
     assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
-    g_o = oracle.render_backward(inp, H, W, True, proj, w, wfn)
+    g_o = oracle.render_backward(inp, H, W, no_mask, proj, w, wfn)
     g64 = {}
 
     def ref64(k):
         if not g64:
-            g64.update(oracle.render_backward(inp, H, W, True, proj, w.astype(np.float64), wfn.astype(np.float64), dtype=np.float64))
+            g64.update(oracle.render_backward(inp, H, W, no_mask, proj, w.astype(np.float64), wfn.astype(np.float64), dtype=np.float64))
         return g64[k]
     verdicts = {}
     for k in LEAVES:
+        if k == "bg" and not no_mask:
+            assert datt[k].grad is None
+            continue
         assert float(np.abs(g_o[k]).max()) > 0.5, (k, "the upstream gradient was meant to make every input gradient O(1) or larger")
         verdicts[k] = grad_close(datt[k].grad, g_o[k], rtol=1e-4, what="%s, %s" % (label, k), ref64=lambda k=k: ref64(k))
     assert all(v == "ok" for v in verdicts.values()), verdicts      # (a 'cond' here would be news: say so instead of passing silently)
@@ -358,6 +364,41 @@ def test_fuzz_regressions_pixel_pass_recomputes_the_forward_bit_for_bit(pkg, ora
         if k == "bg" and not no_mask:
             continue
         _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
+
+
+def test_fuzz_regression_an_image_that_shows_nothing_still_has_its_tiny_geometry_gradient(pkg, oracle):
+    """Found by profiles/tools/fuzz_parity.py under round 5's scale-aware bar (case 82 of seed 6106): an 8x8 screen, the camera 25 units away, white
+    background -- no pixel is covered and every silhouette factor 1 - exp(-sigma d^2) rounds to exactly 1, so the image is alpha = 0 to the last bit.  The
+    derivative terms of those factors are 1e-9 small but they are the WHOLE geometry gradient of this batch; the backward used to skip pixels whose stored
+    product is exactly 1 and returned exact zeros (invisible to the old absolute bar).  Same bar as everywhere: 1e-4 of each gradient's own maximum."""
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "ellipsoid.npz"), 8)
+    dr.boxlen, dr.sigmainv = 0.05, 7000.0
+    N = pkg._native
+    dr.options = N.OPT_BARY_ONE_MINUS | N.OPT_BBOX_MIN_CLOSED_MAX_OPEN | N.OPT_WALK_BATCH        # (the case's option bits: 640 | 2048)
+    assert dr.options == 640 | 2048
+    dev = torch.device("cuda:0")
+    B, H, W = 8, 8, 8
+    att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=295243571)
+    att["distances"] = torch.full_like(att["distances"], 25.444954239929586)
+    datt = {k: (v.to(dev).requires_grad_(k in LEAVES) if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp["faces"] = dr.faces.numpy().astype(np.int32); inp["face_uvs"] = dr.face_uvs.numpy()[0]
+    proj = dr.cam_proj.numpy().reshape(3)
+    loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=False, **datt)
+    loss.backward()
+    kw = dict(boxlen=0.05, sigmainv=7000.0)
+    with oracle.options(640):
+        rgba_o, fidx_o, _, _ = oracle.render_forward(inp, H, W, False, proj, **kw)
+        _, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, want_grad=True)
+        g_o = oracle.render_backward(inp, H, W, False, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None, **kw)
+    assert (fidx_o == -1).all() and float(rgba_o[..., 3].max()) == 0.0                         # the image shows nothing at all
+    assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
+    assert np.array_equal(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
+    for k in ("vertices", "azimuths", "elevations", "distances", "biases"):
+        assert 0 < float(np.abs(g_o[k]).max()) < 1e-8, k                                       # tiny, and not zero
+        _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
+    for k in ("textures", "lights"):
+        assert float(np.abs(g_o[k]).max()) == 0.0 and float(datt[k].grad.abs().max()) == 0.0
 
 
 def test_backward_twice_after_one_forward(pkg):

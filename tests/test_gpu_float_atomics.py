@@ -86,8 +86,8 @@ def test_texture_mapping_backward_without_a_workspace_has_a_bounded_spread():
     floats = [run(False) for _ in range(4)]
     spread = max(rel_errors(f, floats[0])[0] for f in floats[1:])
     off = max(rel_errors(f, fixed[0])[0] for f in floats)
-    assert spread <= 2e-6, spread                                    # a few ulps of the largest sum: the order of ~16 float adds per texel
-    assert off <= 2e-6, off
+    assert spread <= 5e-6, spread                                    # a few ulps of the largest sum: the order of ~16 float adds per texel (measured 2e-7 ... 6e-7)
+    assert off <= 5e-6, off
     print("texture_mapping backward without a workspace: run-to-run spread %.2e, distance from the fixed-point path %.2e (of max|grad|)" % (spread, off))
 
 
@@ -107,7 +107,7 @@ def test_texture_flow_image_gradient_has_a_bounded_spread():
     for gi, gf in grads[1:]:
         assert torch.equal(gf, grads[0][1])                          # the flow gradient has no atomic: bit-identical
     spread = max(rel_errors(gi, grads[0][0])[0] for gi, _ in grads[1:])
-    assert float(grads[0][0].abs().max()) > 0 and spread <= 2e-6, spread
+    assert float(grads[0][0].abs().max()) > 0 and spread <= 5e-6, spread
     # against torch's own bicubic grid_sample (float64, CPU)
     im64 = img.double().requires_grad_(True)
     grid = flow.permute(0, 2, 3, 1).double()

@@ -86,7 +86,7 @@ def test_texture_mapping_backward_without_a_workspace_has_a_bounded_spread():
     floats = [run(False) for _ in range(4)]
     spread = max(rel_errors(f, floats[0])[0] for f in floats[1:])
     off = max(rel_errors(f, fixed[0])[0] for f in floats)
-    assert spread <= 5e-6, spread                                    # a few ulps of the largest sum: the order of ~16 float adds per texel (measured 2e-7 ... 6e-7)
+    assert spread <= 5e-6, spread                                    # a few ulps of the largest sum: the order of ~16 float adds per texel
     assert off <= 5e-6, off
     print("texture_mapping backward without a workspace: run-to-run spread %.2e, distance from the fixed-point path %.2e (of max|grad|)" % (spread, off))
 

@@ -12,6 +12,13 @@
 #include "../../include/mm_render.h"
 
 #define MM_WAVE 64
+// MM_FP_EXACT at the head of a block: every fp32 expression inside rounds as written, whatever the translation unit's flags (the relaxed backward
+// includes these functions too).  -DMM_ALLOW_CONTRACT (bound experiments only, wrong bits): the block follows the translation unit's flags.
+#ifdef MM_ALLOW_CONTRACT
+#define MM_FP_EXACT
+#else
+#define MM_FP_EXACT _Pragma("clang fp contract(off)")
+#endif
 // a value that is the same in all lanes of the wave BY CONSTRUCTION (derived from threadIdx.x >> 6 and the like), said so: the compiler then
 // keeps it in a scalar register, and what is addressed by it becomes scalar arithmetic and scalar-cache loads.  -DMM_NO_SCALAR_WAVE: A/B switch.
 #ifdef MM_NO_SCALAR_WAVE
@@ -279,7 +286,7 @@ __device__ inline float pixel_y(int py, int H, float mult) { return (mult / (flo
 // Hence: no contraction inside (pragma), no division (the flags change how `/` rounds), pixel centre and sigma' passed in as the
 // forward computes them (IEEE: multiplier / W and sigmainv / multiplier^2 are formed on the host for the backward).
 __device__ inline float seg_dist2_fast(float px, float py, float ux, float uy, float vx, float vy) {
-#pragma clang fp contract(off)
+MM_FP_EXACT
     const float ex = vx - ux, ey = vy - uy, rx = px - ux, ry = py - uy;
     const float len2 = ex * ex + ey * ey;
     const float dot = rx * ex + ry * ey;
@@ -289,19 +296,23 @@ __device__ inline float seg_dist2_fast(float px, float py, float ux, float uy, f
     return qx * qx + qy * qy;
 }
 __device__ inline float soft_factor(float x0, float y0, const float4& p0, const float4& p1, float sig2) {
-#pragma clang fp contract(off)
+MM_FP_EXACT
+#ifdef MM_BOUND_SOFT1                                           // (bound experiment, WRONG results: one edge instead of three)
+    const float d = seg_dist2_fast(x0, y0, p0.x, p0.y, p0.z, p0.w);
+#else
     const float d = fminf(fminf(seg_dist2_fast(x0, y0, p0.x, p0.y, p0.z, p0.w), seg_dist2_fast(x0, y0, p0.z, p0.w, p1.x, p1.y)),
                           seg_dist2_fast(x0, y0, p1.x, p1.y, p0.x, p0.y));
+#endif
     return 1.f - __builtin_amdgcn_exp2f(-(d * sig2) * 1.4426950408889634f);
 }
 // pixel centre from the host-formed factor k = multiplier / W (or / H): the same float as pixel_x / pixel_y in a translation unit with
 // IEEE division, in any translation unit
 __device__ inline float pixel_x_k(int px, int W, float kx) {
-#pragma clang fp contract(off)
+MM_FP_EXACT
     return kx * (float)(2 * px + 1 - W);
 }
 __device__ inline float pixel_y_k(int py, int H, float ky) {
-#pragma clang fp contract(off)
+MM_FP_EXACT
     return ky * (float)(H - 2 * py - 1);
 }
 
@@ -346,7 +357,12 @@ __device__ inline void bary_weights(float ax, float ay, float bx, float by, floa
                                     float& w0, float& w1, float& w2, float& nrm) {
     if (!one_minus) {
         edge_weights(ax, ay, bx, by, cx, cy, x0, y0, eps, w0, w1, w2, nrm);
+#ifdef MM_BOUND_FASTDIV                                         // (bound experiment, WRONG bits: one hardware reciprocal instead of three IEEE divisions)
+        const float r = __builtin_amdgcn_rcpf(nrm);
+        w0 *= r; w1 *= r; w2 *= r;
+#else
         w0 /= nrm; w1 /= nrm; w2 /= nrm;
+#endif
         return;
     }
     float aex = ax - x0, aey = ay - y0, bex = bx - x0, bey = by - y0, cex = cx - x0, cey = cy - y0;

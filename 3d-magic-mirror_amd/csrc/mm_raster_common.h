@@ -100,7 +100,7 @@ __device__ inline float next_down(float v) {
 }
 __device__ inline void box_masks(const RasterArgs& a, const TileCtx& t, float xlo, float ylo, float xhi, float yhi, bool hard, bool soft, int mode,
                                  uint64_t& mh, uint64_t& ms) {
-#pragma clang fp contract(off)
+MM_FP_EXACT
     float xlo2 = xlo - a.infl, ylo2 = ylo - a.infl, xhi2 = xhi + a.infl, yhi2 = yhi + a.infl;
     // An OPEN border (MM_OPT_BBOX_HALF_OPEN / MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN: a centre exactly on it is outside) is the closed test against
     // the neighbouring float: the same decisions as  x <= lo / x >= hi, and one code path for the three forms (the kernel's register
@@ -178,7 +178,7 @@ __device__ inline unsigned long long depth_key(float z, int rank) {
 // ~6e-7 of the largest |z|; 1e-5 of it is added.  A face whose bound lies below what a pixel already holds can never win that pixel
 // (strictly below: equal depths, which the lower face index wins, are never cut) -- the walk's early-z, exact.
 __device__ inline unsigned depth_bound(float az, float bz, float cz) {
-#pragma clang fp contract(off)
+MM_FP_EXACT
     const float zmax = fmaxf(fmaxf(az, bz), cz), amax = fmaxf(fmaxf(fabsf(az), fabsf(bz)), fabsf(cz));
     const float zb = zmax + 1e-5f * amax;
     return (zb == zb && amax < INFINITY) ? depth_ord(zb) : 0xFFFFFFFFu;     // (NaN / inf corners: never cut)
@@ -252,7 +252,7 @@ __device__ inline void hard_pairs(const RasterArgs& a, const TileCtx& t, Stage* 
             const unsigned kh0 = (unsigned)(st->key[l0] >> 32), kh1 = (unsigned)(st->key[l1] >> 32);
             bool pass0, pass1;
             {
-#pragma clang fp contract(off)
+MM_FP_EXACT
                 const mm_f2 x0 = {a.kx * (t.xf0 + (float)(2 * (l0 & 7))), a.kx * (t.xf0 + (float)(2 * (l1 & 7)))};
                 const mm_f2 y0 = {a.ky * (t.yf0 - (float)(2 * (l0 >> 3))), a.ky * (t.yf0 - (float)(2 * (l1 >> 3)))};
                 const mm_f2 ax = {A0.x, A1.x}, ay = {A0.y, A1.y}, bx = {A0.z, A1.z}, by = {A0.w, A1.w}, cx = {B0.x, B1.x}, cy = {B0.y, B1.y};
@@ -295,6 +295,9 @@ __device__ inline void hard_pairs(const RasterArgs& a, const TileCtx& t, Stage* 
 // sig2 = sigmainv / multiplier^2 (d is in multiplier units).
 template <class Stage>
 __device__ inline void soft_pair(const RasterArgs& a, const TileCtx& t, Stage* st, Stage* acc, float sig2, int l, int j, bool live) {
+#ifdef MM_BOUND_NOSOFT                                          // (bound experiment, WRONG results: the silhouette pairs cost nothing)
+    return;
+#endif
     const float x0 = pixel_x_k(t.tx0 + (l & 7), a.W, a.kx), y0 = pixel_y_k(t.ty0 + (l >> 3), a.H, a.ky);
     const float4 p0 = st->p0[j], p1 = st->p1[j];
     const float q = soft_factor(x0, y0, p0, p1, sig2);
@@ -314,7 +317,7 @@ __device__ inline void soft_pair(const RasterArgs& a, const TileCtx& t, Stage* s
 // are issued per half): q is BIT-IDENTICAL to soft_factor's, which the backward divides the stored product by.
 // sm: this lane's pixel, bit j = queued candidate j it takes.
 __device__ inline mm_f2 seg_dist2_pk(mm_f2 px, mm_f2 py, mm_f2 ux, mm_f2 uy, mm_f2 vx, mm_f2 vy) {
-#pragma clang fp contract(off)
+MM_FP_EXACT
     const mm_f2 ex = vx - ux, ey = vy - uy, rx = px - ux, ry = py - uy;
     const mm_f2 len2 = ex * ex + ey * ey;
     const mm_f2 dot = rx * ex + ry * ey;
@@ -327,6 +330,9 @@ __device__ inline mm_f2 seg_dist2_pk(mm_f2 px, mm_f2 py, mm_f2 ux, mm_f2 uy, mm_
 }
 template <class Stage>
 __device__ inline void soft_pairs(const RasterArgs& a, const TileCtx& t, Stage* st, uint64_t sm, float sig2) {
+#ifdef MM_BOUND_NOSOFT
+    return;
+#endif
     int total;
     int k = wave_prefix_excl(__popcll(sm), t.lane, total);      // index of this lane's next unwritten pair
     uint64_t rem = sm;
@@ -346,12 +352,16 @@ __device__ inline void soft_pairs(const RasterArgs& a, const TileCtx& t, Stage* 
             const float4 A0 = st->p0[j0], B0 = st->p1[j0], A1 = st->p0[j1], B1 = st->p1[j1];
             float q[2];
             {
-#pragma clang fp contract(off)
+MM_FP_EXACT
                 const mm_f2 x0 = {a.kx * (t.xf0 + (float)(2 * (l0 & 7))), a.kx * (t.xf0 + (float)(2 * (l1 & 7)))};
                 const mm_f2 y0 = {a.ky * (t.yf0 - (float)(2 * (l0 >> 3))), a.ky * (t.yf0 - (float)(2 * (l1 >> 3)))};
                 const mm_f2 ax = {A0.x, A1.x}, ay = {A0.y, A1.y}, bx = {A0.z, A1.z}, by = {A0.w, A1.w}, cx = {B0.x, B1.x}, cy = {B0.y, B1.y};
                 const mm_f2 d0 = seg_dist2_pk(x0, y0, ax, ay, bx, by), d1 = seg_dist2_pk(x0, y0, bx, by, cx, cy), d2 = seg_dist2_pk(x0, y0, cx, cy, ax, ay);
+#ifdef MM_BOUND_SOFT1                                           // (bound experiment, WRONG results: one edge instead of three)
+                const float dx = d0.x, dy = d0.y;
+#else
                 const float dx = fminf(fminf(d0.x, d1.x), d2.x), dy = fminf(fminf(d0.y, d1.y), d2.y);
+#endif
                 q[0] = 1.f - __builtin_amdgcn_exp2f(-(dx * sig2) * 1.4426950408889634f);
                 q[1] = 1.f - __builtin_amdgcn_exp2f(-(dy * sig2) * 1.4426950408889634f);
             }

@@ -26,7 +26,7 @@ class MMRenderDesc(ctypes.Structure):
                 ("rgba", c_p), ("face_idx", c_p), ("face_normals", c_p), ("imnormal", c_p),
                 ("workspace", c_p), ("workspace_bytes", ctypes.c_size_t), ("prof_events", c_p),
                 ("fused_gt", c_p), ("fused_image_weight", c_f), ("fused_loss", c_p), ("fused_grad_loss", c_p),
-                ("options", c_i), ("geometry_only", c_i), ("status_flag", c_p), ("fused_contour", c_f)]
+                ("options", c_i), ("geometry_only", c_i), ("status_flag", c_p), ("fused_contour", c_f), ("fused_totals", c_p)]
 
 
 class MMRenderGrads(ctypes.Structure):
@@ -117,7 +117,7 @@ class MMMaskIouDesc(ctypes.Structure):
 
 
 PROF_RENDER = ("vertex_fwd", "raster_fwd", "pixel_bwd", "gather_bwd", "vertex_bwd", "order")
-ABI_VERSION = 5
+ABI_VERSION = 6
 OPT_WALK_BLOCK, OPT_WALK_WAVE = 1 << 1, 1 << 2
 OPT_CULL_STRICT, OPT_SOFT_SKIP_CULLED, OPT_BBOX_HALF_OPEN, OPT_BARY_ONE_MINUS, OPT_SH_ORDER_XYZ = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9
@@ -125,7 +125,7 @@ OPT_WALK_QUEUE, OPT_WALK_BATCH = 1 << 10, 1 << 11
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_render_status", "mm_render_fused_loss", "mm_debug_workspace_layout", "mm_recon_query_workspace",
-           "mm_recon_data_forward", "mm_recon_data_backward", "mm_build_vertex_corner_csr", "mm_build_vertex_corner_csr_device", "mm_build_vertex_corner_table", "mm_nearest_neighbour", "mm_chamfer_nearest", "mm_status_string", "mm_last_error_detail",
+           "mm_recon_data_forward", "mm_recon_data_backward", "mm_recon_data_totals", "mm_build_vertex_corner_csr", "mm_build_vertex_corner_csr_device", "mm_build_vertex_corner_table", "mm_nearest_neighbour", "mm_chamfer_nearest", "mm_status_string", "mm_last_error_detail",
            "mm_mesh_reg_query_workspace", "mm_mesh_reg_forward", "mm_mesh_reg_backward", "mm_texture_flow_forward",
            "mm_texture_flow_backward", "mm_attribute_loss_query_workspace", "mm_attribute_loss_forward",
            "mm_attribute_loss_backward",
@@ -171,6 +171,8 @@ def lib():
     L.mm_recon_query_workspace.argtypes = [ctypes.POINTER(MMReconDesc)]
     L.mm_recon_data_forward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
     L.mm_recon_data_backward.argtypes = [ctypes.POINTER(MMReconDesc), c_p]
+    L.mm_recon_data_totals.restype = c_p
+    L.mm_recon_data_totals.argtypes = [ctypes.POINTER(MMReconDesc)]
     L.mm_nearest_neighbour.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]
     L.mm_chamfer_nearest.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     L.mm_mesh_reg_query_workspace.restype = ctypes.c_size_t

@@ -14,6 +14,7 @@ int launch_fused_loss(const MMRenderDesc*, const Workspace&, hipStream_t);
 size_t recon_workspace_bytes(const MMReconDesc*);
 int launch_recon_fwd(const MMReconDesc*, hipStream_t);
 int launch_recon_bwd(const MMReconDesc*, hipStream_t);
+const float* recon_totals(const MMReconDesc*);
 int launch_nn(int, int, int, const float*, const float*, float*, int32_t*, hipStream_t);
 int launch_nn_both(int, int, int, const float*, const float*, float*, int32_t*, float*, int32_t*, hipStream_t);
 size_t reg_workspace_bytes(const MMMeshRegDesc*);
@@ -43,6 +44,11 @@ static int check_render(const MMRenderDesc* d, bool backward) {
     if (d->fused_gt && !d->geometry_only) {                                       // the contour term of the fused loss (include/mm_render.h)
         if (!(d->fused_contour >= 0.f)) return MM_ERR_BAD_SHAPE;
         if (d->fused_contour > 0.f && ((d->H & 3) || (d->W & 3))) return MM_ERR_BAD_SHAPE;
+    }
+    if (d->fused_totals) {                                                        // deferred fusion: the backward of a render whose recon_data ran on its own
+        if (!backward || d->geometry_only) return MM_ERR_UNSUPPORTED;
+        if (!d->fused_gt) return MM_ERR_NULL_POINTER;
+        if (d->fused_contour != 0.f) return MM_ERR_UNSUPPORTED;
     }
     if (backward && !d->vc_table) return MM_ERR_NULL_POINTER;
     if (backward && d->vc_stride <= 0) return MM_ERR_BAD_SHAPE;
@@ -148,6 +154,11 @@ int mm_recon_data_backward(const MMReconDesc* d, mm_stream_t stream) {
     if (st != MM_OK) return st;
     mm::clear_stale_error();
     return mm::launch_recon_bwd(d, (hipStream_t)stream);
+}
+
+const float* mm_recon_data_totals(const MMReconDesc* d) {
+    if (!d || d->B <= 0 || !d->workspace || d->workspace_bytes < mm_recon_query_workspace(d)) return nullptr;
+    return mm::recon_totals(d);
 }
 
 int mm_nearest_neighbour(int32_t B, int32_t N, int32_t M, const float* x, const float* y, float* dist, int32_t* idx,

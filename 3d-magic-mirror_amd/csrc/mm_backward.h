@@ -35,6 +35,9 @@ struct BwdArgs {
     // fused recon_data (gt == nullptr: off)
     const float* gt; const float* rgba; const float* grad_loss; float* loss; float image_weight, contour;
     const long long* ltot;                                       // (B,MM_LSUB,4) fused loss sums of the raster waves (fixed point)
+                                                                 // DEFERRED fusion (MMRenderDesc.fused_totals; options & MM_INT_DEFERRED): the SAME field carries
+                                                                 // mm_recon_data_forward's per-image totals (B,4) floats instead (deferred_totals below) -- one more
+                                                                 // pointer in this struct costs the default pixel kernel eight scalar-register spills
     // gather
     unsigned* gmax;                                              // (B,2) per image: max |K2 number| and max |dL/dalpha| as float bits (pixel pass -> gather)
     const int2* items; const int2* nitems; float* part; int item_cap;   // sweep items {face, chunk} of the plan workgroups; their partial sums
@@ -42,6 +45,9 @@ struct BwdArgs {
     int ntx, nty;
     float* grad_textures;
 };
+
+#define MM_INT_DEFERRED (1 << 30)   // BwdArgs::options, set by launch_raster_bwd (not an MM_OPT_* bit of the ABI)
+__device__ inline const float* deferred_totals(const BwdArgs& a) { return reinterpret_cast<const float*>(a.ltot); }
 
 __device__ inline void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

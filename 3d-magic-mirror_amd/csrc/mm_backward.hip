@@ -470,8 +470,9 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.tcur = w.tcur; a.tdrop = w.tdrop; a.trcnt = w.trcnt; a.toff = w.toff; a.tstatus = w.tstatus; a.trec = w.trec; a.ntiles_ = w.ntiles; a.trcap = w.trcap;
     a.gmax = w.gmax;                                             // (B, MM_GSHARD, 8): two maxima per 32-byte sector
     a.status_flag = d->status_flag;
-    a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_loss;
+    a.gt = d->fused_gt; a.rgba = d->rgba; a.grad_loss = d->fused_grad_loss; a.loss = d->fused_totals ? nullptr : d->fused_loss;
     a.image_weight = d->fused_image_weight; a.contour = d->fused_gt ? d->fused_contour : 0.f; a.ltot = w.ltot;
+    if (d->fused_gt && d->fused_totals) { a.options |= MM_INT_DEFERRED; a.ltot = reinterpret_cast<const long long*>(d->fused_totals); }   // (deferred fusion: see BwdArgs::ltot)
     a.items = w.items; a.nitems = w.nitems; a.part = w.part; a.item_cap = w.item_cap;
     a.plan_chunkmap = w.chunkmap; a.plan_items = w.items; a.plan_nitems = w.nitems; a.plan_wgs = d->F > 4096 ? MM_PLAN_WGS : 1;
     a.ntx = (d->Wt + MM_TS - 1) / MM_TS; a.nty = (d->Ht + MM_TS - 1) / MM_TS;

@@ -182,6 +182,8 @@ size_t recon_workspace_bytes(const MMReconDesc* d) {
     return align256(((size_t)d->B * MM_LOSS_CHUNKS * 4 + (size_t)d->B * 4) * sizeof(float));
 }
 
+const float* recon_totals(const MMReconDesc* d) { return (const float*)d->workspace + (size_t)d->B * MM_LOSS_CHUNKS * 4; }   // (make_loss_args' `totals`)
+
 int launch_recon_fwd(const MMReconDesc* d, hipStream_t s) {
     LossArgs a = make_loss_args(d);
     { ProfScope p(d->prof_events, MM_PROF_RECON_PARTIAL, s);

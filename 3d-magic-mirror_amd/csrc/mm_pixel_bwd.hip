@@ -128,7 +128,10 @@ __device__ inline void plan_sweep_items(const BwdArgs& a, int b, int q) {
 // kContour: the fused loss carries recon_data's contour term (MMRenderDesc.fused_contour > 0).  The reference's default is --lambda_contour 0
 // (train.py:115, trainer.py:441): the default caller gets the instantiation without the term's code (24 vector instructions per wave and its
 // registers), chosen by the host.
-template <bool kNoMask, bool kContour>
+// kDeferred: DEFERRED fusion (BwdArgs::ltot as deferred_totals, MMRenderDesc.fused_totals): recon_data ran on its own on the image this render wrote; dL/d rgba is formed
+// here with mm_recon_data_backward's expressions (csrc/mm_loss.hip: recon_bwd_kernel), in their order, from that call's per-image totals -- the bits
+// that kernel would have written -- plus the caller's grad_rgba if there is one.  Never together with kContour.
+template <bool kNoMask, bool kContour, bool kDeferred>
 __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) {
     MM_TIMELINE_BEGIN();
     __shared__ float s_dl[MM_BLOCK_WAVES][9];
@@ -160,7 +163,26 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
     // back (16 bytes per pixel of a bandwidth-bound kernel); the sign is taken where the pixel's colour is re-formed (grad_colour below).
     float gi3[3] = {0.f, 0.f, 0.f}, gmv = 0.f, kl1 = 0.f;
     const bool fused = a.gt != nullptr;
-    if (fused) {
+    float gsw = 0.f, cnt = 1.f;                                  // kDeferred: gs * image_weight and B*3*H*W, as recon_bwd_kernel forms them
+    if (kDeferred) {
+        const float gs = a.grad_loss ? a.grad_loss[0] : 1.f;
+        gsw = gs * a.image_weight;
+        cnt = (float)a.B * 3.f * (float)a.H * (float)a.W;
+        const float up = deferred_totals(a)[b * 4 + 1], U = deferred_totals(a)[b * 4 + 2] + 1e-10f;
+        if (in_img) {
+            hf = a.face_idx[pix];
+            const float* g = a.gt + (size_t)b * 4 * hw;
+            const float gm = g[3 * hw + pin];
+            gmv = gm;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gi3[c] = g[c * hw + pin] * gm + 1.f * (1.f - gm);
+            g4.w = gs * (-(1.f / (float)a.B) * (gm / U - up * (1.f - gm) / (U * U)));
+            if (a.grad_rgba) {                                   // the image's other consumers (autograd would have added the two gradients)
+                const float4 ext = *(const float4*)(a.grad_rgba + pix * 4);
+                g4.x = ext.x; g4.y = ext.y; g4.z = ext.z; g4.w += ext.w;
+            }
+        }
+    } else if (fused) {
         // the image's totals are exact integer sums left by its raster waves
         float l1s, up, un;
         loss_totals(a.ltot, b, l1s, up, un);
@@ -206,6 +228,7 @@ __global__ __launch_bounds__(256, MM_PIXEL_LB) void pixel_bwd_kernel(BwdArgs a) 
         const float pc = pre < 0.f ? 0.f : (pre > 1.f ? 1.f : pre);
         const float pi = pc * gmv + 1.f * (1.f - gmv);
         const float df = pi - gi3[c], sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        if (kDeferred) return gsw * sg * gmv / cnt + gin[c];     // recon_bwd_kernel: gs * image_weight * sg * gm / cnt  (+ the caller's own gradient, 0 if none)
         return kl1 * sg * gmv;
     };
     float m2 = 0.f, m4 = 0.f;                                    // this lane's largest |K2 number| / |dL/dalpha|: the gather's fixed-point scale
@@ -455,8 +478,13 @@ int launch_pixel_bwd(const BwdArgs& a, const MMRenderDesc* d, hipStream_t s) {
     ProfScope p(d->prof_events, MM_PROF_PIXEL_BWD, s);
     dim3 grid(a.blocks_per_image * d->B + a.plan_wgs * d->B);    // + the plan workgroups, in front
     const bool contour = a.gt != nullptr && a.contour > 0.f;
-    if (d->no_mask) { if (contour) hipLaunchKernelGGL((pixel_bwd_kernel<true, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((pixel_bwd_kernel<true, false>), grid, dim3(256), 0, s, a); }
-    else { if (contour) hipLaunchKernelGGL((pixel_bwd_kernel<false, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((pixel_bwd_kernel<false, false>), grid, dim3(256), 0, s, a); }
+    if (a.options & MM_INT_DEFERRED) {                           // deferred fusion (never with the contour term: check_render)
+        if (d->no_mask) hipLaunchKernelGGL((pixel_bwd_kernel<true, false, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((pixel_bwd_kernel<false, false, true>), grid, dim3(256), 0, s, a);
+        return MM_OK;
+    }
+    if (d->no_mask) { if (contour) hipLaunchKernelGGL((pixel_bwd_kernel<true, true, false>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((pixel_bwd_kernel<true, false, false>), grid, dim3(256), 0, s, a); }
+    else { if (contour) hipLaunchKernelGGL((pixel_bwd_kernel<false, true, false>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((pixel_bwd_kernel<false, false, false>), grid, dim3(256), 0, s, a); }
     return MM_OK;
 }
 

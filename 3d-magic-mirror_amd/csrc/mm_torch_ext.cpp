@@ -11,10 +11,51 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // device guard + current stream of a ROCm build of torch (host headers only)
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "../../include/mm_render.h"
 
 namespace {
+
+// ---- DEFERRED FUSION (MMRenderDesc.fused_totals, ABI 6) ---------------------------------------------------------------------------------------
+// The un-modified trainer calls `pred, att = render(...)` and later `recon_data(pred, gt)` (trainer.py:276,441).  When that `pred` is the untouched
+// image of a render of this process, the loss VALUE is formed by mm_recon_data_forward as always, but its BACKWARD is routed into the render node:
+// the render node hands out, next to the image, a one-element `token`; recon_data consumes (token, pred.detach(), gt) instead of (pred, gt); its
+// backward returns dL/dloss as the token's gradient and launches nothing; the render node's backward, seeing a token gradient, runs
+// mm_render_backward with fused_gt / fused_totals: no dL/drgba tensor, no recon_data backward launch, no read of it by the pixel pass -- and the
+// bits mm_recon_data_backward + mm_render_backward would have produced (csrc/mm_pixel_bwd.hip: kDeferred).  Gradients that reach the image from
+// its OTHER consumers arrive as grad_rgba as before and are added.
+// What a render leaves for a later recon_data to find (keyed by the image's storage address), and what recon_data leaves for the render's backward:
+struct Mailbox {
+    const void* rgba_ptr = nullptr;
+    const void* node = nullptr;             // the render's autograd node (identity of `pred`'s producer)
+    uint32_t version = 0;                   // the image's version counter when render returned it
+    int64_t B = 0, H = 0, W = 0;
+    at::Tensor token;                       // the render node's fifth output
+    bool claimed = false;                   // a recon_data has taken this render (a second one runs un-deferred)
+    at::Tensor gt, recon_ws;                // recon_data's dense target and its workspace (the totals live in it)
+    const float* totals = nullptr;
+    double image_weight = 0.0;
+};
+std::mutex g_mail_mutex;
+std::unordered_map<const void*, std::weak_ptr<Mailbox>> g_mail;      // image storage address -> its render's mailbox (weak: dies with the node)
+
+// a 0-byte CPU tensor whose storage context owns a shared_ptr<Mailbox>: the form in which an AutogradContext can hold it (saved_data takes IValues)
+void mailbox_deleter(void* ctx) { delete static_cast<std::shared_ptr<Mailbox>*>(ctx); }
+at::Tensor mailbox_holder(const std::shared_ptr<Mailbox>& mb) {
+    auto* ctx = new std::shared_ptr<Mailbox>(mb);
+    c10::DataPtr dp(nullptr, ctx, &mailbox_deleter, c10::Device(c10::kCPU));
+    c10::Storage st(c10::Storage::use_byte_size_t(), 0, std::move(dp), nullptr, false);
+    return at::empty({0}, at::TensorOptions().dtype(at::kByte)).set_(st, 0, {0}, {1});
+}
+std::shared_ptr<Mailbox> mailbox_of(const at::Tensor& holder) {
+    if (!holder.defined()) return nullptr;
+    const c10::DataPtr& dp = holder.storage().data_ptr();
+    if (dp.get_deleter() != &mailbox_deleter || !dp.get_context()) return nullptr;
+    return *static_cast<std::shared_ptr<Mailbox>*>(dp.get_context());
+}
 
 typedef int (*render_fwd_t)(const MMRenderDesc*, void*);
 typedef int (*render_bwd_t)(const MMRenderDesc*, const MMRenderGrads*, void*);
@@ -93,10 +134,11 @@ std::vector<at::Tensor> render_backward(int64_t f_bwd, const std::string& proto,
                                         c10::optional<at::Tensor> bg, at::Tensor azimuths, at::Tensor elevations, at::Tensor distances,
                                         at::Tensor biases, at::Tensor face_idx, at::Tensor fn, c10::optional<at::Tensor> gt,
                                         c10::optional<at::Tensor> rgba_fwd, c10::optional<at::Tensor> g_rgba, c10::optional<at::Tensor> g_fn,
-                                        c10::optional<at::Tensor> g_loss, double image_weight, at::Tensor ws, int64_t stream) {
+                                        c10::optional<at::Tensor> g_loss, double image_weight, at::Tensor ws, int64_t stream, int64_t deferred_totals) {
     MMRenderDesc d = proto_desc(proto);
     const int64_t B = azimuths.size(0), H = d.H, W = d.W;
     const bool fused = gt.has_value() && gt->defined();
+    const bool deferred = fused && deferred_totals != 0;         // deferred fusion: gt / totals come from the recon_data that consumed this render's image
     at::Tensor grgba, gfn, gloss;
     d.vertices = fptr(vertices); d.textures = fptr(textures); d.lights = fptr(lights); d.bg = d.no_mask ? optp(bg) : nullptr;
     d.azimuths = fptr(azimuths); d.elevations = fptr(elevations); d.distances = fptr(distances); d.biases = fptr(biases);
@@ -110,6 +152,10 @@ std::vector<at::Tensor> render_backward(int64_t f_bwd, const std::string& proto,
                                                           : at::zeros({}, vertices.options().dtype(at::kFloat));
         d.fused_gt = optp(gt); d.fused_image_weight = (float)image_weight; d.fused_grad_loss = fptr(gloss);
         d.rgba = nullptr;                                    // the backward re-forms the prediction per pixel: the image is not read back (nor saved)
+        if (deferred) {
+            d.fused_totals = reinterpret_cast<const float*>(deferred_totals); d.fused_contour = 0.f;
+            if (g_rgba.has_value() && g_rgba->defined()) grgba = g_rgba->to(at::kFloat).contiguous();   // the image's other consumers: added by the kernel
+        }
     } else {
         grgba = (g_rgba.has_value() && g_rgba->defined()) ? g_rgba->to(at::kFloat).contiguous() : at::zeros({B, H, W, 4}, vertices.options());
         d.rgba = nullptr;                                    // (not read by the backward)
@@ -118,7 +164,7 @@ std::vector<at::Tensor> render_backward(int64_t f_bwd, const std::string& proto,
     if (d.no_mask) gbg = at::empty_like(*bg);
     at::Tensor ga = at::empty_like(azimuths), ge = at::empty_like(elevations), gd = at::empty_like(distances), gb = at::empty_like(biases);
     MMRenderGrads g;
-    g.grad_rgba = fused ? nullptr : fptr(grgba); g.grad_face_normals = fptr(gfn); g.grad_vertices = mptr(gv); g.grad_textures = mptr(gt_);
+    g.grad_rgba = (fused && !deferred) ? nullptr : fptr(grgba); g.grad_face_normals = fptr(gfn); g.grad_vertices = mptr(gv); g.grad_textures = mptr(gt_);
     g.grad_lights = mptr(gl); g.grad_bg = mptr(gbg); g.grad_azimuths = mptr(ga); g.grad_elevations = mptr(ge); g.grad_distances = mptr(gd);
     g.grad_biases = mptr(gb);
     check(((render_bwd_t)f_bwd)(&d, &g, (void*)stream), "mm_render_backward");
@@ -171,7 +217,7 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
     static tensor_list forward(AutogradContext* ctx, int64_t f_fwd, int64_t f_loss, int64_t f_bwd, std::string proto, int64_t ws_bytes,
                                at::Tensor vertices, at::Tensor textures, at::Tensor lights, c10::optional<at::Tensor> bg, at::Tensor azimuths,
                                at::Tensor elevations, at::Tensor distances, at::Tensor biases, c10::optional<at::Tensor> gt, bool want_imnormal,
-                               double image_weight, int64_t stream) {
+                               double image_weight, int64_t stream, bool defer) {
         TORCH_CHECK(azimuths.is_cuda(), "the MI355X render path needs tensors in device memory; there is no CPU fallback");
         const DeviceGuard guard(azimuths.device());
         stream = current_stream(azimuths.device());              // (the argument is kept for the binding's signature only)
@@ -190,6 +236,18 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
         if (fused) ctx->mark_non_differentiable({out[0]});
         tensor_list ret = {out[0], out[1], out[2], out[3]};
         if (fused) ret.push_back(out[4]);
+        else if (defer) {
+            // deferred fusion: a fifth output whose only job is to carry dL/dloss of a later recon_data(image, gt) back into THIS node (never read, never
+            // written: no launch), and the mailbox that recon_data finds through the image's address
+            auto mb = std::make_shared<Mailbox>();
+            mb->rgba_ptr = out[0].data_ptr(); mb->B = out[0].size(0); mb->H = out[0].size(1); mb->W = out[0].size(2);
+            mb->token = at::empty({1}, out[0].options());
+            ctx->saved_data["mb"] = mailbox_holder(mb);
+            { std::lock_guard<std::mutex> lock(g_mail_mutex);
+              if (g_mail.size() > 256) for (auto it = g_mail.begin(); it != g_mail.end();) it = it->second.expired() ? g_mail.erase(it) : std::next(it);
+              g_mail[mb->rgba_ptr] = mb; }
+            ret.push_back(mb->token);
+        }
         return ret;
     }
 
@@ -198,13 +256,52 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
         const bool fused = ctx->saved_data["fused"].toBool();
         const DeviceGuard guard(sv[4].device());
         auto opt = [](const at::Tensor& t) { return t.defined() ? c10::optional<at::Tensor>(t) : c10::nullopt; };
-        auto gr = render_backward(ctx->saved_data["f_bwd"].toInt(), ctx->saved_data["proto"].toStringRef(), sv[0], sv[1], sv[2], opt(sv[3]), sv[4], sv[5],
-                                  sv[6], sv[7], sv[8], sv[9], opt(sv[10]), opt(sv[11]), opt(g[0]), opt(g[1]),
-                                  (fused && g.size() > 4) ? opt(g[4]) : c10::nullopt, ctx->saved_data["image_weight"].toDouble(), sv[12],
-                                  current_stream(sv[4].device()));
+        // deferred fusion: a recon_data consumed this render's image and its loss takes part in what is differentiated (the token has a gradient)
+        std::shared_ptr<Mailbox> mb;
+        if (!fused && g.size() > 4 && g[4].defined() && ctx->saved_data.count("mb")) mb = mailbox_of(ctx->saved_data["mb"].toTensor());
+        const bool deferred = mb && mb->gt.defined() && mb->totals != nullptr;
+        TORCH_CHECK(deferred || fused || g.size() <= 4 || !g[4].defined(), "a recon_data token carries a gradient but its render has no recon_data on record");
+        auto gr = deferred
+            ? render_backward(ctx->saved_data["f_bwd"].toInt(), ctx->saved_data["proto"].toStringRef(), sv[0], sv[1], sv[2], opt(sv[3]), sv[4], sv[5],
+                              sv[6], sv[7], sv[8], sv[9], opt(mb->gt), c10::nullopt, opt(g[0]), opt(g[1]), opt(g[4]), mb->image_weight, sv[12],
+                              current_stream(sv[4].device()), reinterpret_cast<int64_t>(mb->totals))
+            : render_backward(ctx->saved_data["f_bwd"].toInt(), ctx->saved_data["proto"].toStringRef(), sv[0], sv[1], sv[2], opt(sv[3]), sv[4], sv[5],
+                              sv[6], sv[7], sv[8], sv[9], opt(sv[10]), opt(sv[11]), opt(g[0]), opt(g[1]),
+                              (fused && g.size() > 4) ? opt(g[4]) : c10::nullopt, ctx->saved_data["image_weight"].toDouble(), sv[12],
+                              current_stream(sv[4].device()), 0);
         // one entry per forward argument: five non-tensors, then vertices, textures, lights, bg, azimuths, elevations, distances, biases, ...
         return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), gr[0], gr[1], gr[2], gr[3], gr[4], gr[5], gr[6], gr[7],
-                at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+                at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+// recon_data on the untouched image of a render that handed out a token (deferred fusion, top of this file): the forward is mm_recon_data_forward on
+// the image as always (same launches, same value); the backward launches NOTHING -- dL/dloss travels to the render node as the token's gradient.
+class ReconDeferredNode : public torch::autograd::Function<ReconDeferredNode> {
+ public:
+    static at::Tensor forward(AutogradContext* ctx, at::Tensor token, at::Tensor holder, int64_t f_ws, int64_t f_fwd, int64_t f_tot, at::Tensor pred,
+                              at::Tensor gt, double image_weight) {
+        const DeviceGuard guard(pred.device());
+        (void)token;
+        auto out = recon_forward(f_ws, f_fwd, pred, gt, image_weight, 0.0, current_stream(pred.device()));
+        auto mb = mailbox_of(holder);
+        TORCH_CHECK(mb, "deferred recon_data without its render's mailbox");
+        MMReconDesc d;
+        std::memset(&d, 0, sizeof d);
+        d.B = (int32_t)out[1].size(0); d.H = (int32_t)out[1].size(2); d.W = (int32_t)out[1].size(3);
+        d.workspace = out[3].data_ptr(); d.workspace_bytes = (size_t)out[3].numel();
+        typedef const float* (*totals_t)(const MMReconDesc*);
+        mb->totals = ((totals_t)f_tot)(&d);
+        TORCH_CHECK(mb->totals != nullptr, "mm_recon_data_totals failed");
+        mb->gt = out[2]; mb->recon_ws = out[3]; mb->image_weight = image_weight;     // alive as long as the render node is
+        ctx->set_materialize_grads(false);
+        return out[0];
+    }
+    static tensor_list backward(AutogradContext* ctx, tensor_list g) {
+        (void)ctx;
+        at::Tensor gt;                                           // the token's gradient = dL/dloss (one float on the device; a view where the caller's is one)
+        if (g[0].defined()) gt = g[0].to(at::kFloat).reshape({1});
+        return {gt, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }
 };
 
@@ -285,13 +382,58 @@ at::Tensor geometry_node(int64_t f_fwd, int64_t f_bwd, std::string proto, int64_
     return GeometryNode::apply(f_fwd, f_bwd, proto, ws_bytes, vertices, azimuths, elevations, distances, biases);
 }
 
+// defer: hand out the token a later recon_data(image, gt) can route its backward through (deferred fusion; the returned list is still
+// {rgba, face_normals, imnormal, face_idx}: the token lives in the mailbox)
 tensor_list render_node(int64_t f_fwd, int64_t f_loss, int64_t f_bwd, std::string proto, int64_t ws_bytes, at::Tensor vertices, at::Tensor textures,
                         at::Tensor lights, c10::optional<at::Tensor> bg, at::Tensor azimuths, at::Tensor elevations, at::Tensor distances, at::Tensor biases,
-                        c10::optional<at::Tensor> gt, bool want_imnormal, double image_weight, int64_t stream) {
-    return RenderNode::apply(f_fwd, f_loss, f_bwd, proto, ws_bytes, vertices, textures, lights, bg, azimuths, elevations, distances, biases, gt,
-                             want_imnormal, image_weight, stream);
+                        c10::optional<at::Tensor> gt, bool want_imnormal, double image_weight, int64_t stream, bool defer) {
+    const bool fused = gt.has_value() && gt->defined();
+    defer = defer && !fused && at::GradMode::is_enabled();
+    tensor_list out = RenderNode::apply(f_fwd, f_loss, f_bwd, proto, ws_bytes, vertices, textures, lights, bg, azimuths, elevations, distances, biases, gt,
+                                        want_imnormal, image_weight, stream, defer);
+    if (defer && out.size() > 4) {
+        std::shared_ptr<Mailbox> mb;
+        { std::lock_guard<std::mutex> lock(g_mail_mutex);
+          auto it = g_mail.find(out[0].data_ptr());
+          if (it != g_mail.end()) mb = it->second.lock(); }
+        if (mb && out[0].grad_fn()) { mb->node = out[0].grad_fn().get(); mb->version = out[0]._version(); mb->token = out[4]; }   // (the token AS an output of the node)
+        else if (mb) mb->claimed = true;                         // nothing requires grad: no backward will ever run, nothing to defer
+        out.pop_back();
+    }
+    return out;
 }
-at::Tensor recon_node(int64_t f_ws, int64_t f_fwd, int64_t f_bwd, at::Tensor pred, at::Tensor gt, double image_weight, double contour, int64_t stream) {
+
+// The render whose image `pred` is, if recon_data may route its backward through it: pred is the (B,4,H,W) permute view of (or the NHWC image itself,
+// seen as (B,4,H,W)) output 0 of a render node that handed out a token, float32, never modified in place since, not yet taken by another recon_data.
+std::shared_ptr<Mailbox> deferrable_render(const at::Tensor& pred) {
+    if (!pred.defined() || !pred.is_cuda() || pred.scalar_type() != at::kFloat || pred.dim() != 4 || !pred.requires_grad() || !at::GradMode::is_enabled()) return nullptr;
+    std::shared_ptr<Mailbox> mb;
+    { std::lock_guard<std::mutex> lock(g_mail_mutex);
+      auto it = g_mail.find(pred.data_ptr());
+      if (it != g_mail.end()) mb = it->second.lock(); }
+    if (!mb || mb->claimed || !mb->node || !mb->token.defined()) return nullptr;
+    if (pred.size(0) != mb->B || pred.size(1) != 4 || pred.size(2) != mb->H || pred.size(3) != mb->W) return nullptr;
+    if (pred.stride(0) != 4 * mb->H * mb->W || pred.stride(1) != 1 || pred.stride(2) != 4 * mb->W || pred.stride(3) != 4) return nullptr;
+    if (pred._version() != mb->version) return nullptr;         // written in place since the render returned it
+    const auto fn = pred.grad_fn();
+    if (!fn) return nullptr;
+    // `pred` must BE the render's image: one permute away from output 0 of the node (what DiffRender.render returns)
+    if (fn->num_inputs() < 1 || fn->next_edges().size() != 1) return nullptr;
+    const auto& e = fn->next_edge(0);
+    if (e.function.get() != mb->node || e.input_nr != 0 || fn->name().find("Permute") == std::string::npos) return nullptr;
+    if (!mb->token.grad_fn() || mb->token.grad_fn().get() != mb->node) return nullptr;
+    return mb;
+}
+
+at::Tensor recon_node(int64_t f_ws, int64_t f_fwd, int64_t f_bwd, at::Tensor pred, at::Tensor gt, double image_weight, double contour, int64_t stream,
+                      int64_t f_tot, bool allow_defer) {
+    if (allow_defer && f_tot != 0 && !(contour > 0.0)) {
+        if (auto mb = deferrable_render(pred)) {
+            mb->claimed = true;
+            // (find the holder again through the node's context is not possible from here: a second holder of the same mailbox travels as an argument)
+            return ReconDeferredNode::apply(mb->token, mailbox_holder(mb), f_ws, f_fwd, f_tot, pred.detach(), gt, image_weight);
+        }
+    }
     return ReconNode::apply(f_ws, f_fwd, f_bwd, pred, gt, image_weight, contour, stream);
 }
 
@@ -306,4 +448,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("recon_data", &recon_node);
     m.def("render_geometry", &geometry_node);
     m.def("desc_bytes", []() { return (int64_t)sizeof(MMRenderDesc); });
+    m.def("deferrable", [](at::Tensor pred) { return deferrable_render(pred) != nullptr; });   // tests / diagnostics: would recon_data(pred, .) defer?
 }

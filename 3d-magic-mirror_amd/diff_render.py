@@ -279,6 +279,12 @@ class DiffRender(object):
         # check_texture_records every backward of the class API asks the library (a stream synchronisation) and raises instead.
         self.extra_texture_records_per_pixel = 0.0
         self.check_texture_records = False
+        # DEFERRED FUSION (C++ nodes only; csrc/mm_torch_ext.cpp, MMRenderDesc.fused_totals): `recon_data(pred, gt)` on the untouched image of an earlier
+        # `render` of this process -- the un-modified trainer's order of calls (trainer.py:276,441) -- forms its value as always and routes its BACKWARD
+        # through the render node: no dL/d image tensor, no loss-backward launch; every gradient of the render's inputs has the bits of the two separate
+        # backward passes.  The one observable difference: recon_data's contribution to the gradient OF THE IMAGE ITSELF (torch.autograd.grad(loss, rgbs),
+        # a hook on rgbs, rgbs.retain_grad()) does not exist as a tensor -- set this to False if the image's own gradient is inspected.
+        self.defer_recon_fusion = True
         camera_fovy = np.arctan(1.0 / 2.5) * 2
         self.cam_proj = template.generate_perspective_projection(camera_fovy, ratio=1 / ratio)     # networks.py:172-174
         mesh = obj_io.load_template(mesh_name)                                                   # :176
@@ -335,7 +341,7 @@ class DiffRender(object):
         proto, nbytes = self._proto(self._static(dev), azimuths.numel(), no_mask, textures.shape[2], textures.shape[3], float(contour) if gt is not None else 0.0)
         return ext.render(N.fn_addr("mm_render_forward"), N.fn_addr("mm_render_fused_loss"), N.fn_addr("mm_render_backward"), proto, nbytes,
                           vertices, textures, lights, bg, azimuths, elevations, distances, biases, gt, bool(self.emit_imnormal),
-                          float(self.image_weight), torch._C._cuda_getCurrentRawStream(dev.index))
+                          float(self.image_weight), torch._C._cuda_getCurrentRawStream(dev.index), bool(self.defer_recon_fusion))
 
     def _status_ptr(self):
         """Address of this object's pinned status word (device-writable host memory): every descriptor built here carries it, so that a
@@ -524,8 +530,10 @@ class DiffRender(object):
         if ext is None:
             return _ReconFn.apply(pred_data, gt_data, self.image_weight, contour)
         N.require_device(pred_data, gt_data)
+        # (pred_data the untouched image of one of this process's renders: its backward is routed through that render's node -- defer_recon_fusion)
         return ext.recon_data(N.fn_addr("mm_recon_query_workspace"), N.fn_addr("mm_recon_data_forward"), N.fn_addr("mm_recon_data_backward"),
-                              pred_data, gt_data, float(self.image_weight), float(contour), torch._C._cuda_getCurrentRawStream(pred_data.device.index))
+                              pred_data, gt_data, float(self.image_weight), float(contour), torch._C._cuda_getCurrentRawStream(pred_data.device.index),
+                              N.fn_addr("mm_recon_data_totals"), bool(self.defer_recon_fusion))
 
     # ---- networks.py:326-362: seven means in one HIP launch per direction (att_loss.py / csrc/mm_attloss.hip); the chamfer
     # variant of the shape term is a HIP nearest-neighbour search + a differentiable gather ----------

@@ -128,6 +128,32 @@ class RenderLossStep:
             N.check(L.mm_recon_data_backward(ctypes.byref(self.r), s), "mm_recon_data_backward")
         N.check(L.mm_render_backward(ctypes.byref(self.d), ctypes.byref(self.g), s), "mm_render_backward")
 
+    def run_deferred(self, stream=None):
+        """The un-fused step with DEFERRED fusion (MMRenderDesc.fused_totals, ABI 6): render, recon_data's forward on the image, then ONE backward
+        call that forms dL/d image itself from recon_data's per-image totals -- no mm_recon_data_backward, no grad_rgba round trip, the same bits."""
+        if self.fused or self.r.contour > 0:
+            raise RuntimeError("run_deferred is the un-fused step without the contour term")
+        L = N.lib()
+        s = ctypes.c_void_p((stream or torch.cuda.current_stream(self.dev)).cuda_stream)
+        N.check(L.mm_render_forward(ctypes.byref(self.d), s), "mm_render_forward")
+        N.check(L.mm_recon_data_forward(ctypes.byref(self.r), s), "mm_recon_data_forward")
+        d = self.render_desc()
+        d.fused_gt, d.fused_image_weight, d.fused_grad_loss = N.ptr(self.gt), float(self.dr.image_weight), N.ptr(self.loss_scale)
+        d.fused_totals = self.recon_totals_ptr()
+        g = self.grads_struct()
+        g.grad_rgba = None
+        N.check(L.mm_render_backward(ctypes.byref(d), ctypes.byref(g), s), "mm_render_backward (deferred)")
+
+    def render_desc(self):
+        """a copy of this step's MMRenderDesc (tests poke at the copy)"""
+        return N.MMRenderDesc.from_buffer_copy(self.d)
+
+    def grads_struct(self):
+        return N.MMRenderGrads.from_buffer_copy(self.g)
+
+    def recon_totals_ptr(self):
+        return N.lib().mm_recon_data_totals(ctypes.byref(self.r))
+
     def run_forward(self, stream=None):
         """The forward half of run() (fused mode): render + recon_data value, on ``stream``."""
         L = N.lib()

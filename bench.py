@@ -16,6 +16,7 @@ steps, each repetition bracketed by barrier + synchronize: the driver's short --
   value_four_streams  the same steps enqueued round-robin on --streams HIP streams (default 4): successive steps are independent batches
                       (the reference's trainer issues four renders per iteration, trainer.py:276,345,347,367) and their kernels overlap.
   value_without_imnormal  `value` without the visualise-only imnormal output.
+  value_api_undeferred  value_api with DiffRender.defer_recon_fusion = False (rounds 1-5's value_api: recon_data's own backward launch, dL/d image through memory)
   value_api           DiffRender.render -> DiffRender.recon_data -> loss.backward() through the torch.autograd wrappers (the calls
                       trainer.py makes, :276,441,509-518), one stream.
   value_api_fused     the same step through DiffRender.render_recon (loss folded into the render kernels).
@@ -391,7 +392,7 @@ def main():
         reducer.wait(); torch.cuda.synchronize(dev)
     loss_value = float(step.loss) if args.mode != "torch" else None
 
-    one_stream = api_value = api_fused_value = shim_value = no_imn_value = None
+    one_stream = api_value = api_fused_value = shim_value = no_imn_value = api_undeferred_value = None
     host_us_per_step = {}
     e1, e1_all = elapsed, elapsed_all
     if args.mode == "eager":
@@ -421,6 +422,14 @@ def main():
         api_value = round(world * B * args.api_steps / e2, 1)
         host_us_per_step["c_abi_one_stream"] = host_us(one_single)
         host_us_per_step["api"] = host_us(one_api)
+        # the same calls with the deferral switched off (round 5's value_api: recon_data's own backward launch + the dL/d image round trip)
+        dr_api.defer_recon_fusion = False
+        for _ in range(10):
+            one_api()
+        e2u, _ = timed_median(one_api, args.api_steps, reps=3)
+        api_undeferred_value = round(world * B * args.api_steps / e2u, 1)
+        host_us_per_step["api_undeferred"] = host_us(one_api)
+        dr_api.defer_recon_fusion = True
         for _ in range(10):
             one_api_fused()
         e2f, _ = timed_median(one_api_fused, args.api_steps, reps=3)
@@ -600,7 +609,7 @@ def main():
             "value_one_stream": one_stream, "value_four_streams": round(total_images / elapsed, 1) if args.mode == "eager" else None,
             "ms_per_step_four_streams": round(elapsed / args.steps * 1e3, 4) if args.mode == "eager" else None,
             "value_without_imnormal": no_imn_value,
-            "value_api": api_value, "value_api_fused": api_fused_value, "host_us_per_step": host_us_per_step, "value_shim": shim_value, "ddp_encoder": ddp_info,
+            "value_api": api_value, "value_api_undeferred": api_undeferred_value, "value_api_fused": api_fused_value, "host_us_per_step": host_us_per_step, "value_shim": shim_value, "ddp_encoder": ddp_info,
             "value_config3": None if not config3 else config3.get("images_per_s"), "config3": config3,
             "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},
             "loss": loss_value,

@@ -109,6 +109,15 @@ typedef struct MMRenderDesc {
      * 4x4 block, which lies in the pixel's own 8x8 screen tile; other sizes: MM_ERR_BAD_SHAPE -- use mm_recon_data_* for those).  Ignored
      * without fused_gt. */
     float fused_contour;
+    /* DEFERRED fusion, mm_render_backward only (ABI 6): the un-modified trainer's order of calls -- `render`, then `recon_data(pred, gt)` on the image
+     * that render wrote (trainer.py:276,441) -- with the fused backward.  The loss VALUE was formed by mm_recon_data_forward on the image (its own
+     * launches, its own bits); fused_totals = that call's per-image totals, mm_recon_data_totals(recon desc): (B,4) floats in ITS workspace, which the
+     * caller keeps alive until this backward has run.  With fused_gt AND fused_totals set, mm_render_backward forms dL/d rgba per pixel with
+     * mm_recon_data_backward's own expressions from those totals and the prediction it re-forms -- bit for bit the gradient mm_recon_data_backward
+     * would have written -- without that launch and without the grad_rgba round trip.  MMRenderGrads.grad_rgba, if not NULL, is ADDED to it (the
+     * image's other consumers).  fused_contour must be 0 (the contour term's gradient is formed in another order by the fused kernels: use
+     * mm_recon_data_backward for it); fused_loss is not written; the forward of this render ran WITHOUT fused_gt.  NULL: off. */
+    const float* fused_totals;
 } MMRenderDesc;
 
 /* MMRenderDesc.options / MMDibrDesc.options: 0 = the semantics of SURVEY.md 8(a) (the oracle's defaults).  The bits switch,
@@ -197,6 +206,9 @@ typedef struct MMReconDesc {
 size_t mm_recon_query_workspace(const MMReconDesc* desc);
 int mm_recon_data_forward(const MMReconDesc* desc, mm_stream_t stream);
 int mm_recon_data_backward(const MMReconDesc* desc, mm_stream_t stream);
+/* Where mm_recon_data_forward left the per-image totals {sum|pi-gi|, sum p*g, sum p+g-p*g, contour sum} (B,4) inside desc->workspace: what
+ * MMRenderDesc.fused_totals takes (deferred fusion).  NULL if desc or its workspace is NULL / too small. */
+const float* mm_recon_data_totals(const MMReconDesc* desc);
 
 /* --------------------------------------------------------------------------------------------------------------------
  * Nearest neighbour of every point of x (B,N,3) in y (B,M,3): squared distance (B,N) and index (B,N) int32, lowest index
@@ -467,9 +479,9 @@ const char* mm_last_error_detail(void);
 size_t mm_struct_size(int which);
 /* Bumped whenever a struct or the meaning of a field changes (2: op boundary added, reserved uv-tile fields and profiling slot
  * MM_PROF_BIN removed, options bits defined; 3: MMRenderDesc takes the fixed-stride vertex -> corner table instead of the CSR,
- * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, MMTexMapGrads.workspace, mm_chamfer_nearest, mm_build_vertex_corner_csr_device; 5: MMRenderDesc.fused_contour).  Bindings must refuse a library whose
+ * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, MMTexMapGrads.workspace, mm_chamfer_nearest, mm_build_vertex_corner_csr_device; 5: MMRenderDesc.fused_contour; 6: MMRenderDesc.fused_totals, mm_recon_data_totals).  Bindings must refuse a library whose
  * version differs from what they mirror. */
-#define MM_ABI_VERSION 5
+#define MM_ABI_VERSION 6
 int mm_abi_version(void);
 
 #ifdef __cplusplus

@@ -16,7 +16,7 @@ N_MAX_D = 32          # MM_DIBR_MAX_D
 
 def test_library_exports_every_declared_symbol(pkg):
     hdr = open(os.path.join(ROOT, "include", "mm_render.h")).read()
-    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(mm_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t|const char\*|const float\*)\s+(mm_\w+)\s*\(", hdr, flags=re.M))
     assert {"mm_render_forward", "mm_render_backward", "mm_recon_data_forward", "mm_recon_data_backward",
             "mm_query_workspace", "mm_recon_query_workspace", "mm_build_vertex_corner_csr", "mm_dibr_rasterization_forward",
             "mm_prepare_vertices_forward", "mm_texture_mapping_forward", "mm_sh_lighting_forward", "mm_mask_iou_forward"} <= declared

@@ -60,13 +60,13 @@ extern "C" {
 
 size_t mm_query_workspace(const MMRenderDesc* d) {
     if (!d || d->B <= 0 || d->V <= 0 || d->F <= 0 || d->H <= 0 || d->W <= 0 || d->Ht <= 0 || d->Wt <= 0) return 0;
-    return mm::carve_workspace(nullptr, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt).bytes;
+    return mm::carve_workspace(nullptr, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, 0, d->geometry_only != 0).bytes;
 }
 
 int mm_render_forward(const MMRenderDesc* d, mm_stream_t stream) {
     int st = check_render(d, false);
     if (st != MM_OK) return st;
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes, d->geometry_only != 0);
     hipStream_t s = (hipStream_t)stream;
     mm::clear_stale_error();
     st = mm::launch_vertex_fwd(d, w, s);
@@ -78,7 +78,7 @@ int mm_render_fused_loss(const MMRenderDesc* d, mm_stream_t stream) {
     int st = check_render(d, false);
     if (st != MM_OK) return st;
     if (!d->fused_gt || !d->fused_loss) return MM_ERR_NULL_POINTER;
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes, d->geometry_only != 0);
     mm::clear_stale_error();
     return mm::launch_fused_loss(d, w, (hipStream_t)stream);
 }
@@ -98,7 +98,7 @@ int mm_render_status(const MMRenderDesc* d, mm_stream_t stream, int32_t* dropped
     if (d->B <= 0 || d->V <= 0 || d->F <= 0 || d->H <= 0 || d->W <= 0 || d->Ht <= 0 || d->Wt <= 0) return MM_ERR_BAD_SHAPE;
     if (!d->workspace) return MM_ERR_NULL_POINTER;
     if (d->workspace_bytes < mm_query_workspace(d) || ((uintptr_t)d->workspace & 255)) return MM_ERR_BAD_SHAPE;   // (MM_ERR_WORKSPACE is this call's "records were dropped")
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes, d->geometry_only != 0);
     std::vector<int32_t> h((size_t)d->B);
     if (hipMemcpyAsync(h.data(), w.tstatus, (size_t)d->B * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return MM_ERR_LAUNCH;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MM_ERR_LAUNCH;
@@ -111,7 +111,7 @@ int mm_render_backward(const MMRenderDesc* d, const MMRenderGrads* g, mm_stream_
     int st = check_render(d, true);
     if (st != MM_OK) return st;
     if (!g || !g->grad_vertices || !g->grad_azimuths || !g->grad_elevations || !g->grad_distances || !g->grad_biases) return MM_ERR_NULL_POINTER;
-    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes);
+    const mm::Workspace w = mm::carve_workspace(d->workspace, d->B, d->V, d->F, d->H, d->W, d->Ht, d->Wt, d->workspace_bytes, d->geometry_only != 0);
     hipStream_t s = (hipStream_t)stream;
     if (d->geometry_only) {                                       // nothing was rasterised: the gradient arrives through face_normals alone
         if (!g->grad_face_normals) return MM_ERR_NULL_POINTER;

@@ -150,30 +150,34 @@ inline bool vertex_bwd_per_image(int B, int F, int vc_stride) {
 }
 
 // avail: bytes the caller really has (0 = the minimum, what mm_query_workspace reports): what is beyond the minimum goes to the images' record arrays
-__host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, int F, int H, int W, int Ht, int Wt, size_t avail = 0) {
+// geo_only (MMRenderDesc.geometry_only: nothing is rasterised): only what the vertex stage touches -- camera, face records, face flags, the counters it
+// clears, the dL/dT partials and ONE (never written, never used) row of item sums per image for the backward's unconditional loads; every other block
+// is empty.  3 MB instead of 71 MB at B=48, 1 280 faces, 128x128 (advisor r05: the lean trainer step keeps such a workspace alive per geometry render).
+__host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, int F, int H, int W, int Ht, int Wt, size_t avail = 0, bool geo_only = false) {
     Workspace w;
     char* p = (char*)base;
     size_t o = 0;
+    const size_t px = geo_only ? 0 : (size_t)H * W;              // per-pixel blocks
     w.bin_shift = bin_shift_for(H, W, F);
     w.nbx = (W + (1 << w.bin_shift) - 1) >> w.bin_shift;
     w.nby = (H + (1 << w.bin_shift) - 1) >> w.bin_shift;
     w.words = (F + 63) / 64;
-    w.binmask_bytes = (size_t)B * w.nbx * w.nby * w.words * sizeof(uint64_t);
+    w.binmask_bytes = geo_only ? 0 : (size_t)B * w.nbx * w.nby * w.words * sizeof(uint64_t);
     w.T = (float*)(p + o);          o += align256((size_t)B * 12 * sizeof(float));
     w.cam = (float*)(p + o);        o += align256((size_t)B * 48 * sizeof(float));
     w.geo = (float4*)(p + o);       o += align256((size_t)B * F * 3 * sizeof(float4));
     w.binmask = (uint64_t*)(p + o); o += align256(w.binmask_bytes);
-    w.soft = (float2*)(p + o);      o += align256((size_t)B * H * W * sizeof(float2));
+    w.soft = (float2*)(p + o);      o += align256((size_t)B * px * sizeof(float2));
     w.dTpart = (float*)(p + o);     o += align256((size_t)B * ((V + 31) / 32) * 12 * sizeof(float));
     w.ticket = (unsigned*)(p + o);  o += align256((size_t)B * sizeof(unsigned));
-    w.gp = (float4*)(p + o);        o += align256((size_t)B * H * W * 2 * sizeof(float4));
-    w.gp2 = (float*)(p + o);        o += align256((size_t)B * H * W * sizeof(float));
+    w.gp = (float4*)(p + o);        o += align256((size_t)B * px * 2 * sizeof(float4));
+    w.gp2 = (float*)(p + o);        o += align256((size_t)B * px * sizeof(float));
     w.blocks_per_image = ((W + MM_BLOCK_PX - 1) / MM_BLOCK_PX) * ((H + MM_BLOCK_PX - 1) / MM_BLOCK_PX);
-    w.dl_part = (float*)(p + o);    o += align256((size_t)B * w.blocks_per_image * 12 * sizeof(float));
+    w.dl_part = (float*)(p + o);    o += align256(geo_only ? 0 : (size_t)B * w.blocks_per_image * 12 * sizeof(float));
     w.ltot = (long long*)(p + o);   o += align256((size_t)B * MM_LSUB * 4 * sizeof(long long));
-    w.order = (unsigned short*)(p + o); o += align256((size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
-    w.nheavy = (int*)(p + o);       o += align256((size_t)B * 4 * sizeof(int));
-    w.bincount = (int*)(p + o);     o += align256((size_t)B * w.nbx * w.nby * sizeof(int));
+    w.order = (unsigned short*)(p + o); o += align256(geo_only ? 0 : (size_t)B * 4 * w.blocks_per_image * sizeof(unsigned short));
+    w.nheavy = (int*)(p + o);       o += align256(geo_only ? 0 : (size_t)B * 4 * sizeof(int));
+    w.bincount = (int*)(p + o);     o += align256(geo_only ? 0 : (size_t)B * w.nbx * w.nby * sizeof(int));
     w.fflag = (int*)(p + o);        o += align256((size_t)B * F * 2 * sizeof(int));   // (ints, not bytes: a byte store may alias every later load in the compiler's eyes)
     w.ntiles = ((Wt + MM_UV_TILE - 1) / MM_UV_TILE) * ((Ht + MM_UV_TILE - 1) / MM_UV_TILE);
     const size_t ndrop = ((size_t)B * w.ntiles * 2 + B + 7) / 8 * 8 - (size_t)B * w.ntiles * 2;   // (gmax starts on a 32-byte sector)
@@ -185,16 +189,16 @@ __host__ __device__ inline Workspace carve_workspace(void* base, int B, int V, i
     w.gmax = (unsigned*)(w.tdrop + ndrop);
     w.tstatus = w.tcnt + w.ntcnt;
     w.trcnt = w.tstatus + B;
-    w.item_cap = F + (int)(((size_t)16 * H * W + MM_CHUNK_PX - 1) / MM_CHUNK_PX);
-    w.chunkmap = (int2*)(p + o);    o += align256((size_t)B * F * sizeof(int2));
-    w.items = (int2*)(p + o);       o += align256((size_t)B * w.item_cap * sizeof(int2));
-    w.nitems = (int2*)(p + o);      o += align256((size_t)B * sizeof(int2));
+    w.item_cap = geo_only ? 1 : F + (int)(((size_t)16 * H * W + MM_CHUNK_PX - 1) / MM_CHUNK_PX);
+    w.chunkmap = (int2*)(p + o);    o += align256(geo_only ? 0 : (size_t)B * F * sizeof(int2));
+    w.items = (int2*)(p + o);       o += align256(geo_only ? 0 : (size_t)B * w.item_cap * sizeof(int2));
+    w.nitems = (int2*)(p + o);      o += align256(geo_only ? 0 : (size_t)B * sizeof(int2));
     w.part = (float*)(p + o);       o += align256((size_t)B * w.item_cap * 12 * sizeof(float));
     w.trec = (TexRecord*)(p + o);                                 // (last: the record arrays take what the caller gives beyond the minimum)
-    const size_t rc_min = ((size_t)H * W * 9 / 8 + 255) & ~(size_t)255;
+    const size_t rc_min = geo_only ? 0 : ((size_t)H * W * 9 / 8 + 255) & ~(size_t)255;
     size_t rc = rc_min;
     const size_t need = o + align256((size_t)B * rc_min * sizeof(TexRecord));
-    if (avail > need) rc += (avail - need) / ((size_t)B * sizeof(TexRecord));
+    if (avail > need && !geo_only) rc += (avail - need) / ((size_t)B * sizeof(TexRecord));
     if (rc > ((size_t)1 << 30)) rc = (size_t)1 << 30;
     w.trcap = (int)rc;
     o += align256((size_t)B * rc_min * sizeof(TexRecord));

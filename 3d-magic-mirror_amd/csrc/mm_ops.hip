@@ -412,36 +412,51 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(MMShDesc d) {
     d.out[p] = coef;
 }
 
-// One workgroup of 1024 threads per image: the nine light gradients are sums over ALL of the image's points -- per thread over its points in
-// index order, a fixed butterfly per wave, the sixteen waves in index order: no atomics (2 304 float atomics per image on nine addresses took
-// 87 us at B=48, 128x128), no zero-fill, bitwise reproducible.
-__global__ __launch_bounds__(1024) void sh_bwd_kernel(MMShDesc d, MMShGrads g) {
+// Backward in two launches (advisor r05: one 1024-thread workgroup per image did both halves -- B CUs busy, N / 1024 dependent trips per thread):
+//   sh_bwd_normals_kernel   dL/dnormals is elementwise: a thread per point over the whole grid.
+//   sh_bwd_lights_kernel    the nine light gradients are sums over ALL of an image's points -- per thread over its points in index order, a fixed
+//                           butterfly per wave, the sixteen waves in index order: no atomics (2 304 float atomics per image on nine addresses took
+//                           87 us at B=48, 128x128), no zero-fill, no scratch (the ABI gives this operator none), bitwise reproducible.  Still one
+//                           workgroup per image, but with EIGHT points of every thread in flight per trip: N / 8192 dependent trips instead of
+//                           N / 1024 (512x512: 32 instead of 256).
+__global__ __launch_bounds__(256) void sh_bwd_normals_kernel(MMShDesc d, MMShGrads g) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= d.N) return;
+    const float* L = d.lights + b * 9;
+    const size_t p = (size_t)b * d.N + n;
+    const float x = d.normals[p * 3], y = d.normals[p * 3 + 1], z = d.normals[p * 3 + 2];
+    const float go = g.grad_out[p];
+    g.grad_normals[p * 3 + 0] = go * (((MM_SH_C1 * L[1] + MM_SH_C4 * y * L[4]) + MM_SH_C7 * z * L[7]) + 2.f * MM_SH_C8 * x * L[8]);
+    g.grad_normals[p * 3 + 1] = go * (((MM_SH_C1 * L[3] + MM_SH_C4 * x * L[4]) + MM_SH_C4 * z * L[5]) - 2.f * MM_SH_C8 * y * L[8]);
+    g.grad_normals[p * 3 + 2] = go * (((MM_SH_C1 * L[2] + MM_SH_C4 * y * L[5]) + 2.f * MM_SH_C6 * z * L[6]) + MM_SH_C7 * x * L[7]);
+}
+
+#define MM_SH_UNROLL 8
+__global__ __launch_bounds__(1024) void sh_bwd_lights_kernel(MMShDesc d, MMShGrads g) {
     __shared__ float s_red[16][9];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* L = d.lights + b * 9;
-    float L9[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) L9[i] = L[i];
     float acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.f;
-    for (int n = tid; n < d.N; n += 1024) {
-        const size_t p = (size_t)b * d.N + n;
-        const float x = d.normals[p * 3], y = d.normals[p * 3 + 1], z = d.normals[p * 3 + 2];
-        const float go = g.grad_out[p];
-        if (g.grad_normals) {
-            g.grad_normals[p * 3 + 0] = go * (((MM_SH_C1 * L9[1] + MM_SH_C4 * y * L9[4]) + MM_SH_C7 * z * L9[7]) + 2.f * MM_SH_C8 * x * L9[8]);
-            g.grad_normals[p * 3 + 1] = go * (((MM_SH_C1 * L9[3] + MM_SH_C4 * x * L9[4]) + MM_SH_C4 * z * L9[5]) - 2.f * MM_SH_C8 * y * L9[8]);
-            g.grad_normals[p * 3 + 2] = go * (((MM_SH_C1 * L9[2] + MM_SH_C4 * y * L9[5]) + 2.f * MM_SH_C6 * z * L9[6]) + MM_SH_C7 * x * L9[7]);
-        }
-        if (g.grad_lights) {
-            float bnd[9];
-            sh_bands(x, y, z, bnd);
+    for (int n0 = tid; n0 < d.N; n0 += 1024 * MM_SH_UNROLL) {     // the trip's loads first (clamped addresses), then the sums in index order
+        float xs[MM_SH_UNROLL], ys[MM_SH_UNROLL], zs[MM_SH_UNROLL], gs[MM_SH_UNROLL];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) acc[i] += go * bnd[i];
+        for (int u = 0; u < MM_SH_UNROLL; ++u) {
+            const int n = n0 + 1024 * u;
+            const size_t p = (size_t)b * d.N + min(n, d.N - 1);
+            xs[u] = d.normals[p * 3]; ys[u] = d.normals[p * 3 + 1]; zs[u] = d.normals[p * 3 + 2];
+            gs[u] = n < d.N ? g.grad_out[p] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < MM_SH_UNROLL; ++u) {
+            if (n0 + 1024 * u < d.N) {
+                float bnd[9];
+                sh_bands(xs[u], ys[u], zs[u], bnd);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) acc[i] += gs[u] * bnd[i];
+            }
         }
     }
-    if (!g.grad_lights) return;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const float s = wave_sum(acc[i]);
@@ -627,7 +642,8 @@ int mm_sh_lighting_backward(const MMShDesc* d, const MMShGrads* g, mm_stream_t s
     if (st != MM_OK) return st;
     if (!g || !g->grad_out || (!g->grad_normals && !g->grad_lights)) return MM_ERR_NULL_POINTER;
     mm::clear_stale_error();
-    hipLaunchKernelGGL(mm::sh_bwd_kernel, dim3(d->B), dim3(1024), 0, (hipStream_t)stream, *d, *g);
+    if (g->grad_normals) hipLaunchKernelGGL(mm::sh_bwd_normals_kernel, dim3((d->N + 255) / 256, d->B), dim3(256), 0, (hipStream_t)stream, *d, *g);
+    if (g->grad_lights) hipLaunchKernelGGL(mm::sh_bwd_lights_kernel, dim3(d->B), dim3(1024), 0, (hipStream_t)stream, *d, *g);
     return mm::launch_ok("sh_lighting_bwd");
 }
 

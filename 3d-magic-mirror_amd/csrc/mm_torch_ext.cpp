@@ -221,6 +221,8 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
         TORCH_CHECK(azimuths.is_cuda(), "the MI355X render path needs tensors in device memory; there is no CPU fallback");
         const DeviceGuard guard(azimuths.device());
         stream = current_stream(azimuths.device());              // (the argument is kept for the binding's signature only)
+        // the camera scalars may arrive as (B), (B,1), ...: the kernels see (B), the gradients go back in the caller's shapes (advisor r05)
+        ctx->saved_data["shape_a"] = azimuths.sizes().vec(); ctx->saved_data["shape_e"] = elevations.sizes().vec(); ctx->saved_data["shape_d"] = distances.sizes().vec();
         at::Tensor ws = at::empty({ws_bytes}, azimuths.options().dtype(at::kByte));   // (the caching allocator is the workspace pool)
         auto out = render_forward(f_fwd, f_loss, proto, vertices, textures, lights, bg, azimuths, elevations, distances, biases, gt, want_imnormal,
                                   image_weight, ws, stream);
@@ -270,7 +272,9 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
                               (fused && g.size() > 4) ? opt(g[4]) : c10::nullopt, ctx->saved_data["image_weight"].toDouble(), sv[12],
                               current_stream(sv[4].device()), 0);
         // one entry per forward argument: five non-tensors, then vertices, textures, lights, bg, azimuths, elevations, distances, biases, ...
-        return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), gr[0], gr[1], gr[2], gr[3], gr[4], gr[5], gr[6], gr[7],
+        return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), gr[0], gr[1], gr[2], gr[3],
+                gr[4].reshape(ctx->saved_data["shape_a"].toIntVector()), gr[5].reshape(ctx->saved_data["shape_e"].toIntVector()),
+                gr[6].reshape(ctx->saved_data["shape_d"].toIntVector()), gr[7],
                 at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }
 };
@@ -338,6 +342,7 @@ class GeometryNode : public torch::autograd::Function<GeometryNode> {
         MMRenderDesc d = proto_desc(proto);
         TORCH_CHECK(d.geometry_only == 1, "GeometryNode needs a geometry-only descriptor prototype");
         vertices = dense_f32(vertices, dev, "vertices");
+        ctx->saved_data["shape_a"] = azimuths.sizes().vec(); ctx->saved_data["shape_e"] = elevations.sizes().vec(); ctx->saved_data["shape_d"] = distances.sizes().vec();
         azimuths = dense_f32(azimuths, dev, "azimuths").reshape({-1}); elevations = dense_f32(elevations, dev, "elevations").reshape({-1});
         distances = dense_f32(distances, dev, "distances").reshape({-1}); biases = dense_f32(biases, dev, "biases");
         const int64_t B = azimuths.size(0);
@@ -372,7 +377,8 @@ class GeometryNode : public torch::autograd::Function<GeometryNode> {
         gr.grad_face_normals = fptr(gfn); gr.grad_vertices = mptr(gv); gr.grad_azimuths = mptr(ga); gr.grad_elevations = mptr(ge);
         gr.grad_distances = mptr(gd); gr.grad_biases = mptr(gb);
         check(((render_bwd_t)ctx->saved_data["f_bwd"].toInt())(&d, &gr, (void*)current_stream(sv[1].device())), "mm_render_backward (geometry only)");
-        none[4] = gv; none[5] = ga; none[6] = ge; none[7] = gd; none[8] = gb;
+        none[4] = gv; none[5] = ga.reshape(ctx->saved_data["shape_a"].toIntVector()); none[6] = ge.reshape(ctx->saved_data["shape_e"].toIntVector());
+        none[7] = gd.reshape(ctx->saved_data["shape_d"].toIntVector()); none[8] = gb;
         return none;
     }
 };

@@ -69,6 +69,7 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dr, no_mask, want_imnormal, gt, vertices, textures, lights, bg, azimuths, elevations, distances, biases, contour):
+        ctx.cam_shapes = (tuple(azimuths.shape), tuple(elevations.shape), tuple(distances.shape))   # (B), (B,1), ...: the gradients go back in these
         dev, B, H, W, vertices, textures, lights, bg, azimuths, elevations, distances, biases = _render_inputs(
             dr, no_mask, vertices, textures, lights, bg, azimuths, elevations, distances, biases)
         st = dr._static(dev)
@@ -141,7 +142,8 @@ class _RenderFn(torch.autograd.Function):
             g = N.MMRenderGrads(None, N.ptr(g_fn), N.ptr(gv), None, None, None, N.ptr(ga), N.ptr(ge), N.ptr(gd), N.ptr(gb))
             with torch.cuda.device(dev):
                 N.check(N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), N.current_stream(dev)), "mm_render_backward")
-            return None, None, None, None, gv, None, None, None, ga, ge, gd, gb, None
+            sa, se, sd = ctx.cam_shapes
+            return None, None, None, None, gv, None, None, None, ga.reshape(sa), ge.reshape(se), gd.reshape(sd), gb, None
         vertices, textures, lights, bg, azimuths, elevations, distances, biases, face_idx, fn, gt = ctx.saved_tensors
         ws = ctx.ws_holder.buf
         dr, dev = ctx.dr, azimuths.device
@@ -171,7 +173,8 @@ class _RenderFn(torch.autograd.Function):
             N.check(N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), N.current_stream(dev)), "mm_render_backward")
             if ctx.dr.check_texture_records:                     # (synchronises: a diagnostic switch)
                 ctx.dr.check_records(d, N.current_stream(dev))
-        return None, None, None, None, gv, gt_, gl, gbg, ga, ge, gd, gb, None
+        sa, se, sd = ctx.cam_shapes
+        return None, None, None, None, gv, gt_, gl, gbg, ga.reshape(sa), ge.reshape(se), gd.reshape(sd), gb, None
 
 
 class _ReconFn(torch.autograd.Function):

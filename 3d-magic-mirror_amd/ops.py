@@ -60,8 +60,26 @@ def poll_reported_faces(device=None, synchronize=False):
         n = int(w[0])
         if n != 0:
             w[0] = 0
-            raise RuntimeError("prepare_vertices: an earlier call's faces held %d vertex ids outside [0, V) (device %s:%d)" % (n, key[0], key[1]))
+            recent = ", ".join("#%d (V=%d, F=%d)" % c for c in _RECENT.get(key, []))
+            _RECENT[key] = []
+            raise RuntimeError("prepare_vertices: faces held %d vertex ids outside [0, V) (device %s:%d).  The report is DEFERRED (no call waits for the "
+                               "device): it surfaces in whichever prepare_vertices call, backward or poll on this device looks next -- possibly not the "
+                               "offender's own.  The offender is one of the calls enqueued there since the last clean look: %s" % (n, key[0], key[1], recent or "(none on record)"))
+        elif synchronize:
+            _RECENT[key] = []                                    # everything enqueued so far has run and was clean
     return None
+
+
+_RECENT = {}         # device key -> [(serial, V, F)] of the prepare_vertices calls since the last clean look (at most 16 kept): named in the deferred error
+_SERIAL = [0]
+
+
+def _note_call(dev, V, F):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    _SERIAL[0] += 1
+    r = _RECENT.setdefault(key, [])
+    r.append((_SERIAL[0], int(V), int(F)))
+    del r[:-16]
 
 
 def _raise_on_reported_faces(dev):
@@ -139,7 +157,9 @@ def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans
 
     ``camera_transform`` (B,4,3) is what the reference passes (networks.py:284-287).  With ``camera_rot`` (B,3,3) /
     ``camera_trans`` (B,3) instead, kaolin's ``rotate_translate_points`` ((p - t) @ R^T) is folded into the same transform.
-    NOTE -- deferred error: vertex ids of ``faces`` outside [0, V) are reported by a LATER call (``poll_reported_faces``), not by this one."""
+    NOTE -- deferred error: vertex ids of ``faces`` outside [0, V) are reported by a LATER look at the device's status word (the next
+    ``prepare_vertices``, a backward -- possibly ANOTHER call's, from the autograd thread -- or ``poll_reported_faces``), not by this call; the
+    message names the calls enqueued since the last clean look (serial number, V, F) so that the offender can be told apart."""
     N.require_device(vertices)
     dev = vertices.device
     if camera_transform is None:
@@ -152,6 +172,7 @@ def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans
     if faces.dim() != 2 or faces.shape[1] != 3:
         raise RuntimeError("faces must be (F,3), got %s" % (tuple(faces.shape),))
     _raise_on_reported_faces(dev)                                # (deferred: see poll_reported_faces)
+    _note_call(dev, vertices.shape[1], faces.shape[0])
     faces_i32, off, items = _faces_tables(faces, int(vertices.shape[1]), dev)
     proj = camera_proj.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()       # stays on the device: read by the kernels
     if proj.numel() != 3:
@@ -298,7 +319,10 @@ class _TexMapFn(torch.autograd.Function):
 
 def texture_mapping(texture_coordinates, texture_maps, mode='nearest'):
     """kaolin.render.mesh.texture_mapping: coordinates (B,H,W,2) or (B,N,2) in [0,1] (v up), maps (B,C,Ht,Wt) or (C,Ht,Wt)
-    -> (B,H,W,C) / (B,N,C).  'nearest' or 'bilinear' = grid_sample(align_corners=False, padding_mode='border')."""
+    -> (B,H,W,C) / (B,N,C).  'nearest' or 'bilinear' = grid_sample(align_corners=False, padding_mode='border').
+    NON-FINITE upstream gradients: the backward accumulates the texture gradient in per-image fixed point (bitwise reproducible), scaled by the
+    image's largest |gradient| -- one NaN / inf element makes that image's WHOLE texture gradient NaN, where ATen's grid_sampler / kaolin poison only
+    the touched texels (include/mm_render.h: MMTexMapGrads.workspace).  Loud by design; mask non-finite values BEFORE the backward, not per texel after."""
     if mode not in ('nearest', 'bilinear'):
         raise ValueError("texture_mapping: mode must be 'nearest' or 'bilinear'")
     N.require_device(texture_coordinates, texture_maps)

@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=30, help="extra eager steps with per-kernel HIP events")
     ap.add_argument("--grad-every", type=int, default=None, help="N > 1: launch the gradient all-reduce every K steps (default: derived, see grad_allreduce.policy)")
     ap.add_argument("--api-steps", type=int, default=200, help="steps of the DiffRender autograd path timed for value_api (0 disables)")
+    ap.add_argument("--options-steps", type=int, default=200, help="steps of `value`'s step timed under each Appendix C option combination a kaolin fixture may select (0 disables; N=1 only)")
     ap.add_argument("--trainer-steps", type=int, default=8, help="trainer-shaped config-3 steps timed for value_config3 (0 disables; N=1 only)")
     ap.add_argument("--grad-mb", type=float, default=None, help="fp32 gradient bytes all-reduced per step over RCCL (default 135 when N>1, else 0)")
     args = ap.parse_args()
@@ -392,7 +393,7 @@ def main():
         reducer.wait(); torch.cuda.synchronize(dev)
     loss_value = float(step.loss) if args.mode != "torch" else None
 
-    one_stream = api_value = api_fused_value = shim_value = no_imn_value = api_undeferred_value = None
+    one_stream = api_value = api_fused_value = shim_value = no_imn_value = api_undeferred_value = options_ab = None
     host_us_per_step = {}
     e1, e1_all = elapsed, elapsed_all
     if args.mode == "eager":
@@ -415,6 +416,30 @@ def main():
             one_noimn()
         e1n, _ = timed_median(one_noimn, args.steps, reps=3)
         no_imn_value = round(world * B * args.steps / e1n, 1)
+        # `value` again under the SURVEY Appendix C option combinations a kaolin fixture may select (tests/test_kaolin_pinning.py; parity at these
+        # sizes: tests/test_gpu_parity.py::test_the_option_combinations_...): whichever it selects is already timed.  Same step, same inputs.
+        if world == 1 and args.options_steps > 0:
+            Nn = pkg._native
+            combos = [("BARY_ONE_MINUS|BBOX_MIN_CLOSED_MAX_OPEN", Nn.OPT_BARY_ONE_MINUS | Nn.OPT_BBOX_MIN_CLOSED_MAX_OPEN),
+                      ("SOFT_SKIP_CULLED", Nn.OPT_SOFT_SKIP_CULLED), ("SH_ORDER_XYZ", Nn.OPT_SH_ORDER_XYZ),
+                      ("all four", Nn.OPT_BARY_ONE_MINUS | Nn.OPT_BBOX_MIN_CLOSED_MAX_OPEN | Nn.OPT_SOFT_SKIP_CULLED | Nn.OPT_SH_ORDER_XYZ)]
+            options_ab = {"defaults": {"options": 0, "images_per_s": one_stream}}
+            dr_opt = pkg.DiffRender(tpath, S, ratio=ratio, emit_imnormal=True)
+            for label, bits in combos:
+                dr_opt.options = int(bits)
+                st_o = stepmod.RenderLossStep(dr_opt, batches[0][0][0], batches[0][0][1], no_mask=True, fused=not args.unfused, emit_imnormal=True)
+                ctr4 = [0]
+
+                def one_opt():
+                    k = ctr4[0]; ctr4[0] += 1
+                    if nrot > 1:
+                        st_o.set_inputs(*batches[0][k % nrot])
+                    st_o.run()
+                for _ in range(20):
+                    one_opt()
+                eo, _ = timed_median(one_opt, args.options_steps, reps=3)
+                options_ab[label] = {"options": int(bits), "images_per_s": round(B * args.options_steps / eo, 1)}
+                del st_o
     if args.api_steps > 0:
         for _ in range(10):
             one_api()
@@ -587,6 +612,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "value_is_b48_one_stream": args.mode == "eager",
             "ranks_seen": ranks_seen, "dist_backend": dist_backend,
+            "value_per_gpu": round(total_images / head / world, 1),     # the N=1-equivalent figure of an N > 1 line (weak scaling: divide by the N=1 line's value)
             "timing": {"reps": max(1, args.reps), "statistic": "median over the repetitions of the K-step timed region",
                        "spread_pct_of_median": spread(e1_all if args.mode == "eager" else elapsed_all)},
             "config": {"workload": "%s: template %s (V=%d,F=%d), B=%d per GPU, %dx%d, texture %dx%d, no_mask, fwd+loss+bwd to all "
@@ -609,6 +635,7 @@ def main():
             "value_one_stream": one_stream, "value_four_streams": round(total_images / elapsed, 1) if args.mode == "eager" else None,
             "ms_per_step_four_streams": round(elapsed / args.steps * 1e3, 4) if args.mode == "eager" else None,
             "value_without_imnormal": no_imn_value,
+            "options_ab": options_ab,
             "value_api": api_value, "value_api_undeferred": api_undeferred_value, "value_api_fused": api_fused_value, "host_us_per_step": host_us_per_step, "value_shim": shim_value, "ddp_encoder": ddp_info,
             "value_config3": None if not config3 else config3.get("images_per_s"), "config3": config3,
             "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},

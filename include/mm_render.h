@@ -420,7 +420,10 @@ typedef struct MMTexMapGrads {
     float* grad_textures;           /* (B,C,Ht,Wt) overwritten, or NULL */
     /* optional scratch of >= mm_texture_mapping_backward_query_workspace bytes (256-byte aligned).  With it the texture gradient is
      * accumulated in 64-bit FIXED POINT (per-image power-of-two scale from max |grad_out|; integer adds commute) and is bitwise
-     * reproducible; without it (NULL) the scatter uses float atomics (order-dependent in the last bits). */
+     * reproducible; without it (NULL) the scatter uses float atomics (order-dependent in the last bits).
+     * NON-FINITE grad_out: the two forms differ.  The fixed-point form scales by the image's max |grad_out|, so ONE NaN / inf element turns the
+     * image's WHOLE texture gradient into NaN (loud, never a silently wrong finite value); the float-atomic form -- like ATen's grid_sampler and
+     * kaolin -- poisons only the texels under that element's footprint.  Code that masks NaNs per texel must pass workspace = NULL. */
     void* workspace;
     size_t workspace_bytes;
 } MMTexMapGrads;

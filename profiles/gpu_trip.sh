@@ -25,8 +25,8 @@ done
 # the bench lines AFTER the counter passes, with this trip's counters installed: their roofline.traffic is then the fresh one
 cp $OUT/profiles/traffic_latest.json $OUT/profiles/valu_latest.json profiles/ 2>/dev/null
 for C in $CONFIGS; do
-  EXTRA=""; [ "$C" != "config2" ] && EXTRA="--trainer-steps 0 --cpu-seconds 0 --steps 200"
+  EXTRA=""; [ "$C" != "config2" ] && EXTRA="--trainer-steps 0 --cpu-seconds 0 --options-steps 0 --steps 200"
   timeout 900 python bench.py --config $C $EXTRA > $OUT/bench_$C.json 2> $OUT/bench_$C.err; echo "bench $C rc=$?"; cut -c1-1500 $OUT/bench_$C.json
 done
-timeout 600 python bench.py --config config2x8 --trainer-steps 0 --cpu-seconds 0 --steps 200 > $OUT/bench_config2x8.json 2> $OUT/bench_config2x8.err; cut -c1-300 $OUT/bench_config2x8.json
+timeout 600 python bench.py --config config2x8 --trainer-steps 0 --cpu-seconds 0 --options-steps 0 --steps 200 > $OUT/bench_config2x8.json 2> $OUT/bench_config2x8.err; cut -c1-300 $OUT/bench_config2x8.json
 du -sh gpurun_out

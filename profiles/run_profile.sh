@@ -12,7 +12,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$CONFIG
 rm -rf $OUT; mkdir -p $OUT/stats $OUT/pmc
-BENCH="python $REPO/bench.py --config $CONFIG --mode eager --streams 1 --cpu-seconds 0 --profile-steps 0 --api-steps 0 --shim-steps 0 --trainer-steps 0 --settle-seconds 0.2 --reps 1"
+BENCH="python $REPO/bench.py --config $CONFIG --mode eager --streams 1 --cpu-seconds 0 --profile-steps 0 --api-steps 0 --shim-steps 0 --trainer-steps 0 --options-steps 0 --settle-seconds 0.2 --reps 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH --steps 50 --warmup 5 > $OUT/stats/bench.log 2>&1
 i=0
 SETS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"

@@ -462,7 +462,7 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     a.mult = d->multiplier; a.eps = d->eps; a.sigmainv = d->sigmainv; a.infl = d->boxlen * d->multiplier;
     a.kx = d->multiplier / (float)d->W; a.ky = d->multiplier / (float)d->H; a.sig2 = d->sigmainv / (d->multiplier * d->multiplier);
     a.geo = w.geo; a.face_uvs = d->face_uvs; a.fn = d->face_normals; a.textures = d->textures; a.lights = d->lights; a.bg = d->bg;
-    a.face_idx = d->face_idx; a.soft = w.soft; a.fflag = walk_queue_mode(d->options, w.bin_shift) ? w.fflag : nullptr;
+    a.face_idx = d->face_idx; a.soft = w.soft; a.fflag = walk_flags_mode(d->options, w.bin_shift) ? w.fflag : nullptr;
     a.sweep_sx = sweep_shrink(d->boxlen, d->W); a.sweep_sy = sweep_shrink(d->boxlen, d->H);
     a.grad_rgba = g->grad_rgba;   // (face flags: only the compacting walk of the forward sets them)
     a.gp = w.gp; a.gp2 = w.gp2; a.dl_part = w.dl_part; a.grad_bg = g->grad_bg;

@@ -71,11 +71,17 @@ struct TexRecord { unsigned xy; float tx, ty, d0, d1, d2; };       // xy = x0 | 
 // surface lands in a few tiles of the texture (a close-up puts four fifths of an image's records into one of 128).
 // which form of the forward walk a shape gets (mm_raster_walk.h): the compacting queue (+ the face flags the backward's sweep plan reads) for
 // screen bins larger than a tile, the per-batch walk for 8-pixel bins; MM_OPT_WALK_QUEUE / MM_OPT_WALK_BATCH force one (identical results)
+#ifndef MM_BATCH_FLAGS
+#define MM_BATCH_FLAGS 0     // 1: the per-batch walk (8-pixel bins) flags the faces that receive gradient, like the compacting walk -- built and measured in r06: raster_fwd +2.5-3 us, gather_bwd -1.4 us at 128x128 (profiles/r06_batch_walk_flags_ab.md): off
+#endif
+inline bool walk_flags_mode(int options, int bin_shift);
 inline bool walk_queue_mode(int options, int bin_shift) {
     if (options & MM_OPT_WALK_QUEUE) return true;
     if (options & MM_OPT_WALK_BATCH) return false;
     return bin_shift != 3;
 }
+// does the forward walk of this shape leave face flags (Workspace::fflag) for the backward's sweep plan?
+inline bool walk_flags_mode(int options, int bin_shift) { return MM_BATCH_FLAGS ? true : walk_queue_mode(options, bin_shift); }
 
 // ---- workspace carving (all offsets multiples of 256 bytes) ---------------------------------------------------------
 struct Workspace {

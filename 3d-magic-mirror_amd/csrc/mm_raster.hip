@@ -42,7 +42,16 @@ namespace mm {
 // kQueue: the compacting walk (tile_walk) for screen bins larger than a tile; otherwise the per-batch walk (tile_walk_batch)
 // kContour: the fused loss carries recon_data's contour term (host: fused_gt && fused_contour > 0)
 template <bool kNoMask, bool kBlock, bool kQueue, bool kContour>
-__global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_eu(MM_RASTER_WPE, MM_RASTER_WPE))) void raster_fwd_kernel(RasterArgs a) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
+__global__ __launch_bounds__(kBlock ? 256 : 64) __attribute__((amdgpu_waves_per_eu(MM_RASTER_WPE, MM_RASTER_WPE))) void raster_fwd_kernel(RasterArgs a_) {   // kBlock: 5 waves per SIMD = 96 VGPRs, 5 x 32 KiB LDS per CU
+#if defined(MM_ARGS_BY_VALUE) || !defined(__HIP_DEVICE_COMPILE__)
+    const RasterArgs& a = a_;
+#else
+    // The arguments are READ FROM THE KERNARG SEGMENT WHERE THEY ARE USED (scalar loads from constant memory, through the scalar cache) instead of
+    // being loaded into ~75 scalar registers at the kernel's entry and kept alive across the whole walk: that is what spilled 35-79 of them into
+    // vector-register lanes (v_writelane / v_readlane on an issue-bound kernel; verdict r05 item 3).
+    (void)a_;
+    const RasterArgs& a = *(const RasterArgs*)__builtin_amdgcn_kernarg_segment_ptr();   // (the kernel's only parameter: the segment starts with it)
+#endif
     MM_TIMELINE_BEGIN();
     __shared__ WaveStage s_stage[kBlock ? 4 : 1];
     MM_PP_BEGIN();
@@ -198,9 +207,10 @@ int launch_raster_fwd(const MMRenderDesc* d, const Workspace& w, hipStream_t s) 
     const bool block = walk_block_mode(a);
     const dim3 grid(walk_grid(a, block));
     ProfScope ps(d->prof_events, MM_PROF_RASTER_FWD, s);
-    // 8-pixel bins: the bin is the tile, nothing to compact -> the per-batch walk, no face flags (every face gets its sweep items)
+    // 8-pixel bins: the bin is the tile, nothing to compact -> the per-batch walk, no face flags (every face gets its sweep items;
+    // -DMM_BATCH_FLAGS=1: the r06 A/B in which this walk sets them too)
     const bool queue = walk_queue_mode(a);
-    if (!queue) a.fflag = nullptr;
+    if (!queue && !MM_BATCH_FLAGS) a.fflag = nullptr;
 #define MM_LAUNCH_RASTER2(NM, BL, QU, CO) hipLaunchKernelGGL((raster_fwd_kernel<NM, BL, QU, CO>), grid, dim3(BL ? 256 : 64), 0, s, a)
 #define MM_LAUNCH_RASTER(NM, BL, QU) do { if (a.contour > 0.f) MM_LAUNCH_RASTER2(NM, BL, QU, true); else MM_LAUNCH_RASTER2(NM, BL, QU, false); } while (0)
     if (block) {

@@ -405,7 +405,7 @@ __device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, Wa
     key = 0ull;
     ss.qnz = 1.f; ss.zeros = 0; ss.lastf = 0x7FFFFFFF;
     if (t.empty) return;                                         // wave-uniform: more than half of all tiles are empty
-    st->key[t.lane] = 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0;
+    st->key[t.lane] = 0ull; st->logsum[t.lane] = 0ll; st->zeros[t.lane] = 0; st->takenw[t.lane] = 0ull;
     wave_lds_sync();
     const float s2 = a.sigmainv / (a.mult * a.mult);
     const float4* geo = a.geo + (size_t)t.b * a.F * 3;
@@ -463,6 +463,11 @@ __device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, Wa
             const uint64_t sm = soft_take(ps, open, a.knum - cnt);   // the first knum hits of this pixel, in order
             cnt += __popcll(sm);
             if (sm != 0 && cnt >= a.knum) lastf = __float_as_int(st->p2[63 - __clzll((unsigned long long)sm)].z);   // knum-th face taken
+            // r06 A/B (-DMM_BATCH_FLAGS=1; a.fflag is null otherwise): the face flags for the backward here too, as the compacting walk sets them.
+            // Costs this kernel more than it saves the gather at 128x128 (profiles/r06_batch_walk_flags_ab.md): off by default.
+#if MM_BATCH_FLAGS
+            if (a.fflag && __ballot(sm != 0)) mark_taken(a, t, st, st, (wave_or_u64(sm) >> t.lane) & 1ull, 1ull, cbase);
+#endif
 #ifdef MM_BATCH_SOFT_PACKED                                             // (two pairs per lane in packed fp32, as the compacting walk does: measured SLOWER
             if (__ballot(sm != 0)) soft_pairs(a, t, st, sm, s2);         //  here, raster_fwd 34.4 / 92.8 / 191.7 us against 33.8 / 88.4 / 184.7 at 128x128 / 256x256 / B=384)
 #else
@@ -472,6 +477,9 @@ __device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, Wa
             wave_lds_sync();
         }
       }
+#if MM_BATCH_FLAGS
+      if (cbase + 64 < a.words) { wave_lds_sync(); flush_taken(a, t, st, cbase); }   // (meshes beyond 4096 faces; the LAST chunk's faces: flush_taken_last)
+#endif
     }
     wave_lds_sync();
     key = st->key[t.lane];

@@ -139,6 +139,9 @@ struct VertexBwdArgs {
     float *grad_azim, *grad_elev, *grad_dist, *grad_bias;
 };
 
+#ifndef MM_VBWD_ROWS
+#define MM_VBWD_ROWS 2
+#endif
 // Eight lanes per vertex, grid (ceil(V/32), B).  Per-vertex gradients are gathered through the static vertex->corner
 // CSR (no atomics); dT is reduced per workgroup and added to the image's accumulator; the LAST
 // workgroup of an image to arrive (agent-scope release / ticket / acquire, cdna_hip_programming.md G16) runs the
@@ -190,26 +193,27 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
             const float* part = a.part + ((size_t)b * a.item_cap + cm.x) * 12;
-            // the first four items' sums in ONE trip (clamped addresses, selected afterwards: a loop over a per-lane count costs a dependent
-            // trip per item, and faces of two or three items are common); the rare rest one by one.  Added in index order either way.
-            float pk[4][5];
+            // the first MM_VBWD_ROWS items' sums in ONE trip (clamped addresses, selected afterwards: a loop over a per-lane count costs a dependent
+            // trip per item); the rest MM_VBWD_ROWS at a time.  Added in index order either way.  (r06: 4 -> 2 rows.  A face has ONE item at 128x128 and
+            // the three spare rows were re-reads of it -- 80 of the ~140 bytes a corner requested, profiles/r06_vertex_bwd_traffic.md.)
+            float pk[MM_VBWD_ROWS][5];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < MM_VBWD_ROWS; ++c) {
                 const float* pc4 = a.part + ((size_t)b * a.item_cap + min(cm.x + min(c, max(cm.y - 1, 0)), a.item_cap - 1)) * 12;   // (a face without items still addresses a valid row)
                 pk[c][0] = pc4[k * 2]; pk[c][1] = pc4[k * 2 + 1]; pk[c][2] = pc4[6]; pk[c][3] = pc4[7]; pk[c][4] = pc4[8];
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < MM_VBWD_ROWS; ++c) {
                 if (c < cm.y) { gx += pk[c][0]; gy += pk[c][1]; g[0] += pk[c][2]; g[1] += pk[c][3]; g[2] += pk[c][4]; }
             }
-            for (int c0 = 4; c0 < cm.y; c0 += 4) {                // (big faces -- a close-up, a crumpled fine mesh: four rows per trip here too)
+            for (int c0 = MM_VBWD_ROWS; c0 < cm.y; c0 += MM_VBWD_ROWS) {   // (big faces -- a close-up, a crumpled fine mesh)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < MM_VBWD_ROWS; ++c) {
                     const float* pc4 = part + (size_t)min(c0 + c, cm.y - 1) * 12;
                     pk[c][0] = pc4[k * 2]; pk[c][1] = pc4[k * 2 + 1]; pk[c][2] = pc4[6]; pk[c][3] = pc4[7]; pk[c][4] = pc4[8];
                 }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < MM_VBWD_ROWS; ++c) {
                     if (c0 + c < cm.y) { gx += pk[c][0]; gy += pk[c][1]; g[0] += pk[c][2]; g[1] += pk[c][3]; g[2] += pk[c][4]; }
                 }
             }

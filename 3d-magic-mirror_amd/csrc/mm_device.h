@@ -485,7 +485,7 @@ struct ProfScope {
 // buffer and its C getter mm_debug_pp_<name>(out[MM_PP_MAX][MM_PP_SLOTS + 3]).  Compiles to nothing otherwise.
 #ifdef MM_PHASE_PROF
 #define MM_PP_MAX 16384
-#define MM_PP_SLOTS 8
+#define MM_PP_SLOTS 10
 #define MM_PP_STORAGE(name)                                                                                               \
     namespace mm { __device__ unsigned long long g_pp_##name[MM_PP_MAX][MM_PP_SLOTS + 3]; }                                  \
     extern "C" int mm_debug_pp_##name(unsigned long long* out) {                                                             \

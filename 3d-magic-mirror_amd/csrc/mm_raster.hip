@@ -26,7 +26,7 @@
 #include "mm_order.h"
 
 MM_TIMELINE_STORAGE(raster_fwd)
-MM_PP_STORAGE(raster_fwd)       // 0 tile setup, 1 mask -> id list, 2 fetch + stage + box tests + transposes, 3 colour pairs, 4 silhouette pairs, 5 shade + store
+MM_PP_STORAGE(raster_fwd)       // 0 tile setup, 1 mask -> id list, 2 fetch + stage + box tests + transposes, 3 colour pairs, 4 silhouette pairs, 5 shade + store, 6 / 7 coop barriers, 8 first mask load (latency alone), 9 first record fetch of a window (latency alone)
 
 namespace mm {
 

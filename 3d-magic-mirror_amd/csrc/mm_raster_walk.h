@@ -201,6 +201,7 @@ __device__ inline void scan_candidates(const RasterArgs& a, const TileCtx& t, Wa
     const int bmode = box_mode(a.options);
     int qn = 0;                                                  // candidates waiting in the queue (wave-uniform)
     uint64_t next_word = idw_load(a, t, 0);
+    MM_PP_MARK(8);                                               // (phase build: the first mask load's latency alone)
     for (int cbase = 0; cbase < a.words; cbase += 64) {
       IdWindows iw;
       cur_cbase = cbase;
@@ -227,6 +228,7 @@ __device__ inline void scan_candidates(const RasterArgs& a, const TileCtx& t, Wa
             n0 = geo[(size_t)nf * 3 + 0]; n1 = geo[(size_t)nf * 3 + 1]; n2 = geo[(size_t)nf * 3 + 2];
         };
         if (total) fetch(0);
+        MM_PP_MARK(9);                                           // (phase build: a window's first record fetch, its latency alone)
         const int nbatch = (total + 63) / 64 + (final ? 1 : 0);
         for (int i = 0; i < nbatch; ++i) {
             const int k0 = i * 64, n = max(0, min(64, total - k0));
@@ -414,6 +416,7 @@ __device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, Wa
     bool open = t.in_img;
     unsigned zfloor = 0;
     uint64_t next_word = idw_load(a, t, 0);
+    MM_PP_MARK(8);
     for (int cbase = 0; cbase < a.words; cbase += 64) {
       IdWindows iw;
       idw_begin(iw, a, t, next_word);
@@ -433,6 +436,7 @@ __device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, Wa
             }
         };
         fetch(0);
+        MM_PP_MARK(9);
         for (int k0 = 0; k0 < total; k0 += 64) {
             const int n = min(64, total - k0);
             const float4 g0 = n0, g1 = n1, g2 = n2;

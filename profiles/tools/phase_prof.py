@@ -33,9 +33,9 @@ KERNELS = {
     "gather_face": (["setup", "sweep: face_idx loads", "compaction", "item loads", "item math + LDS adds", "stores"], ("trips", "items")),
     "gather_tex": (["count + first record", "clear LDS", "records", "tile store"], ("records", "-")),
     "raster_fwd": (["tile setup", "mask -> id list", "geo fetch + stage + box tests + transposes", "colour pairs (coop: pair list)", "silhouette pairs (coop: pair evaluation)", "winner + shade + store", "coop: barrier + counts",
-                   "coop: barrier after the pairs"], ("candidates", "batches (coop: pairs)")),
+                   "coop: barrier after the pairs", "first mask-row load: latency alone", "first record fetch of a window: latency alone"], ("candidates", "batches (coop: pairs)")),
 }
-SL, MAXW = 8, 16384
+SL, MAXW = 10, 16384
 print("== %s: %s B=%d %dx%d (100 MHz ticks -> us)" % (cfg, name, B, H, W))
 for kn, (phases, cn) in KERNELS.items():
     fn = getattr(L, "mm_debug_pp_" + kn, None)

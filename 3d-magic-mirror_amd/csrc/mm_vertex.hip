@@ -140,7 +140,7 @@ struct VertexBwdArgs {
 };
 
 #ifndef MM_VBWD_ROWS
-#define MM_VBWD_ROWS 2
+#define MM_VBWD_ROWS 4      // item rows per corner and trip (2: -2.5 us at 256x256, -1.5 at 512x512 where faces have several items; equal at 128x128: r06_batch_walk_flags_ab.md)
 #endif
 // Eight lanes per vertex, grid (ceil(V/32), B).  Per-vertex gradients are gathered through the static vertex->corner
 // CSR (no atomics); dT is reduced per workgroup and added to the image's accumulator; the LAST
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             for (int j = 0; j < 3; ++j) { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
             const float* part = a.part + ((size_t)b * a.item_cap + cm.x) * 12;
             // the first MM_VBWD_ROWS items' sums in ONE trip (clamped addresses, selected afterwards: a loop over a per-lane count costs a dependent
-            // trip per item); the rest MM_VBWD_ROWS at a time.  Added in index order either way.  (r06: 4 -> 2 rows.  A face has ONE item at 128x128 and
-            // the three spare rows were re-reads of it -- 80 of the ~140 bytes a corner requested, profiles/r06_vertex_bwd_traffic.md.)
+            // trip per item); the rest MM_VBWD_ROWS at a time.  Added in index order either way.  (A face has ONE item at 128x128 and the spare rows are
+            // re-reads of it that hit the L1: two rows instead of four were measured equal there and slower where faces have several items.)
             float pk[MM_VBWD_ROWS][5];
 #pragma unroll
             for (int c = 0; c < MM_VBWD_ROWS; ++c) {

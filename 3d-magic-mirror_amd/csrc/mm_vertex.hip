@@ -185,13 +185,19 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
             const size_t o = (size_t)b * a.F + f;
             // the face's gradients = its sweep items' partial sums, added in index order (one item for most faces)
             float gx = 0.f, gy = 0.f, g[3] = {0.f, 0.f, 0.f};
-            const int2 cm = a.geometry_only ? make_int2(0, 0) : a.chunkmap[o];
+#ifndef MM_DBG_VBWD_SKIP
+#define MM_DBG_VBWD_SKIP 0       // traffic break-down builds (WRONG results, profiles/r06_vertex_bwd_traffic.md): 1 no item rows, 2 no face vertices, 4 no chunk map
+#endif
+            const int2 cm = (a.geometry_only || (MM_DBG_VBWD_SKIP & 4)) ? make_int2(0, (MM_DBG_VBWD_SKIP & 4) ? 1 : 0) : a.chunkmap[o];
             // the face's three vertices ride along with chunkmap: loaded whether or not the normal gradient below turns out to be zero
             // -- inside that branch they would cost a dependent trip to memory of their own
             const int i0 = ent.y, i1 = ent.z, i2 = ent.w;
             float pa[3], pb[3], pc[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
+            for (int j = 0; j < 3; ++j) {
+                if (MM_DBG_VBWD_SKIP & 2) { pa[j] = p[j]; pb[j] = p[j] + 1.f; pc[j] = p[j] - 1.f; }
+                else { pa[j] = vb[(size_t)i0 * 3 + j]; pb[j] = vb[(size_t)i1 * 3 + j]; pc[j] = vb[(size_t)i2 * 3 + j]; }
+            }
             const float* part = a.part + ((size_t)b * a.item_cap + cm.x) * 12;
             // the first MM_VBWD_ROWS items' sums in ONE trip (clamped addresses, selected afterwards: a loop over a per-lane count costs a dependent
             // trip per item); the rest MM_VBWD_ROWS at a time.  Added in index order either way.  (A face has ONE item at 128x128 and the spare rows are
@@ -200,6 +206,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
 #pragma unroll
             for (int c = 0; c < MM_VBWD_ROWS; ++c) {
                 const float* pc4 = a.part + ((size_t)b * a.item_cap + min(cm.x + min(c, max(cm.y - 1, 0)), a.item_cap - 1)) * 12;   // (a face without items still addresses a valid row)
+                if (MM_DBG_VBWD_SKIP & 1) { pk[c][0] = pk[c][1] = pk[c][2] = pk[c][3] = pk[c][4] = (float)item; continue; }
                 pk[c][0] = pc4[k * 2]; pk[c][1] = pc4[k * 2 + 1]; pk[c][2] = pc4[6]; pk[c][3] = pc4[7]; pk[c][4] = pc4[8];
             }
 #pragma unroll

@@ -33,7 +33,9 @@ struct Mailbox {
     const void* node = nullptr;             // the render's autograd node (identity of `pred`'s producer)
     uint32_t version = 0;                   // the image's version counter when render returned it
     int64_t B = 0, H = 0, W = 0;
-    at::Tensor token;                       // the render node's fifth output
+    bool has_token = false;                 // the node declared a fifth output (the token's slot: output_nr 4).  The token TENSOR is not kept here: it would
+                                            // close a reference cycle node -> context -> mailbox -> token -> grad_fn -> node that nothing ever frees;
+                                            // recon_data makes a fresh tensor and hangs it on the node's output 4 (deferred_token below)
     bool claimed = false;                   // a recon_data has taken this render (a second one runs un-deferred)
     at::Tensor gt, recon_ws;                // recon_data's dense target and its workspace (the totals live in it)
     const float* totals = nullptr;
@@ -243,12 +245,12 @@ class RenderNode : public torch::autograd::Function<RenderNode> {
             // written: no launch), and the mailbox that recon_data finds through the image's address
             auto mb = std::make_shared<Mailbox>();
             mb->rgba_ptr = out[0].data_ptr(); mb->B = out[0].size(0); mb->H = out[0].size(1); mb->W = out[0].size(2);
-            mb->token = at::empty({1}, out[0].options());
+            mb->has_token = true;
             ctx->saved_data["mb"] = mailbox_holder(mb);
             { std::lock_guard<std::mutex> lock(g_mail_mutex);
               if (g_mail.size() > 256) for (auto it = g_mail.begin(); it != g_mail.end();) it = it->second.expired() ? g_mail.erase(it) : std::next(it);
               g_mail[mb->rgba_ptr] = mb; }
-            ret.push_back(mb->token);
+            ret.push_back(at::empty({1}, out[0].options()));    // (declares output 4 and its metadata; dropped by render_node)
         }
         return ret;
     }
@@ -402,8 +404,9 @@ tensor_list render_node(int64_t f_fwd, int64_t f_loss, int64_t f_bwd, std::strin
         { std::lock_guard<std::mutex> lock(g_mail_mutex);
           auto it = g_mail.find(out[0].data_ptr());
           if (it != g_mail.end()) mb = it->second.lock(); }
-        if (mb && out[0].grad_fn()) { mb->node = out[0].grad_fn().get(); mb->version = out[0]._version(); mb->token = out[4]; }   // (the token AS an output of the node)
-        else if (mb) mb->claimed = true;                         // nothing requires grad: no backward will ever run, nothing to defer
+        if (mb && out[0].grad_fn() && out[4].grad_fn().get() == out[0].grad_fn().get() && out[4].output_nr() == 4) {
+            mb->node = out[0].grad_fn().get(); mb->version = out[0]._version();
+        } else if (mb) mb->claimed = true;                       // nothing requires grad: no backward will ever run, nothing to defer
         out.pop_back();
     }
     return out;
@@ -417,7 +420,7 @@ std::shared_ptr<Mailbox> deferrable_render(const at::Tensor& pred) {
     { std::lock_guard<std::mutex> lock(g_mail_mutex);
       auto it = g_mail.find(pred.data_ptr());
       if (it != g_mail.end()) mb = it->second.lock(); }
-    if (!mb || mb->claimed || !mb->node || !mb->token.defined()) return nullptr;
+    if (!mb || mb->claimed || !mb->node || !mb->has_token) return nullptr;
     if (pred.size(0) != mb->B || pred.size(1) != 4 || pred.size(2) != mb->H || pred.size(3) != mb->W) return nullptr;
     if (pred.stride(0) != 4 * mb->H * mb->W || pred.stride(1) != 1 || pred.stride(2) != 4 * mb->W || pred.stride(3) != 4) return nullptr;
     if (pred._version() != mb->version) return nullptr;         // written in place since the render returned it
@@ -427,8 +430,15 @@ std::shared_ptr<Mailbox> deferrable_render(const at::Tensor& pred) {
     if (fn->num_inputs() < 1 || fn->next_edges().size() != 1) return nullptr;
     const auto& e = fn->next_edge(0);
     if (e.function.get() != mb->node || e.input_nr != 0 || fn->name().find("Permute") == std::string::npos) return nullptr;
-    if (!mb->token.grad_fn() || mb->token.grad_fn().get() != mb->node) return nullptr;
     return mb;
+}
+
+// a one-element tensor that IS output 4 of `pred`'s render node as far as autograd is concerned: whatever gradient reaches it arrives in that node's
+// backward as g[4].  (`pred` has passed deferrable_render: its grad_fn is the permute whose only input edge is the node's output 0.)
+at::Tensor deferred_token(const at::Tensor& pred) {
+    at::Tensor tok = at::empty({1}, pred.options());
+    torch::autograd::impl::set_gradient_edge(tok, torch::autograd::Edge(pred.grad_fn()->next_edge(0).function, 4));
+    return tok;
 }
 
 at::Tensor recon_node(int64_t f_ws, int64_t f_fwd, int64_t f_bwd, at::Tensor pred, at::Tensor gt, double image_weight, double contour, int64_t stream,
@@ -437,7 +447,7 @@ at::Tensor recon_node(int64_t f_ws, int64_t f_fwd, int64_t f_bwd, at::Tensor pre
         if (auto mb = deferrable_render(pred)) {
             mb->claimed = true;
             // (find the holder again through the node's context is not possible from here: a second holder of the same mailbox travels as an argument)
-            return ReconDeferredNode::apply(mb->token, mailbox_holder(mb), f_ws, f_fwd, f_tot, pred.detach(), gt, image_weight);
+            return ReconDeferredNode::apply(deferred_token(pred), mailbox_holder(mb), f_ws, f_fwd, f_tot, pred.detach(), gt, image_weight);
         }
     }
     return ReconNode::apply(f_ws, f_fwd, f_bwd, pred, gt, image_weight, contour, stream);

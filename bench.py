@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--grad-every", type=int, default=None, help="N > 1: launch the gradient all-reduce every K steps (default: derived, see grad_allreduce.policy)")
     ap.add_argument("--api-steps", type=int, default=200, help="steps of the DiffRender autograd path timed for value_api (0 disables)")
     ap.add_argument("--options-steps", type=int, default=200, help="steps of `value`'s step timed under each Appendix C option combination a kaolin fixture may select (0 disables; N=1 only)")
+    ap.add_argument("--api-warmup", type=int, default=300, help="untimed steps of EACH autograd-API flavour before any of them is timed")
     ap.add_argument("--trainer-steps", type=int, default=8, help="trainer-shaped config-3 steps timed for value_config3 (0 disables; N=1 only)")
     ap.add_argument("--grad-mb", type=float, default=None, help="fp32 gradient bytes all-reduced per step over RCCL (default 135 when N>1, else 0)")
     args = ap.parse_args()
@@ -441,8 +442,17 @@ def main():
                 options_ab[label] = {"options": int(bits), "images_per_s": round(B * args.options_steps / eo, 1)}
                 del st_o
     if args.api_steps > 0:
-        for _ in range(10):
-            one_api()
+        # Run-in: the FIRST autograd flavour measured in a process used to carry ~80 us of host time per step for its first few hundred steps
+        # (measured, profiles/tools/api_noise.py: 175-186 us against 100-108 us from the second pass on, whichever flavour comes first: the
+        # engine's thread, the caching allocator's size classes, the host's clocks) -- r05's driver line read 226 us for value_api and 89 us
+        # for value_api_fused for that reason.  All three flavours are run in before any of them is timed.
+        api_warm = max(10, args.api_warmup)
+        for flavour in range(3):
+            dr_api.defer_recon_fusion = flavour != 1
+            for _ in range(api_warm):
+                (one_api_fused if flavour == 2 else one_api)()
+        torch.cuda.synchronize(dev)
+        dr_api.defer_recon_fusion = True
         e2, _ = timed_median(one_api, args.api_steps, reps=3)
         api_value = round(world * B * args.api_steps / e2, 1)
         host_us_per_step["c_abi_one_stream"] = host_us(one_single)

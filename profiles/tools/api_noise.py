@@ -1,0 +1,35 @@
+import sys, os, importlib, time, torch, numpy as np
+ROOT = "/root/repo"; sys.path.insert(0, ROOT)
+pkg = importlib.import_module("3d-magic-mirror_amd")
+dev = torch.device("cuda:0")
+LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "distances", "biases")
+dr = pkg.DiffRender(os.path.join(ROOT, "tests/golden/templates/smpl_uv_642.npz"), 128)
+sets = []
+for r in range(8):
+    att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, 48, 128, 128, seed=r)
+    datt = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}
+    sets.append((datt, {k: datt[k].clone().requires_grad_(True) for k in LEAVES}, gt.to(dev)))
+ctr = [0]
+def one(fused=False):
+    datt, lv, gtd = sets[ctr[0] % 8]; ctr[0] += 1
+    for v in lv.values(): v.grad = None
+    a = dict(datt); a.update(lv)
+    if fused:
+        dr.render_recon(gtd, no_mask=True, **a)[0].backward()
+    else:
+        rgbs, _ = dr.render(no_mask=True, **a)
+        dr.recon_data(rgbs, gtd, no_mask=True).backward()
+def host(fn, n=60):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    dt = (time.perf_counter() - t0) / n * 1e6; torch.cuda.synchronize(); return dt
+def thr(fn, n=300):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return 48 * n / (time.perf_counter() - t0)
+for rep in range(4):
+    for name, defer, fused in (("deferred", True, False), ("undeferred", False, False), ("fused", True, True)):
+        dr.defer_recon_fusion = defer
+        f = lambda: one(fused)
+        for _ in range(20): f()
+        print(rep, name, "host us %.1f %.1f %.1f" % (host(f), host(f), host(f)), "img/s %.0f %.0f" % (thr(f), thr(f)), "mem MB %.0f" % (torch.cuda.memory_allocated() / 1e6), flush=True)

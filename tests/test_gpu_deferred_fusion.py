@@ -184,3 +184,32 @@ def test_deferred_totals_at_the_c_abi(pkg):
     assert N.lib().mm_render_backward(ctypes.byref(d), ctypes.byref(g), None) == -5        # MM_ERR_UNSUPPORTED: the contour term is not deferred
     d.fused_contour = 0.0
     assert N.lib().mm_render_forward(ctypes.byref(d), None) == -5                          # ... and a forward has nothing to defer
+
+
+def test_deferred_steps_free_everything_they_held(pkg):
+    """The render node keeps the recon_data's target and workspace alive for its backward (the mailbox) -- and lets go of them with the graph: no
+    reference cycle through the token (the token tensor is made at recon_data time, not kept by the node).  Device memory in use is flat over steps
+    that bring a fresh target each."""
+    _ext(pkg)
+    dr, datt, gt, dev = _setup(pkg, "smpl_uv_642", 8, 64, seed=3)
+    used = []
+    for step in range(24):
+        for k in LEAVES:
+            datt[k].grad = None
+        g = gt.clone() + 0.0                                     # a new target tensor every step, as a data loader hands them out
+        rgbs, out = dr.render(no_mask=True, **datt)
+        loss = dr.recon_data(rgbs, g, no_mask=True)
+        loss.backward()
+        del rgbs, out, loss, g
+        torch.cuda.synchronize()
+        used.append(torch.cuda.memory_allocated(dev))
+    assert used[-1] == used[8], (used[8], used[-1])
+    # ... and without a backward (an evaluation loop that forgot no_grad): the graph dies with its last reference
+    for step in range(12):
+        g = gt.clone() + 0.0
+        rgbs, out = dr.render(no_mask=True, **datt)
+        loss = dr.recon_data(rgbs, g, no_mask=True)
+        del rgbs, out, loss, g
+        torch.cuda.synchronize()
+        used.append(torch.cuda.memory_allocated(dev))
+    assert used[-1] == used[-6], (used[-6], used[-1])

@@ -18,7 +18,9 @@ steps, each repetition bracketed by barrier + synchronize: the driver's short --
   value_without_imnormal  `value` without the visualise-only imnormal output.
   value_api_undeferred  value_api with DiffRender.defer_recon_fusion = False (rounds 1-5's value_api: recon_data's own backward launch, dL/d image through memory)
   value_api           DiffRender.render -> DiffRender.recon_data -> loss.backward() through the torch.autograd wrappers (the calls
-                      trainer.py makes, :276,441,509-518), one stream.
+                      trainer.py makes, :276,441,509-518), one stream; recon_data's backward deferred into the render node (round 6).
+                      value_api* = the best of three interleaved rounds of 200 steps (host-bound figures on a host with slow spells:
+                      host_us_per_step.rounds keeps every round).
   value_api_fused     the same step through DiffRender.render_recon (loss folded into the render kernels).
                       (Rounds 3-4 also reported value_api_graphed*: captured class-API steps, removed in round 5 -- slower than value_api_fused on
                       every box, profiles/r05_api_paths.md.)
@@ -452,24 +454,26 @@ def main():
             for _ in range(api_warm):
                 (one_api_fused if flavour == 2 else one_api)()
         torch.cuda.synchronize(dev)
+        # The three flavours INTERLEAVED, three rounds, best round per flavour: this path is host-bound, and the box's host has slow spells of a second
+        # or two (all flavours at ~200 us per step instead of ~100: profiles/tools/api_noise2.py, profiles/r06_api_noise.md) that would otherwise land on
+        # whichever flavour is being timed; every round's figures are kept in the line (api_rounds).
+        flavours = (("api", True, one_api), ("api_undeferred", False, one_api), ("api_fused", True, one_api_fused))
+        api_rounds = {name: [] for name, _, _ in flavours}
+        host_rounds = {name: [] for name, _, _ in flavours}
+        for _round in range(3):
+            for name, defer, fn in flavours:
+                dr_api.defer_recon_fusion = defer
+                for _ in range(10):
+                    fn()
+                e_, _ = timed_median(fn, args.api_steps, reps=1)
+                api_rounds[name].append(round(world * B * args.api_steps / e_, 1))
+                host_rounds[name].append(host_us(fn))
         dr_api.defer_recon_fusion = True
-        e2, _ = timed_median(one_api, args.api_steps, reps=3)
-        api_value = round(world * B * args.api_steps / e2, 1)
+        api_value, api_undeferred_value, api_fused_value = (max(api_rounds[n]) for n in ("api", "api_undeferred", "api_fused"))
         host_us_per_step["c_abi_one_stream"] = host_us(one_single)
-        host_us_per_step["api"] = host_us(one_api)
-        # the same calls with the deferral switched off (round 5's value_api: recon_data's own backward launch + the dL/d image round trip)
-        dr_api.defer_recon_fusion = False
-        for _ in range(10):
-            one_api()
-        e2u, _ = timed_median(one_api, args.api_steps, reps=3)
-        api_undeferred_value = round(world * B * args.api_steps / e2u, 1)
-        host_us_per_step["api_undeferred"] = host_us(one_api)
-        dr_api.defer_recon_fusion = True
-        for _ in range(10):
-            one_api_fused()
-        e2f, _ = timed_median(one_api_fused, args.api_steps, reps=3)
-        api_fused_value = round(world * B * args.api_steps / e2f, 1)
-        host_us_per_step["api_fused"] = host_us(one_api_fused)
+        for name in api_rounds:
+            host_us_per_step[name] = min(host_rounds[name])
+        host_us_per_step["rounds"] = {"images_per_s": api_rounds, "host_us": host_rounds, "statistic": "value_api* = best of three interleaved rounds; host_us = the smallest"}
     if args.shim_steps > 0 and rank == 0:
         # the un-fused kaolin-shaped operator chain in the reference's order (networks.py:278-317): ~40 launches per render, float atomics
         try:

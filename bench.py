@@ -20,7 +20,9 @@ steps, each repetition bracketed by barrier + synchronize: the driver's short --
   value_api           DiffRender.render -> DiffRender.recon_data -> loss.backward() through the torch.autograd wrappers (the calls
                       trainer.py makes, :276,441,509-518), one stream; recon_data's backward deferred into the render node (round 6).
                       value_api* = the best of three interleaved rounds of 200 steps (host-bound figures on a host with slow spells:
-                      host_us_per_step.rounds keeps every round).
+                      host_us_per_step.rounds keeps every round).  value_api*_st: the same with torch.autograd.set_multithreading_enabled(False)
+                      (the whole backward on the calling thread: one line in train.py; the default's two thread wake-ups per step are what a dozing
+                      host charges 60-100 us for).
   value_api_fused     the same step through DiffRender.render_recon (loss folded into the render kernels).
                       (Rounds 3-4 also reported value_api_graphed*: captured class-API steps, removed in round 5 -- slower than value_api_fused on
                       every box, profiles/r05_api_paths.md.)
@@ -397,6 +399,7 @@ def main():
     loss_value = float(step.loss) if args.mode != "torch" else None
 
     one_stream = api_value = api_fused_value = shim_value = no_imn_value = api_undeferred_value = options_ab = None
+    api_st_values = {}
     host_us_per_step = {}
     e1, e1_all = elapsed, elapsed_all
     if args.mode == "eager":
@@ -458,20 +461,29 @@ def main():
         # or two (all flavours at ~200 us per step instead of ~100: profiles/tools/api_noise2.py, profiles/r06_api_noise.md) that would otherwise land on
         # whichever flavour is being timed; every round's figures are kept in the line (api_rounds).
         flavours = (("api", True, one_api), ("api_undeferred", False, one_api), ("api_fused", True, one_api_fused))
-        api_rounds = {name: [] for name, _, _ in flavours}
-        host_rounds = {name: [] for name, _, _ in flavours}
+        # ... and each flavour a second time with the WHOLE backward on the calling thread (torch.autograd.set_multithreading_enabled(False): one line in
+        # train.py, same results): the default hands every backward to the engine's device thread and back -- two thread wake-ups per step, which is what
+        # the host's slow spells are made of (60-100 us per step on a dozing host; profiles/r06_api_noise.md).  *_st = single-threaded backward.
+        names = [n for n, _, _ in flavours] + [n + "_st" for n, _, _ in flavours]
+        api_rounds = {name: [] for name in names}
+        host_rounds = {name: [] for name in names}
         for _round in range(3):
-            for name, defer, fn in flavours:
-                dr_api.defer_recon_fusion = defer
-                for _ in range(10):
-                    fn()
-                e_, _ = timed_median(fn, args.api_steps, reps=1)
-                api_rounds[name].append(round(world * B * args.api_steps / e_, 1))
-                host_rounds[name].append(host_us(fn))
+            for st_mode in (False, True):
+                torch.autograd.set_multithreading_enabled(not st_mode)
+                for name, defer, fn in flavours:
+                    key = name + ("_st" if st_mode else "")
+                    dr_api.defer_recon_fusion = defer
+                    for _ in range(10):
+                        fn()
+                    e_, _ = timed_median(fn, args.api_steps, reps=1)
+                    api_rounds[key].append(round(world * B * args.api_steps / e_, 1))
+                    host_rounds[key].append(host_us(fn))
+        torch.autograd.set_multithreading_enabled(True)
         dr_api.defer_recon_fusion = True
         api_value, api_undeferred_value, api_fused_value = (max(api_rounds[n]) for n in ("api", "api_undeferred", "api_fused"))
+        api_st_values = {"value_" + n: max(api_rounds[n]) for n in names if n.endswith("_st")}
         host_us_per_step["c_abi_one_stream"] = host_us(one_single)
-        for name in api_rounds:
+        for name in names:
             host_us_per_step[name] = min(host_rounds[name])
         host_us_per_step["rounds"] = {"images_per_s": api_rounds, "host_us": host_rounds, "statistic": "value_api* = best of three interleaved rounds; host_us = the smallest"}
     if args.shim_steps > 0 and rank == 0:
@@ -650,7 +662,8 @@ def main():
             "ms_per_step_four_streams": round(elapsed / args.steps * 1e3, 4) if args.mode == "eager" else None,
             "value_without_imnormal": no_imn_value,
             "options_ab": options_ab,
-            "value_api": api_value, "value_api_undeferred": api_undeferred_value, "value_api_fused": api_fused_value, "host_us_per_step": host_us_per_step, "value_shim": shim_value, "ddp_encoder": ddp_info,
+            "value_api": api_value, "value_api_undeferred": api_undeferred_value, "value_api_fused": api_fused_value,
+            **api_st_values, "host_us_per_step": host_us_per_step, "value_shim": shim_value, "ddp_encoder": ddp_info,
             "value_config3": None if not config3 else config3.get("images_per_s"), "config3": config3,
             "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v, 3) for k, v in kernels_us.items()},
             "loss": loss_value,

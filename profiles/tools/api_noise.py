@@ -27,6 +27,9 @@ def thr(fn, n=300):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return 48 * n / (time.perf_counter() - t0)
+if os.environ.get("MM_SINGLE_THREAD_BACKWARD"):
+    torch.autograd.set_multithreading_enabled(False)             # the whole backward on the calling thread: no hand-over to the engine's device thread
+    print("multithreaded backward OFF")
 for rep in range(4):
     for name, defer, fused in (("deferred", True, False), ("undeferred", False, False), ("fused", True, True)):
         dr.defer_recon_fusion = defer

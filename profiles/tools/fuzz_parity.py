@@ -128,13 +128,34 @@ for case in range(ncase):
             # A gradient beyond 1e-4 of the fp32 oracle with the image itself in agreement: is fp32 the problem?  The same backward in float64 is the
             # judge: where the fp32 ORACLE is itself far from it and the HIP result is no farther (twice its distance + 1e-4), the case is ill-conditioned
             # in fp32 (tiny screens with huge soft margins: a few pixels carry the whole loss) -- reported as COND and counted apart, never as ok.
-            g64 = oracle.render_backward(inp, H, W, no_mask, proj, dpred_nhwc.astype(np.float64), None if wfn_o is None else wfn_o.astype(np.float64), dtype=np.float64, **kw)
+            with oracle.options(optbit):
+                g64 = oracle.render_backward(inp, H, W, no_mask, proj, dpred_nhwc.astype(np.float64), None if wfn_o is None else wfn_o.astype(np.float64), dtype=np.float64, **kw)
             cond = True
+            late = []
             for k in LEAVES:
                 if datt.get(k) is None or (k == "bg" and not no_mask):
                     continue
                 e_hip = rel_errors(datt[k].grad, g64[k])[0]; e_o32 = rel_errors(g_o[k], g64[k])[0]
-                cond = cond and e_hip <= 2.0 * e_o32 + 1e-4
+                if e_hip > 2.0 * e_o32 + 1e-4:
+                    late.append((k, e_hip))
+            if late:
+                # The fp32 oracle can be LUCKY (r06, seed 8308 case 126: dL/d distance of one image = a sum over 2 562 vertices that cancels to 1e-3 of its
+                # terms; oracle 4.5e-4 from float64, HIP 2.0e-3).  Second judge, independent of either fp32 result: the float64 backward's own sensitivity to
+                # inputs moved by ONE fp32 rounding (vertices and camera scalars times 1 + 2^-24 N(0,1), three draws) -- what ANY fp32 evaluation may suffer
+                # before it has done a single operation.  A gradient no farther from float64 than four times that (+ 1e-4) is a conditioning case.
+                sens = {k: 0.0 for k, _ in late}
+                prng = np.random.default_rng(12345 + case)
+                for _ in range(3):
+                    inp_p = dict(inp)
+                    for kk in ("vertices", "azimuths", "elevations", "distances", "biases"):
+                        inp_p[kk] = (inp[kk].astype(np.float64) * (1.0 + 2.0 ** -24 * prng.standard_normal(inp[kk].shape))).astype(np.float64)
+                    with oracle.options(optbit):
+                        g64p = oracle.render_backward(inp_p, H, W, no_mask, proj, dpred_nhwc.astype(np.float64), None if wfn_o is None else wfn_o.astype(np.float64), dtype=np.float64, **kw)
+                    for k, _ in late:
+                        sens[k] = max(sens[k], rel_errors(g64p[k], g64[k])[0])
+                cond = all(e <= 4.0 * sens[k] + 1e-4 for k, e in late)
+                if os.environ.get("MM_FUZZ_DETAIL"):
+                    print("      float64 sensitivity to one fp32 rounding of the inputs:", {k: "%.2e (HIP %.2e)" % (sens[k], e) for k, e in late})
             if cond:
                 label = "COND"; ncond += 1
         print("%s  case %2d  %-90s face_idx diff %d, worst err %.2e (%s)%s" % (label, case, tag, nf, worst, max((k for k in errs if k not in negl), key=errs.get),
@@ -142,7 +163,8 @@ for case in range(ncase):
         bad += label == "FAIL"
         if not ok and os.environ.get("MM_FUZZ_DETAIL"):
             print("      all errors:", {k: "%.2e" % v for k, v in errs.items()})
-            g64 = oracle.render_backward(inp, H, W, no_mask, proj, dpred_nhwc.astype(np.float64), None if wfn_o is None else wfn_o.astype(np.float64), dtype=np.float64, **kw)
+            with oracle.options(optbit):
+              g64 = oracle.render_backward(inp, H, W, no_mask, proj, dpred_nhwc.astype(np.float64), None if wfn_o is None else wfn_o.astype(np.float64), dtype=np.float64, **kw)
             for k in ("vertices", "distances", "azimuths"):
                 got = datt[k].grad.cpu().numpy().astype(np.float64); r32 = g_o[k].astype(np.float64); r64 = g64[k]
                 i = np.unravel_index(np.abs(got - r32).argmax(), got.shape)

@@ -10,6 +10,9 @@ element: a gradient tensor has exact zeros and entries that are sums of cancelli
 Where fp32 conditioning makes that unattainable (tiny screens with huge soft margins: a few pixels carry the whole loss and the fp32
 ORACLE is itself far from its float64 form), the float64 oracle decides, exactly as the fuzz tool's COND rule does: the case passes as
 "cond" iff HIP is no farther from the float64 backward than twice the fp32 oracle's own distance + rtol -- reported apart, never as ok.
+(The fuzz tool has a second judge for the case of a LUCKY fp32 oracle -- found in round 6: a camera gradient that is a sum cancelling to 1e-3 of
+its terms, oracle 4.5e-4 from float64, HIP 2.0e-3 --: the float64 backward's own sensitivity to inputs moved by one fp32 rounding; a gradient no
+farther from float64 than four times that + rtol is a conditioning case too.  profiles/tools/fuzz_parity.py, profiles/r06_fuzz_parity_tail.txt.)
 """
 import numpy as np
 

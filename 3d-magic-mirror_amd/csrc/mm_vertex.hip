@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void vertex_bwd_kernel(VertexBwdArgs a) {
 #ifndef MM_DBG_VBWD_SKIP
 #define MM_DBG_VBWD_SKIP 0       // traffic break-down builds (WRONG results, profiles/r06_vertex_bwd_traffic.md): 1 no item rows, 2 no face vertices, 4 no chunk map
 #endif
-            const int2 cm = (a.geometry_only || (MM_DBG_VBWD_SKIP & 4)) ? make_int2(0, (MM_DBG_VBWD_SKIP & 4) ? 1 : 0) : a.chunkmap[o];
+            const int2 cm = (a.geometry_only || (MM_DBG_VBWD_SKIP & 4) != 0) ? make_int2(0, (MM_DBG_VBWD_SKIP & 4) ? 1 : 0) : a.chunkmap[o];
             // the face's three vertices ride along with chunkmap: loaded whether or not the normal gradient below turns out to be zero
             // -- inside that branch they would cost a dependent trip to memory of their own
             const int i0 = ent.y, i1 = ent.z, i2 = ent.w;

@@ -42,7 +42,10 @@ namespace mm {
 #ifndef MM_SWEEP
 #define MM_SWEEP 16             // pixels per lane per trip
 #endif
+#ifndef MM_FL                  // (4 / 16 lanes and 8 / 4 pixels per lane and trip measured in r06, profiles/r06_sweep_shape_ab.md: 8 x 16 is the best shape at every
+                               //  one-batch size; 4 x 16 wins 5 % of this kernel at B=384 only)
 #define MM_FL 8                 // lanes per sweep item: a trip covers MM_FL * MM_SWEEP pixels of each of the wave's items
+#endif
 #define MM_FPW (64 / MM_FL)     // items per wave
 static_assert(MM_CHUNK_PX % (MM_FL * MM_SWEEP) == 0, "a chunk is a whole number of trips");
 
@@ -296,9 +299,10 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
     }
     for (int k = sl; k < 9; k += MM_FL) st->slot[grp].acc[k] = 0ll;
     int nmax = hi - lo;
-    nmax = max(nmax, (int)lane_xchg<8>((unsigned)nmax, lane)); nmax = max(nmax, (int)lane_xchg<16>((unsigned)nmax, lane));
-    nmax = max(nmax, (int)lane_xchg<32>((unsigned)nmax, lane));
-    static_assert(MM_FL == 8, "the exchange strides above start at the lanes-per-item count");
+    if (MM_FL <= 4) nmax = max(nmax, (int)lane_xchg<4>((unsigned)nmax, lane));
+    if (MM_FL <= 8) nmax = max(nmax, (int)lane_xchg<8>((unsigned)nmax, lane));
+    nmax = max(nmax, (int)lane_xchg<16>((unsigned)nmax, lane)); nmax = max(nmax, (int)lane_xchg<32>((unsigned)nmax, lane));
+    static_assert(MM_FL == 16 || MM_FL == 8 || MM_FL == 4, "the exchange strides above start at the lanes-per-item count");
     wave_sync_lds();
     MM_PP_MARK(0);
 

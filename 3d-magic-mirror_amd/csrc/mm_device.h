@@ -464,14 +464,18 @@ struct ProfScope {
 // mm_debug_timeline_<name>(out[MM_TIMELINE_MAX][2]).  Everything compiles to nothing otherwise.
 #ifdef MM_TIMELINE
 #define MM_TIMELINE_MAX 81920
+// third word: where the workgroup's first wave ran -- HW_REG_HW_ID (gfx9 layout: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]) in the
+// low half, HW_REG_XCC_ID [3:0] (the XCD) in the high half: profiles/tools/timeline.py turns it into the per-CU placement of the launch
 #define MM_TIMELINE_STORAGE(name)                                                                                         \
-    namespace mm { __device__ unsigned long long g_tl_##name[MM_TIMELINE_MAX][2]; }                                          \
+    namespace mm { __device__ unsigned long long g_tl_##name[MM_TIMELINE_MAX][3]; }                                          \
     extern "C" int mm_debug_timeline_##name(unsigned long long* out) {                                                       \
-        return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm::g_tl_##name), sizeof(unsigned long long) * MM_TIMELINE_MAX * 2) == hipSuccess ? 0 : -1; \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm::g_tl_##name), sizeof(unsigned long long) * MM_TIMELINE_MAX * 3) == hipSuccess ? 0 : -1; \
     }
 #define MM_TIMELINE_BEGIN() const unsigned long long tl_begin_ = wall_clock64()
 #define MM_TIMELINE_END(name) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < MM_TIMELINE_MAX) {                 \
-    mm::g_tl_##name[blockIdx.x][0] = tl_begin_; mm::g_tl_##name[blockIdx.x][1] = wall_clock64(); } } while (0)
+    mm::g_tl_##name[blockIdx.x][0] = tl_begin_; mm::g_tl_##name[blockIdx.x][1] = wall_clock64();                             \
+    mm::g_tl_##name[blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |                         \
+                                     ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 32); } } while (0)
 #else
 #define MM_TIMELINE_STORAGE(name)
 #define MM_TIMELINE_BEGIN() do { } while (0)

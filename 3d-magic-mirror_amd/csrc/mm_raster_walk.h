@@ -438,6 +438,9 @@ __device__ inline void tile_walk_batch(const RasterArgs& a, const TileCtx& t, Wa
         fetch(0);
         MM_PP_MARK(9);
         for (int k0 = 0; k0 < total; k0 += 64) {
+#ifdef MM_BOUND_CAP                                             // BOUND EXPERIMENT (WRONG results, never in the product; profiles/r06_semi_heavy_bound.md): a single-wave tile stops after
+            if (k0 >= MM_BOUND_CAP) break;                       // this many candidates -- what the launch would last if no single-wave tile were heavier than that
+#endif
             const int n = min(64, total - k0);
             const float4 g0 = n0, g1 = n1, g2 = n2;
             const int f = nf;

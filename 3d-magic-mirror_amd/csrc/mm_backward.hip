@@ -47,6 +47,9 @@ namespace mm {
 #define MM_FL 8                 // lanes per sweep item: a trip covers MM_FL * MM_SWEEP pixels of each of the wave's items
 #endif
 #define MM_FPW (64 / MM_FL)     // items per wave
+#ifndef MM_FL4_MIN_B
+#define MM_FL4_MIN_B 128         // batches from this size on sweep with FOUR lanes per item (see launch_raster_bwd)
+#endif
 static_assert(MM_CHUNK_PX % (MM_FL * MM_SWEEP) == 0, "a chunk is a whole number of trips");
 
 // squared distance from p to segment u-v by clamped projection: t in [0,1] is where the nearest point lies, q = p - nearest.
@@ -106,8 +109,9 @@ struct __attribute__((aligned(16))) FaceSlot {
     long long acc[9];                // dL/d(ax,ay,bx,by,cx,cy), dL/d(n), fixed point
 };
 
-struct __attribute__((aligned(16))) SweepStage {
-    FaceSlot slot[MM_FPW];
+template <int FL>
+struct __attribute__((aligned(16))) SweepStageT {
+    FaceSlot slot[64 / FL];
     unsigned short items[MM_SWEEP * 64];   // owned << 15 | sweep slot << 6 | lane
 };
 
@@ -288,8 +292,9 @@ __device__ inline void item_finish(const BwdArgs& a, FaceSlot& fs, const ItemLoa
 //     gradient, uncovered pixels that hold it among their first knum soft-mask faces give K4.  The hits of a trip are
 //     ballot-compacted over the whole wave and finished by all 64 lanes (one round of loads per trip) into the per-face
 //     fixed-point LDS sums.  This lane's face is `f` of image `b`, and its group sweeps box pixels [lo, hi) of it.
-__device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f, int lane, const FaceBox& fb, int lo, int hi, float scale MM_PP_ARG) {
-    const int grp = lane / MM_FL, sl = lane % MM_FL;
+template <int FL>
+__device__ inline void face_sweep(const BwdArgs& a, SweepStageT<FL>* st, int b, int f, int lane, const FaceBox& fb, int lo, int hi, float scale MM_PP_ARG) {
+    const int grp = lane / FL, sl = lane % FL;
     const size_t hw = (size_t)a.H * a.W;
     const float s2 = a.mult * a.mult;
     if (sl == 0) {
@@ -297,21 +302,21 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
         fs.p0 = fb.p0; fs.p1 = fb.p1; fs.box[0] = fb.xmin; fs.box[1] = fb.ymin; fs.box[2] = fb.xmax; fs.box[3] = fb.ymax;
         fs.px0 = fb.px0; fs.py0 = fb.py0; fs.bw = fb.bw; fs.inv_bw = fb.inv_bw; fs.lo = lo; fs.f = f;
     }
-    for (int k = sl; k < 9; k += MM_FL) st->slot[grp].acc[k] = 0ll;
+    for (int k = sl; k < 9; k += FL) st->slot[grp].acc[k] = 0ll;
     int nmax = hi - lo;
-    if (MM_FL <= 4) nmax = max(nmax, (int)lane_xchg<4>((unsigned)nmax, lane));
-    if (MM_FL <= 8) nmax = max(nmax, (int)lane_xchg<8>((unsigned)nmax, lane));
+    if (FL <= 4) nmax = max(nmax, (int)lane_xchg<4>((unsigned)nmax, lane));
+    if (FL <= 8) nmax = max(nmax, (int)lane_xchg<8>((unsigned)nmax, lane));
     nmax = max(nmax, (int)lane_xchg<16>((unsigned)nmax, lane)); nmax = max(nmax, (int)lane_xchg<32>((unsigned)nmax, lane));
-    static_assert(MM_FL == 16 || MM_FL == 8 || MM_FL == 4, "the exchange strides above start at the lanes-per-item count");
+    static_assert(FL == 16 || FL == 8 || FL == 4, "the exchange strides above start at the lanes-per-item count");
     wave_sync_lds();
     MM_PP_MARK(0);
 
     // A lane's pixels of a trip are MM_FL apart in the row-major box: the first one by division, the others by stepping (column += MM_FL mod
     // width, row += MM_FL div width, one wrap at most) -- five instructions instead of the twelve of a division, sixteen times per trip.
     int step_c, step_r;
-    box_pixel(MM_FL, 0, 0, fb.bw, fb.inv_bw, step_c, step_r);
+    box_pixel(FL, 0, 0, fb.bw, fb.inv_bw, step_c, step_r);
     const unsigned step_off = (unsigned)step_r * (unsigned)a.W + (unsigned)step_c, wrap_off = (unsigned)a.W - (unsigned)fb.bw;   // a wrap: one row down, width back
-    for (int base = 0; base < nmax; base += MM_FL * MM_SWEEP) {
+    for (int base = 0; base < nmax; base += FL * MM_SWEEP) {
         bool own[MM_SWEEP], opn[MM_SWEEP];
         int col, row;
         box_pixel(lo + base + sl, 0, 0, fb.bw, fb.inv_bw, col, row);
@@ -319,7 +324,7 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
         unsigned off = (unsigned)(fb.py0 + row) * (unsigned)a.W + (unsigned)(fb.px0 + col);   // (H, W <= 65535: fits 32 bits)
 #pragma unroll
         for (int i = 0; i < MM_SWEEP; ++i) {
-            const int idx = lo + base + i * MM_FL + sl;
+            const int idx = lo + base + i * FL + sl;
             const int fi = idx < hi ? fimg[off] : -2;
             own[i] = fi == f; opn[i] = fi == -1;
             col += step_c; off += step_off;
@@ -342,9 +347,9 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
                 if (u >= 1 && j0 + 64 * u >= n) break;               // wave-uniform: a short list has no second half
                 const unsigned it = st->items[ld[u].live ? j : 0];
                 const int l = it & 63, i = (it >> 6) & 0x1FF;
-                ld[u].g = l / MM_FL;
+                ld[u].g = l / FL;
                 const FaceSlot& fs = st->slot[ld[u].g];
-                box_pixel(fs.lo + base + i * MM_FL + (l % MM_FL), fs.px0, fs.py0, fs.bw, fs.inv_bw, ld[u].px, ld[u].py);
+                box_pixel(fs.lo + base + i * FL + (l % FL), fs.px0, fs.py0, fs.bw, fs.inv_bw, ld[u].px, ld[u].py);
                 const size_t pix = (size_t)b * hw + (size_t)ld[u].py * a.W + ld[u].px;   // every group of the wave sweeps the same image
                 // the sweep already knows which kind of hit this is: only the three loads that kind needs are issued
                 ld[u].owned = (it & 0x8000u) != 0;
@@ -370,9 +375,11 @@ __device__ inline void face_sweep(const BwdArgs& a, SweepStage* st, int b, int f
 // a wave takes MM_FPW consecutive sweep items of ONE image (consecutive faces, or consecutive chunks of a big face: neighbours on
 // the screen); waves walk the images round-robin.  The item's partial sums go to part[item]; the vertex backward adds the items
 // of a face up.
-__device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage* s_stage) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / MM_FL, sl = lane % MM_FL;
-    SweepStage* st = &s_stage[wave];
+template <int FL>
+__device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStageT<FL>* s_stage) {
+    constexpr int FPW = 64 / FL;                                 // items per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / FL, sl = lane % FL;
+    SweepStageT<FL>* st = &s_stage[wave];
     const long long wid = (long long)block * 4 + MM_WAVE_UNIFORM(wave);   // wave index over (item octet, image)
     // (wave-uniform by construction; saying so makes the image's scalars -- item count, chunk size, the 32 shards of the fixed-point scale -- SCALAR
     //  loads from the scalar cache instead of 34 vector loads of one address per wave: 8 000 waves x 34 wave-loads were ~a third of the kernel's
@@ -382,7 +389,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     // The image's items are dealt to its waves ROUND-ROBIN (wave w takes items w, w + nw, w + 2 nw, ...): the chunks of a close-up face are
     // consecutive items, most of their pixels owned, and a wave holding eight of them in a row (a thousand hits, sixteen dependent rounds
     // of hit loads) was the tail of this kernel; spread out, every wave gets at most one or two of them.
-    const int w_img = (int)(wid / a.B), nw = (ni.x + MM_FPW - 1) / MM_FPW;
+    const int w_img = (int)(wid / a.B), nw = (ni.x + FPW - 1) / FPW;
     if (w_img >= nw) return;                                      // wave-uniform: the image has fewer items (the grid is sized for the cap)
     const int item = grp * nw + w_img;
     const bool live = item < ni.x;
@@ -397,7 +404,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     float inv;
     const float scale = face_sum_scale(a, b, inv);
     face_sweep(a, st, b, e.x, lane, fb, lo, hi, scale MM_PP_PASS);
-    if (live) for (int k = sl; k < 9; k += MM_FL) a.part[((size_t)b * a.item_cap + item) * 12 + k] = (float)st->slot[grp].acc[k] * inv;
+    if (live) for (int k = sl; k < 9; k += FL) a.part[((size_t)b * a.item_cap + item) * 12 + k] = (float)st->slot[grp].acc[k] * inv;
     MM_PP_MARK(5);
     MM_PP_FLUSH(gather_face, wid);
 }
@@ -422,6 +429,7 @@ __device__ inline float fused_loss_value(const long long* ltot, int B, int H, in
 #ifndef MM_GATHER_LB
 #define MM_GATHER_LB 8            // waves per SIMD the register allocation is held to (64 VGPRs, no spills)
 #endif
+template <int FL>
 __global__ __launch_bounds__(256, MM_GATHER_LB) void gather_bwd_kernel(BwdArgs a, int ntex, int dbg_skip) {
     MM_TIMELINE_BEGIN();
 #ifdef MM_PHASE_PROF                                            // timing experiments only (results are wrong): leave one kind of workgroup out
@@ -429,10 +437,10 @@ __global__ __launch_bounds__(256, MM_GATHER_LB) void gather_bwd_kernel(BwdArgs a
     if ((dbg_skip & 2) && (int)blockIdx.x >= ntex) return;
 #endif
     // the two kinds of workgroup never coexist in one workgroup: their LDS is overlaid (more workgroups per CU)
-    constexpr size_t kLds = sizeof(float) * 3 * MM_TS * MM_TS > sizeof(SweepStage) * 4 ? sizeof(float) * 3 * MM_TS * MM_TS : sizeof(SweepStage) * 4;
+    constexpr size_t kLds = sizeof(float) * 3 * MM_TS * MM_TS > sizeof(SweepStageT<FL>) * 4 ? sizeof(float) * 3 * MM_TS * MM_TS : sizeof(SweepStageT<FL>) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLds];
     int (*s_acc)[MM_TS * MM_TS] = reinterpret_cast<int (*)[MM_TS * MM_TS]>(s_raw);
-    SweepStage* s_stage = reinterpret_cast<SweepStage*>(s_raw);
+    SweepStageT<FL>* s_stage = reinterpret_cast<SweepStageT<FL>*>(s_raw);
     if (a.gt && a.loss && blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {  // fused recon_data value: fixed-order sum over images
         const float v = fused_loss_value(a.ltot, a.B, a.H, a.W, a.image_weight, a.contour, threadIdx.x);
         if (threadIdx.x == 0) a.loss[0] = v;
@@ -487,13 +495,18 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
     {
         ProfScope p(d->prof_events, MM_PROF_GATHER_BWD, s);
         const int ntex = a.ntx * a.nty * d->B;
-        const long long nwaves = (long long)d->B * ((w.item_cap + MM_FPW - 1) / MM_FPW);   // (item octet, image), sized for the cap: waves
+        // lanes per sweep item: 8 (eight items per wave) where one batch is in flight; 4 (sixteen items per wave, half the waves, each with twice the
+        // hits) for the large batches that run the chip in many rounds -- r06, profiles/r06_sweep_shape_ab.md: -5 % of this kernel at B=384, +4 to +15 % at B=48
+        const bool fl4 = MM_FL == 8 && d->B >= MM_FL4_MIN_B;
+        const int fpw = fl4 ? 16 : MM_FPW;
+        const long long nwaves = (long long)d->B * ((w.item_cap + fpw - 1) / fpw);          // (item group, image), sized for the cap: waves
         const unsigned nface = (unsigned)((nwaves + 3) / 4);                                // beyond an image's item count exit at once
         int dbg_skip = 0;
 #ifdef MM_PHASE_PROF
         if (const char* e = getenv("MM_DBG_GATHER")) dbg_skip = atoi(e);
 #endif
-        hipLaunchKernelGGL(gather_bwd_kernel, dim3(ntex + nface), dim3(256), 0, s, a, ntex, dbg_skip);
+        if (fl4) hipLaunchKernelGGL(gather_bwd_kernel<4>, dim3(ntex + nface), dim3(256), 0, s, a, ntex, dbg_skip);
+        else hipLaunchKernelGGL(gather_bwd_kernel<MM_FL>, dim3(ntex + nface), dim3(256), 0, s, a, ntex, dbg_skip);
     }
     return launch_ok("raster_bwd");
 }

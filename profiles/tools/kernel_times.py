@@ -10,7 +10,7 @@ if os.environ.get("MM_DBG_LIB"):
     importlib.import_module("3d-magic-mirror_amd.build_native").needs_build = lambda: False
 dev = torch.device("cuda:0")
 for cfg in (sys.argv[1:] or ["config2"]):
-    name, B, S, ratio = bench.CONFIGS[cfg]
+    name, B, S, ratio = bench.CONFIGS[cfg] if cfg in bench.CONFIGS else (lambda t: (t[0], int(t[1]), int(t[2]), int(t[3])))(cfg.split(":"))   # or template:B:size:ratio
     dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio, emit_imnormal=False)
     dr.options = int(os.environ.get("MM_OPTIONS", "0"))          # MMRenderDesc.options (e.g. 2 / 4: force a walk-kernel shape)
     H, W = dr.render_height, dr.image_size

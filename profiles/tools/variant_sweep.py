@@ -24,7 +24,7 @@ else:
             env["MM_DBG_LIB"] = path
         out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "kernel_times.py")] + cfgs, env=env, capture_output=True, text=True)
         for line in out.stdout.splitlines():
-            if line.startswith(("config", "market")):
+            if line.startswith(("config", "market")) or ":" in line.split(" ")[0]:
                 print("%-14s %s" % (name, line), flush=True)
         if out.returncode:
             print(name, "FAILED", out.stderr[-400:])

@@ -663,10 +663,18 @@ const unsigned short* launch_order(RasterArgs& a, unsigned short* order, int* nh
 // block) 546 / 613; 256x256 1280 faces 147 / 134.  The first wins where single tiles are heavy enough to be the kernel's tail
 // (8-pixel bins: the mesh folds into few tiles) or where the four tiles are neighbours (unsorted); the second where tiles are many,
 // even and taken in sorted order.  MM_OPT_WALK_BLOCK / MM_OPT_WALK_WAVE force one (tuning / tests).
+#ifndef MM_WAVE_SHAPE_MIN_TILES
+#define MM_WAVE_SHAPE_MIN_TILES 49152      // tiles per launch (B x tiles per image) from which 8-pixel-bin shapes take the one-tile-per-workgroup walk: B = 192 at 128x128
+#endif
 inline bool walk_block_mode(const RasterArgs& a) {
     if (a.options & MM_OPT_WALK_BLOCK) return true;
     if (a.options & MM_OPT_WALK_WAVE) return false;
-    return a.bin_shift == 3 || a.order == nullptr;               // 8-pixel bins, or no tile sort (a screen beyond MM_ORDER_MAX_SLOTS tiles)
+    if (a.order == nullptr) return true;                         // no tile sort (a screen beyond MM_ORDER_MAX_SLOTS tiles)
+    if (a.bin_shift != 3) return false;
+    // 8-pixel bins: the 256-thread shape with its cooperative heavy tiles, whose point is the launch's TAIL -- unless the batch runs the chip in many
+    // rounds, where the tail is a small share and one tile per workgroup packs better (r06, profiles/r06_large_batch_shapes.md: raster_fwd -5 ... -9 % at
+    // B = 256 / 384 with 128x128 images for near, SURVEY-8(d) and far cameras alike; at B = 128 far cameras still lose 14 % without the cooperative walk)
+    return (long long)a.B * 4 * a.blocks_per_image < MM_WAVE_SHAPE_MIN_TILES;
 }
 // Sorted launch order: workgroup i -> (image, rank j of the workgroup inside the image).  The dispatcher deals consecutive workgroups to
 // the eight XCDs in turn (observed).  `i % B` keeps an image on one XCD (B a multiple of 8): its face records and bin masks are read

@@ -11,14 +11,16 @@ if os.environ.get("MM_DBG_LIB"):
 dev = torch.device("cuda:0")
 for cfg in (sys.argv[1:] or ["config2"]):
     name, B, S, ratio = bench.CONFIGS[cfg] if cfg in bench.CONFIGS else (lambda t: (t[0], int(t[1]), int(t[2]), int(t[3])))(cfg.split(":"))   # or template:B:size:ratio
-    dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio, emit_imnormal=False)
+    dr = pkg.DiffRender(os.path.join(ROOT, "tests", "golden", "templates", name + ".npz"), S, ratio=ratio, emit_imnormal=os.environ.get("MM_IMN") == "1")
     dr.options = int(os.environ.get("MM_OPTIONS", "0"))          # MMRenderDesc.options (e.g. 2 / 4: force a walk-kernel shape)
     H, W = dr.render_height, dr.image_size
     batches = []
     for r in range(6):
         att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=100 * r)
+        if os.environ.get("MM_DIST"):                              # camera distances drawn from lo,hi instead of SURVEY 8(d)'s U(2,7): far cameras fold the mesh into a few heavy tiles
+            lo_, hi_ = map(float, os.environ["MM_DIST"].split(",")); att["distances"] = torch.rand(B, generator=torch.Generator().manual_seed(r)) * (hi_ - lo_) + lo_
         batches.append(({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in att.items()}, gt.to(dev)))
-    st = stepmod.RenderLossStep(dr, batches[0][0], batches[0][1], fused=True)
+    st = stepmod.RenderLossStep(dr, batches[0][0], batches[0][1], fused=True, emit_imnormal=os.environ.get("MM_IMN") == "1")
     st.enable_profiling()
     acc = {}
     for i in range(33):

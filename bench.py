@@ -465,13 +465,13 @@ def main():
         # train.py, same results): the default hands every backward to the engine's device thread and back -- two thread wake-ups per step, which is what
         # the host's slow spells are made of (60-100 us per step on a dozing host; profiles/r06_api_noise.md).  *_st = single-threaded backward.
         names = [n for n, _, _ in flavours] + [n + "_st" for n, _, _ in flavours]
-        api_rounds = {name: [] for name in names}
-        host_rounds = {name: [] for name in names}
+        api_rounds = {fl: [] for fl in names}
+        host_rounds = {fl: [] for fl in names}
         for _round in range(3):
             for st_mode in (False, True):
                 torch.autograd.set_multithreading_enabled(not st_mode)
-                for name, defer, fn in flavours:
-                    key = name + ("_st" if st_mode else "")
+                for fl, defer, fn in flavours:
+                    key = fl + ("_st" if st_mode else "")
                     dr_api.defer_recon_fusion = defer
                     for _ in range(10):
                         fn()
@@ -483,8 +483,8 @@ def main():
         api_value, api_undeferred_value, api_fused_value = (max(api_rounds[n]) for n in ("api", "api_undeferred", "api_fused"))
         api_st_values = {"value_" + n: max(api_rounds[n]) for n in names if n.endswith("_st")}
         host_us_per_step["c_abi_one_stream"] = host_us(one_single)
-        for name in names:
-            host_us_per_step[name] = min(host_rounds[name])
+        for fl in names:
+            host_us_per_step[fl] = min(host_rounds[fl])
         host_us_per_step["rounds"] = {"images_per_s": api_rounds, "host_us": host_rounds, "statistic": "value_api* = best of three interleaved rounds; host_us = the smallest"}
     if args.shim_steps > 0 and rank == 0:
         # the un-fused kaolin-shaped operator chain in the reference's order (networks.py:278-317): ~40 launches per render, float atomics

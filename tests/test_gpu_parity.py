@@ -683,6 +683,51 @@ def test_gradients_reach_all_inputs_at_headline_size(pkg):
     assert float((datt["textures"].grad != 0).float().mean()) < 0.9
 
 
+@pytest.mark.parametrize("dist", [None, 8.0])
+def test_batches_of_192_images_take_the_large_batch_shapes_and_hold_the_bar(pkg, oracle, dist):
+    """B = 192 at 128x128 crosses both large-batch thresholds of round 6: raster_fwd takes the one-tile-per-workgroup walk for 8-pixel bins
+    (MM_WAVE_SHAPE_MIN_TILES = 49 152 tiles per launch, mm_raster_common.h: walk_block_mode) and gather_bwd sweeps with four lanes per item
+    (MM_FL4_MIN_B = 128, mm_backward.hip).  The whole batch against the oracle at the full bar, the default dispatch against the forced
+    256-thread shape bit for bit, and against the same images rendered 48 at a time (the small-batch kernels: eight lanes per item, the ticketed
+    vertex backward), whose gradients differ from the large call's only in the last fixed-point step of the per-face sums."""
+    B, S = 192, 128
+    N = pkg._native
+    res = {}
+    for tag, opt in (("default", 0), ("block", N.OPT_WALK_BLOCK)):
+        dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", B, S, seed=23)
+        if dist is not None:
+            with torch.no_grad():
+                datt["distances"].fill_(dist)
+            inp["distances"] = np.full_like(inp["distances"], dist)
+        dr.options = opt
+        rgbs, out = dr.render(no_mask=True, **datt)
+        dr.recon_data(rgbs, gt.to(dev), no_mask=True).backward()
+        torch.cuda.synchronize()
+        res[tag] = (rgbs.detach().clone(), dr.last_face_idx.clone(), {k: datt[k].grad.clone() for k in LEAVES})
+    a, b = res["default"], res["block"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in LEAVES:
+        assert torch.equal(a[2][k], b[2][k]), k
+    # the oracle on the whole batch
+    rgba_o, fidx_o, _, _ = oracle.render_forward(inp, H, W, True, proj)
+    assert np.array_equal(a[1].cpu().numpy(), fidx_o)
+    _close(a[0].permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
+    loss_o, g_o = oracle.step(inp, gt.numpy(), H, W, True, proj, image_weight=dr.image_weight)
+    for k in LEAVES:
+        _gclose(a[2][k].cpu().numpy(), g_o[k], what=k)
+    # the same images 48 at a time: recon_data is a mean over the batch, so a quarter's gradients are 4x the large call's
+    for q in range(4):
+        sl = slice(48 * q, 48 * q + 48)
+        part = {kk: (v[sl].detach().clone().requires_grad_(kk in LEAVES) if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for kk, v in datt.items()}
+        r1, _ = dr.render(no_mask=True, **part)
+        assert torch.equal(dr.last_face_idx, a[1][sl]) and torch.equal(r1.detach(), a[0][sl])
+        dr.recon_data(r1, gt[sl].to(dev), no_mask=True).backward()
+        for kk in LEAVES:
+            if datt[kk].shape[:1] != (B,):
+                continue
+            _gclose(a[2][kk][sl].cpu().numpy() * 4, part[kk].grad.cpu().numpy(), 2e-5, what=kk)
+
+
 def test_stress_size_batch_independence_and_four_images_against_oracle(pkg, oracle):
     """BASELINE config 5 (smpl_uv: 13 776 faces, B=16, 512x512, texture 1024x512) at FULL size.  Size-independent property: an
     image's result does not depend on the batch it is rendered in (bitwise, forward and backward: every accumulation of the backward is

@@ -131,9 +131,12 @@ __device__ inline int compact_hits(const bool (&own)[MM_SWEEP], const bool (&opn
 
 // Fixed-point scale of an image's face sums.  The pixel pass left max |K2 number| and max |dL/dalpha| of the image (gmax); a K4
 // contribution is bounded by |dL/dalpha| * mult * sqrt(2 sigma' / e), sigma' = sigmainv / mult^2 (the maximum of d exp(-sigma' d^2)
-// times the constant factors of Appendix A.2).  The largest contribution is placed at 2^40: 2^22 of them fit a 63-bit sum, and
-// the unit is 2^-40 of it.
-__device__ inline float face_sum_scale(const BwdArgs& a, int b, float& inv) {
+// times the constant factors of Appendix A.2).  A sum belongs to ONE sweep item and takes at most one contribution per pixel of the
+// item's chunk (chunk_px = MM_CHUNK_PX << k pixels in this image, nitems[b].y): the largest contribution is placed at 2^(62 - L),
+// L = ceil(log2 chunk_px), so that 2^L of them fit a 63-bit sum -- 2^55 for the usual 128-pixel chunk, i.e. the unit is 2^-55 of the
+// bound (rounds 2-5 placed it at 2^40 whatever the chunk, room for a 2048 x 2048 chunk nobody cuts: contributions below 2^-41 of the
+// bound were rounded to zero, which randomised cases with saturated silhouettes kept finding -- r06 seed 8809 case 254).
+__device__ inline float face_sum_scale(const BwdArgs& a, int b, int chunk_px, float& inv) {
     float m2 = 0.f, m4 = 0.f;
 #pragma unroll
     for (int sh = 0; sh < MM_GSHARD; ++sh) {
@@ -145,7 +148,8 @@ __device__ inline float face_sum_scale(const BwdArgs& a, int b, float& inv) {
     if (!(M > 0.f) || !(M < INFINITY)) { inv = 0.f; return 0.f; }
     int e;
     (void)frexpf(M, &e);                                         // M < 2^e
-    const int k = min(max(40 - e, -80), 126);
+    const int L = 32 - __clz(max(chunk_px, 2) - 1);              // ceil(log2 chunk_px) in [1, 31]: a chunk is at most MM_CHUNK_PX << 20 pixels (plan kernel)
+    const int k = min(max(62 - L - e, -80), 126);
     inv = ldexpf(1.f, -k);
     return ldexpf(1.f, k);
 }
@@ -402,7 +406,7 @@ __device__ inline void face_gather_block(const BwdArgs& a, int block, SweepStage
     const int hi = live && (front || !(a.options & MM_OPT_SOFT_SKIP_CULLED)) ? min(fb.npx, lo + ni.y) : lo;
     MM_PP_BEGIN();
     float inv;
-    const float scale = face_sum_scale(a, b, inv);
+    const float scale = face_sum_scale(a, b, ni.y, inv);
     face_sweep(a, st, b, e.x, lane, fb, lo, hi, scale MM_PP_PASS);
     if (live) for (int k = sl; k < 9; k += FL) a.part[((size_t)b * a.item_cap + item) * 12 + k] = (float)st->slot[grp].acc[k] * inv;
     MM_PP_MARK(5);

@@ -16,7 +16,7 @@ LEAVES = ("vertices", "textures", "lights", "bg", "azimuths", "elevations", "dis
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
-bad = 0; ncond = 0; nnegl = 0
+bad = 0; ncond = 0; nnegl = 0; npool = 0
 only = os.environ.get("MM_FUZZ_ONLY")
 for case in range(ncase):
     name = rng.choice(["sphere", "smpl_uv_642", "ellipsoid", "sphere2", "smpl_uv"], p=[0.25, 0.3, 0.15, 0.15, 0.15])
@@ -66,35 +66,53 @@ for case in range(ncase):
     if only is not None and case != int(only):                  # (after EVERY draw of the case: a skipped case consumes the same random numbers)
         continue
     try:
-        if api == "render + random upstream":
-            rgbs, out = dr.render(no_mask=no_mask, **datt)
-            ((rgbs.permute(0, 2, 3, 1) * torch.from_numpy(w_up).to(dev)).sum() + (out["face_normals"] * torch.from_numpy(wfn_up).to(dev)).sum()).backward()
-        elif api == "render+recon_data":
-            rgbs, out = dr.render(no_mask=no_mask, **datt)
-            dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask, contour=contour).backward()
-        elif api == "render_recon":
-            loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=no_mask, contour=contour, **datt)
-            loss.backward()
-        else:                                                    # the reference's own composition of the kaolin-shaped operators
-            Tt = torch.from_numpy(oracle.camera(inp["distances"], inp["elevations"], inp["azimuths"], inp["biases"])).to(dev).requires_grad_(True)
-            F = dr.num_faces
-            fvc_t, fvi_t, fn_t = kal.render.mesh.prepare_vertices(vertices=datt["vertices"], faces=dr.faces, camera_proj=dr.cam_proj, camera_transform=Tt)
-            nrm = kal.ops.mesh.face_normals(fvc_t, unit=True).unsqueeze(-2).repeat(1, 1, 3, 1)
-            feats = [torch.ones((B, F, 3, 1), device=dev), dr.face_uvs.to(dev).repeat(B, 1, 1, 1), nrm]
-            (texmask, texcoord, imnormal), soft_t, fidx_t = kal.render.mesh.dibr_rasterization(
-                H, W, fvc_t[:, :, :, -1], fvi_t, feats, fn_t[:, :, -1], knum=knum, boxlen=boxlen, sigmainv=sigmainv)
-            texcolor = kal.render.mesh.texture_mapping(texcoord, datt["textures"], mode='bilinear')
-            coef = kal.render.mesh.spherical_harmonic_lighting(imnormal, datt["lights"])
-            image = (texcolor * texmask + datt["bg"].permute(0, 2, 3, 1) * (1 - texmask)) * coef.unsqueeze(-1) if no_mask else \
-                texcolor * texmask * coef.unsqueeze(-1) + torch.ones_like(texcolor) * (1 - texmask)
-            rgbs = torch.cat([torch.clamp(image, 0, 1), soft_t[..., None]], -1).permute(0, 3, 1, 2)
-            dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask, contour=contour).backward()
-            dr.last_face_idx = fidx_t.int()
-            # the camera chain is the oracle's here (T is a leaf): push dL/dT through it so that all eight gradients can be compared
-            dd, de, da, db = oracle.camera_backward(inp["distances"], inp["elevations"], inp["azimuths"], inp["biases"], Tt.grad.cpu().numpy())
-            for k, v in (("distances", dd), ("elevations", de), ("azimuths", da), ("biases", db)):
-                datt[k].grad = torch.from_numpy(np.ascontiguousarray(v)).to(dev).reshape(datt[k].shape)
+        def run_api():
+            if api == "render + random upstream":
+                rgbs, out = dr.render(no_mask=no_mask, **datt)
+                ((rgbs.permute(0, 2, 3, 1) * torch.from_numpy(w_up).to(dev)).sum() + (out["face_normals"] * torch.from_numpy(wfn_up).to(dev)).sum()).backward()
+            elif api == "render+recon_data":
+                rgbs, out = dr.render(no_mask=no_mask, **datt)
+                dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask, contour=contour).backward()
+            elif api == "render_recon":
+                loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=no_mask, contour=contour, **datt)
+                loss.backward()
+            else:                                                    # the reference's own composition of the kaolin-shaped operators
+                Tt = torch.from_numpy(oracle.camera(inp["distances"], inp["elevations"], inp["azimuths"], inp["biases"])).to(dev).requires_grad_(True)
+                F = dr.num_faces
+                fvc_t, fvi_t, fn_t = kal.render.mesh.prepare_vertices(vertices=datt["vertices"], faces=dr.faces, camera_proj=dr.cam_proj, camera_transform=Tt)
+                nrm = kal.ops.mesh.face_normals(fvc_t, unit=True).unsqueeze(-2).repeat(1, 1, 3, 1)
+                feats = [torch.ones((B, F, 3, 1), device=dev), dr.face_uvs.to(dev).repeat(B, 1, 1, 1), nrm]
+                (texmask, texcoord, imnormal), soft_t, fidx_t = kal.render.mesh.dibr_rasterization(
+                    H, W, fvc_t[:, :, :, -1], fvi_t, feats, fn_t[:, :, -1], knum=knum, boxlen=boxlen, sigmainv=sigmainv)
+                texcolor = kal.render.mesh.texture_mapping(texcoord, datt["textures"], mode='bilinear')
+                coef = kal.render.mesh.spherical_harmonic_lighting(imnormal, datt["lights"])
+                image = (texcolor * texmask + datt["bg"].permute(0, 2, 3, 1) * (1 - texmask)) * coef.unsqueeze(-1) if no_mask else \
+                    texcolor * texmask * coef.unsqueeze(-1) + torch.ones_like(texcolor) * (1 - texmask)
+                rgbs = torch.cat([torch.clamp(image, 0, 1), soft_t[..., None]], -1).permute(0, 3, 1, 2)
+                dr.recon_data(rgbs, gt.to(dev), no_mask=no_mask, contour=contour).backward()
+                dr.last_face_idx = fidx_t.int()
+                # the camera chain is the oracle's here (T is a leaf): push dL/dT through it so that all eight gradients can be compared
+                dd, de, da, db = oracle.camera_backward(inp["distances"], inp["elevations"], inp["azimuths"], inp["biases"], Tt.grad.cpu().numpy())
+                for k, v in (("distances", dd), ("elevations", de), ("azimuths", da), ("biases", db)):
+                    datt[k].grad = torch.from_numpy(np.ascontiguousarray(v)).to(dev).reshape(datt[k].shape)
+            return rgbs
+        rgbs = run_api()
         torch.cuda.synchronize()
+        pool = ""
+        ndrop = dr.poll_dropped_records()
+        if ndrop:
+            # the minimum workspace's texture-record array (9/8 records per pixel) overflowed: loud by contract (NaN texture gradients + the status word,
+            # tests/test_gpu_parity.py::test_texture_record_pool_overflow_...) -- verified here, then the case is run again with the array enlarged
+            assert api != "shim operators" and bool(torch.isnan(datt["textures"].grad).any()), "records dropped without NaN texture gradients"
+            for k in LEAVES:
+                if datt.get(k) is not None:
+                    datt[k].grad = None
+            dr.extra_texture_records_per_pixel = 3.0
+            rgbs = run_api()
+            torch.cuda.synchronize()
+            assert dr.poll_dropped_records() == 0
+            pool = " | record pool overflowed (%d dropped, NaN texture gradients: loud), run again with room for 4 1/8 records per pixel" % ndrop
+            npool += 1
         kw = dict(knum=knum, boxlen=boxlen, sigmainv=sigmainv)
         with oracle.options(optbit):
             rgba_o, fidx_o, fn_o, imn_o = oracle.render_forward(inp, H, W, no_mask, proj, **kw)
@@ -156,10 +174,29 @@ for case in range(ncase):
                 cond = all(e <= 4.0 * sens[k] + 1e-4 for k, e in late)
                 if os.environ.get("MM_FUZZ_DETAIL"):
                     print("      float64 sensitivity to one fp32 rounding of the inputs:", {k: "%.2e (HIP %.2e)" % (sens[k], e) for k, e in late})
+                if not cond:
+                    # Third judge (r06, seed 7607 case 272: 13 776 faces on 24x24 pixels, dL/d distance of the one image = the sum of 6 890 vertex gradients of up
+                    # to 3.8e3 that cancels to 0.86; every one of those terms is itself 1e-3 of the maximum away from float64 in BOTH fp32 results, which agree
+                    # with each other to 1e-7 there -- the float64 judge above sees only the inputs' rounding, not the intermediate ones).  The fp32 ORACLE's own
+                    # spread when its inputs move by one fp32 rounding: where the checker's result moves by more than the bar under a perturbation no fp32
+                    # caller can avoid, the bar cannot be held by any fp32 evaluation.  HIP no farther from the unperturbed fp32 oracle than four times that
+                    # spread (+ 1e-4) is a conditioning case.
+                    sens32 = {k: 0.0 for k, _ in late}
+                    for _ in range(3):
+                        inp_p = dict(inp)
+                        for kk in ("vertices", "azimuths", "elevations", "distances", "biases"):
+                            inp_p[kk] = (inp[kk].astype(np.float64) * (1.0 + 2.0 ** -24 * prng.standard_normal(inp[kk].shape))).astype(np.float32)
+                        with oracle.options(optbit):
+                            g32p = oracle.render_backward(inp_p, H, W, no_mask, proj, dpred_nhwc, wfn_o, **kw)
+                        for k, _ in late:
+                            sens32[k] = max(sens32[k], rel_errors(g32p[k], g_o[k])[0])
+                    cond = all(errs[k] <= 4.0 * sens32[k] + 1e-4 for k, _ in late)
+                    if os.environ.get("MM_FUZZ_DETAIL"):
+                        print("      fp32 oracle's own spread under one fp32 rounding of the inputs:", {k: "%.2e (HIP vs oracle %.2e)" % (sens32[k], errs[k]) for k, _ in late})
             if cond:
                 label = "COND"; ncond += 1
         print("%s  case %2d  %-90s face_idx diff %d, worst err %.2e (%s)%s" % (label, case, tag, nf, worst, max((k for k in errs if k not in negl), key=errs.get),
-                                                                                  " | negligible gradients (< 1e-9 of the case's largest), compared absolutely: %s" % negl if negl else ""), flush=True)
+                                                                                  (" | negligible gradients (< 1e-9 of the case's largest), compared absolutely: %s" % negl if negl else "") + pool), flush=True)
         bad += label == "FAIL"
         if not ok and os.environ.get("MM_FUZZ_DETAIL"):
             print("      all errors:", {k: "%.2e" % v for k, v in errs.items()})
@@ -174,4 +211,5 @@ for case in range(ncase):
         print("EXC   case %2d  %s: %r" % (case, tag, e), flush=True)
         bad += 1
 print("failures:", bad, "| ill-conditioned in fp32 (HIP no farther from the float64 backward than the fp32 oracle is):", ncond,
-      "| cases with a negligible gradient below the fixed-point resolution (compared absolutely, see NEGL):", nnegl)
+      "| cases with a negligible gradient below the fixed-point resolution (compared absolutely, see NEGL):", nnegl,
+      "| cases whose texture-record pool overflowed loudly and were run again with a larger one:", npool)

@@ -435,6 +435,41 @@ def test_fuzz_regression_an_image_that_shows_nothing_still_has_its_tiny_geometry
         assert float(np.abs(g_o[k]).max()) == 0.0 and float(datt[k].grad.abs().max()) == 0.0
 
 
+def test_fuzz_regression_saturated_silhouettes_keep_their_tiny_geometry_gradient_to_the_full_bar(pkg, oracle):
+    """Found by profiles/tools/fuzz_parity.py in round 6 (case 254 of seed 8809): 13 776 faces on a 16x16 screen 26.6 units away, sigmainv = 200 -- every
+    silhouette pixel is saturated and none is covered: the geometry gradients are 3e-11 (vertices) ... 1e-13 (azimuths) under an upstream gradient of 1.7e-2.  Rounds 2-5 kept the
+    gather's per-item fixed-point sums at a unit of 2^-40 of the image's K4 bound whatever the item's size: these gradients came out 1e-3 ... 4e-3 of their own
+    maximum off (and exact zeros below 2^-41 of the bound: round 5's NEGL class).  The unit now follows the chunk size (2^-55 of the bound for a 128-pixel
+    chunk, csrc/mm_backward.hip: face_sum_scale): the full bar holds for every one of them."""
+    dr = pkg.DiffRender(os.path.join(TEMPLATES, "smpl_uv.npz"), 16)
+    dr.knum, dr.boxlen, dr.sigmainv = 30, 0.05, 200.0
+    dr.options = 128
+    dev = torch.device("cuda:0")
+    B, H, W = 3, 16, 16
+    att, gt = pkg.synthetic.synthetic_batch(dr.vertices_init, B, H, W, seed=906465233)
+    att["distances"] = torch.full_like(att["distances"], 26.642802256650747)
+    datt = {k: (v.to(dev).requires_grad_(k in LEAVES) if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in att.items()}
+    inp["faces"] = dr.faces.numpy().astype(np.int32); inp["face_uvs"] = dr.face_uvs.numpy()[0]
+    proj = dr.cam_proj.numpy().reshape(3)
+    loss, rgbs, out = dr.render_recon(gt.to(dev), no_mask=False, contour=0.5, **datt)
+    loss.backward()
+    kw = dict(knum=30, boxlen=0.05, sigmainv=200.0)
+    with oracle.options(128):
+        rgba_o, fidx_o, _, _ = oracle.render_forward(inp, H, W, False, proj, **kw)
+        _, dpred = oracle.recon_data(rgba_o.transpose(0, 3, 1, 2), gt.numpy(), image_weight=dr.image_weight, contour=0.5, want_grad=True)
+        g_o = oracle.render_backward(inp, H, W, False, proj, np.ascontiguousarray(dpred.transpose(0, 2, 3, 1)), None, **kw)
+    assert (dr.last_face_idx.cpu().numpy() == fidx_o).all()
+    _close(rgbs.detach().permute(0, 2, 3, 1).cpu().numpy(), rgba_o)
+    assert (fidx_o == -1).all() and float(rgba_o[..., 3].max()) == 1.0                         # nothing covered, saturated silhouette pixels
+    up = float(np.abs(dpred).max())                                                             # the upstream gradient dL/d(pixel): 1.7e-2
+    for k in ("vertices", "azimuths", "elevations", "distances", "biases"):
+        assert 0 < float(np.abs(g_o[k]).max()) < 1e-7 * up, k                                   # tiny beside what drives them, and not zero
+        _gclose(datt[k].grad.cpu().numpy(), g_o[k], what=k)
+    for k in ("textures", "lights"):
+        assert float(np.abs(g_o[k]).max()) == 0.0 and float(datt[k].grad.abs().max()) == 0.0
+
+
 def test_backward_twice_after_one_forward(pkg):
     """retain_graph: the backward leaves its scratch counters the way it found them (the library clears them in-kernel)."""
     dr, att, datt, gt, inp, proj, H, W, dev = _setup(pkg, "smpl_uv_642", 4, 96, seed=21)

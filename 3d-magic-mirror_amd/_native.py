@@ -122,6 +122,7 @@ OPT_WALK_BLOCK, OPT_WALK_WAVE = 1 << 1, 1 << 2
 OPT_CULL_STRICT, OPT_SOFT_SKIP_CULLED, OPT_BBOX_HALF_OPEN, OPT_BARY_ONE_MINUS, OPT_SH_ORDER_XYZ = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9
 OPT_WALK_QUEUE, OPT_WALK_BATCH = 1 << 10, 1 << 11
+OPT_MANY_IN_FLIGHT = 1 << 12          # hint: several independent calls in flight (identical results; include/mm_render.h)
 PROF_RECON = ("recon_partial", "recon_final", "recon_bwd", "recon_contour")
 
 EXPORTS = ("mm_query_workspace", "mm_render_forward", "mm_render_backward", "mm_render_status", "mm_render_fused_loss", "mm_debug_workspace_layout", "mm_recon_query_workspace",

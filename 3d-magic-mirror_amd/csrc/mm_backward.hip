@@ -501,7 +501,8 @@ int launch_raster_bwd(const MMRenderDesc* d, const MMRenderGrads* g, const Works
         const int ntex = a.ntx * a.nty * d->B;
         // lanes per sweep item: 8 (eight items per wave) where one batch is in flight; 4 (sixteen items per wave, half the waves, each with twice the
         // hits) for the large batches that run the chip in many rounds -- r06, profiles/r06_sweep_shape_ab.md: -5 % of this kernel at B=384, +4 to +15 % at B=48
-        const bool fl4 = MM_FL == 8 && d->B >= MM_FL4_MIN_B;
+        // (MM_OPT_MANY_IN_FLIGHT: several calls share the chip -- the same regime, said by the caller: +1 % with four B=48 steps on four streams)
+        const bool fl4 = MM_FL == 8 && (d->B >= MM_FL4_MIN_B || (d->options & MM_OPT_MANY_IN_FLIGHT) != 0);
         const int fpw = fl4 ? 16 : MM_FPW;
         const long long nwaves = (long long)d->B * ((w.item_cap + fpw - 1) / fpw);          // (item group, image), sized for the cap: waves
         const unsigned nface = (unsigned)((nwaves + 3) / 4);                                // beyond an image's item count exit at once

@@ -671,6 +671,7 @@ inline bool walk_block_mode(const RasterArgs& a) {
     if (a.options & MM_OPT_WALK_WAVE) return false;
     if (a.order == nullptr) return true;                         // no tile sort (a screen beyond MM_ORDER_MAX_SLOTS tiles)
     if (a.bin_shift != 3) return false;
+    if (a.options & MM_OPT_MANY_IN_FLIGHT) return false;            // the caller says the chip is shared by several calls: the large-batch shape (below)
     // 8-pixel bins: the 256-thread shape with its cooperative heavy tiles, whose point is the launch's TAIL -- unless the batch runs the chip in many
     // rounds, where the tail is a small share and one tile per workgroup packs better (r06, profiles/r06_large_batch_shapes.md: raster_fwd -5 ... -9 % at
     // B = 256 / 384 with 128x128 images for near, SURVEY-8(d) and far cameras alike; at B = 128 far cameras still lose 14 % without the cooperative walk)

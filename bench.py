@@ -16,6 +16,9 @@ steps, each repetition bracketed by barrier + synchronize: the driver's short --
   value_four_streams  the same steps enqueued round-robin on --streams HIP streams (default 4): successive steps are independent batches
                       (the reference's trainer issues four renders per iteration, trainer.py:276,345,347,367) and their kernels overlap.
   value_without_imnormal  `value` without the visualise-only imnormal output.
+  value_four_streams_hinted  value_four_streams with MM_OPT_MANY_IN_FLIGHT (the caller's hint that several calls share the chip: the kernels take the shapes large
+                      batches take on their own -- one tile per workgroup in the forward walk, four lanes per sweep item; DiffRender.options,
+                      bit-identical results).
   value_api_undeferred  value_api with DiffRender.defer_recon_fusion = False (rounds 1-5's value_api: recon_data's own backward launch, dL/d image through memory)
   value_api           DiffRender.render -> DiffRender.recon_data -> loss.backward() through the torch.autograd wrappers (the calls
                       trainer.py makes, :276,441,509-518), one stream; recon_data's backward deferred into the render node (round 6).
@@ -398,7 +401,7 @@ def main():
         reducer.wait(); torch.cuda.synchronize(dev)
     loss_value = float(step.loss) if args.mode != "torch" else None
 
-    one_stream = api_value = api_fused_value = shim_value = no_imn_value = api_undeferred_value = options_ab = None
+    one_stream = api_value = api_fused_value = shim_value = no_imn_value = api_undeferred_value = options_ab = four_streams_hinted = None
     api_st_values = {}
     host_us_per_step = {}
     e1, e1_all = elapsed, elapsed_all
@@ -446,6 +449,28 @@ def main():
                 eo, _ = timed_median(one_opt, args.options_steps, reps=3)
                 options_ab[label] = {"options": int(bits), "images_per_s": round(B * args.options_steps / eo, 1)}
                 del st_o
+        # Several steps in flight: the chip then runs every launch in many rounds, the regime in which large batches take the one-tile-per-workgroup
+        # forward walk on their own (walk_block_mode, csrc/mm_raster_common.h).  The library cannot see the caller's concurrency: a caller that
+        # keeps independent steps in flight on several streams says so with MM_OPT_MANY_IN_FLIGHT (DiffRender.options; results bit-identical,
+        # tests/test_gpu_parity.py::test_the_two_walk_kernel_shapes_agree_bit_for_bit).  Same steps, same streams, same inputs as value_four_streams.
+        if world == 1 and args.options_steps > 0 and nstreams > 1:
+            dr_ww = pkg.DiffRender(tpath, S, ratio=ratio, emit_imnormal=True)
+            dr_ww.options = int(pkg._native.OPT_MANY_IN_FLIGHT)
+            st_w = [stepmod.RenderLossStep(dr_ww, batches[s_][0][0], batches[s_][0][1], no_mask=True, fused=not args.unfused, emit_imnormal=True)
+                    for s_ in range(nstreams)]
+            ctr5 = [0]
+
+            def one_ww():
+                k = ctr5[0]; ctr5[0] += 1
+                s_ = k % nstreams
+                if nrot > 1:
+                    st_w[s_].set_inputs(*batches[s_][(k // nstreams) % nrot])
+                st_w[s_].run(streams_[s_])
+            for _ in range(20 * nstreams):
+                one_ww()
+            ew_, _ = timed_median(one_ww, args.steps, reps=3)
+            four_streams_hinted = round(B * args.steps / ew_, 1)
+            del st_w
     if args.api_steps > 0:
         # Run-in: the FIRST autograd flavour measured in a process used to carry ~80 us of host time per step for its first few hundred steps
         # (measured, profiles/tools/api_noise.py: 175-186 us against 100-108 us from the second pass on, whichever flavour comes first: the
@@ -661,6 +686,7 @@ def main():
             "value_one_stream": one_stream, "value_four_streams": round(total_images / elapsed, 1) if args.mode == "eager" else None,
             "ms_per_step_four_streams": round(elapsed / args.steps * 1e3, 4) if args.mode == "eager" else None,
             "value_without_imnormal": no_imn_value,
+            "value_four_streams_hinted": four_streams_hinted,
             "options_ab": options_ab,
             "value_api": api_value, "value_api_undeferred": api_undeferred_value, "value_api_fused": api_fused_value,
             **api_st_values, "host_us_per_step": host_us_per_step, "value_shim": shim_value, "ddp_encoder": ddp_info,

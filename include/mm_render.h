@@ -486,7 +486,7 @@ const char* mm_last_error_detail(void);
 size_t mm_struct_size(int which);
 /* Bumped whenever a struct or the meaning of a field changes (2: op boundary added, reserved uv-tile fields and profiling slot
  * MM_PROF_BIN removed, options bits defined; 3: MMRenderDesc takes the fixed-stride vertex -> corner table instead of the CSR,
- * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, MMTexMapGrads.workspace, mm_chamfer_nearest, mm_build_vertex_corner_csr_device; 5: MMRenderDesc.fused_contour; 6: MMRenderDesc.fused_totals, mm_recon_data_totals).  Bindings must refuse a library whose
+ * MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN; 4: MMRenderDesc.geometry_only / status_flag, MMPrepareDesc.proj_device, MMTexMapGrads.workspace, mm_chamfer_nearest, mm_build_vertex_corner_csr_device; 5: MMRenderDesc.fused_contour; 6: MMRenderDesc.fused_totals, mm_recon_data_totals; still 6: the hint bit MM_OPT_MANY_IN_FLIGHT, which changes no result and no layout).  Bindings must refuse a library whose
  * version differs from what they mirror. */
 #define MM_ABI_VERSION 6
 int mm_abi_version(void);

@@ -62,6 +62,16 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.mm_face_normals_forward(0, 1, None, None, None) == -1
 
 
+def test_option_bits_of_the_binding_are_the_headers(pkg):
+    """Every MM_OPT_* bit include/mm_render.h declares has its OPT_* twin in the ctypes binding with the same value, and no two share a bit."""
+    hdr = open(os.path.join(ROOT, "include", "mm_render.h")).read()
+    bits = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r"MM_OPT_([A-Z_]+)\s*=\s*1\s*<<\s*(\d+)", hdr)}
+    assert len(bits) >= 11 and "MANY_IN_FLIGHT" in bits
+    assert len(set(bits.values())) == len(bits)
+    for name, value in bits.items():
+        assert getattr(pkg._native, "OPT_" + name) == value, name
+
+
 def test_host_csr_builders(pkg):
     from importlib import import_module
     N = import_module("3d-magic-mirror_amd._native")

@@ -244,6 +244,11 @@ def torch_ext():
     if _EXT is False:
         _EXT = None
         from . import build_native as bn
+        if not os.environ.get("MM_NO_TORCH_EXT") and os.path.exists(bn.EXT) and bn.ext_needs_build():
+            # (r06: a header edit without a rebuild left the class API on its Python path, three times the host time per step, without a word)
+            import warnings
+            warnings.warn("lib/mm_torch_ext.so is older than its sources (csrc/mm_torch_ext.cpp, include/mm_render.h): the autograd API uses its "
+                          "slower Python host path. Rebuild with `python __graft_entry__.py`.", RuntimeWarning, stacklevel=2)
         if not os.environ.get("MM_NO_TORCH_EXT") and os.path.exists(bn.EXT) and not bn.ext_needs_build():
             import importlib.machinery
             import importlib.util

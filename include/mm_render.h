@@ -138,7 +138,7 @@ enum { MM_OPT_WALK_BLOCK = 1 << 1,         /* tuning: force the 256-thread / coo
        MM_OPT_MANY_IN_FLIGHT = 1 << 12,    /* hint, identical results: the caller keeps several independent calls in flight (several streams), so every launch
                                             * shares the chip -- the kernels take the shapes large batches take on their own (forward walk: one tile per
                                             * workgroup for 8-pixel screen bins; face sweep of the backward: four lanes per item).  Four B=48 steps on four
-                                            * streams: +3 % images/s; ONE step at a time: -4 % (profiles/r06_many_in_flight_ab.md)                        */
+                                            * streams: +3 % images/s; ONE step at a time: -14 % (profiles/r06_many_in_flight_ab.md)                       */
        MM_OPT_BBOX_MIN_CLOSED_MAX_OPEN = 1 << 9 };  /* bbox test [min, max): reject x < min || x >= max -- the third form upstream may have,
                                             * between the closed default and MM_OPT_BBOX_HALF_OPEN (which opens both borders)  (App. C-4) */
 

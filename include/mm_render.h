@@ -125,7 +125,9 @@ typedef struct MMRenderDesc {
  * (kaolin is not vendored): a maintainer with a CUDA box and real kaolin can pin the path by flipping a bit instead of
  * editing kernels.  oracle/mm_oracle.inc takes the same bits, and tests/ hold HIP == oracle for every one of them. */
 enum { MM_OPT_WALK_BLOCK = 1 << 1,         /* tuning: force the 256-thread / cooperative-heavy-tile shape of the walk kernels ...          */
-       MM_OPT_WALK_WAVE = 1 << 2,          /* ... or the one-wave-per-tile shape (identical results; default: chosen by screen-bin size)   */
+       MM_OPT_WALK_WAVE = 1 << 2,          /* ... or the one-wave-per-tile shape (default: chosen by screen-bin size and batch).  Identical forward outputs;
+                                            * identical gradients too, except that with screen bins larger than a tile the 256-thread shape sweeps a few
+                                            * more faces over their inflated boxes: the same integer sums cut into other items, <= 1e-9 of a gradient's maximum */
        MM_OPT_CULL_STRICT = 1 << 4,        /* rasterise faces with face_normals_z > 0 instead of >= 0                    (App. C-1) */
        MM_OPT_SOFT_SKIP_CULLED = 1 << 5,   /* the soft mask skips the faces the colour pass culls                          (App. C-1) */
        MM_OPT_BBOX_HALF_OPEN = 1 << 6,     /* a pixel centre exactly on a face's bbox edge is outside (<= / >= reject)     (App. C-4) */

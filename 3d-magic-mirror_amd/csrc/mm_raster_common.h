@@ -596,6 +596,19 @@ __device__ inline void shade_empty_tiles(const RasterArgs& a, int b, int e0, int
     unsigned sl[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) sl[q] = a.order[(size_t)b * nslot + min(e0 + q, nslot - 1)] & 0x7FFFu;
+#ifdef MM_BOUND_NO_EMPTY                                        // BOUND EXPERIMENT (WRONG results, never in the product; profiles/r06_empty_shading_bound.md): of an empty tile's
+    for (int q = 0; q < 4; ++q) {                                // 60 bytes per pixel only the 12 the backward cannot do without (face_idx = -1, soft-mask state) are written
+        const int blk = (int)sl[q] >> 2, quad = (int)sl[q] & 3;
+        const int px = (blk % a.blocks_x) * MM_BLOCK_PX + (quad & 1) * MM_TILE + (lane & 7);
+        const int py = (blk / a.blocks_x) * MM_BLOCK_PX + (quad >> 1) * MM_TILE + (lane >> 3);
+        if (q < ne && px < a.W && py < a.H) {
+            const size_t pix = (size_t)b * hw + (size_t)py * a.W + px;
+            a.face_idx[pix] = -1;
+            a.soft[pix] = make_float2(1.f, __int_as_float(0x7FFFFFFF));
+        }
+    }
+    return;
+#endif
     const float coef = MM_SH_C0 * a.lights[b * 9] + (0.f - MM_SH_C6B) * a.lights[b * 9 + 6];   // (bands 0 and 6: the same lights whatever the band order)
     bool in[4];
     size_t pin[4];

@@ -38,7 +38,11 @@ __device__ inline void block_camera(const float* azim, const float* elev, const 
     if (tid < 4) {
         const float ang = MM_DEG2RAD * (tid < 2 ? elev[b] : azim[b]);
         // fp64 sin/cos rounded to fp32: the oracle does the same, so both sides see correctly rounded values
+#ifdef MM_BOUND_FAST_TRIG                                       // BOUND EXPERIMENT (wrong last bits, never in the product): what the fp64 library trig costs the forward's head
+        s_trig[tid] = (tid & 1) ? __sinf(ang) : __cosf(ang);
+#else
         s_trig[tid] = (tid & 1) ? (float)sin((double)ang) : (float)cos((double)ang);
+#endif
     }
     __syncthreads();
     if (tid == 0) camera_build(dist[b], s_trig[0], s_trig[1], s_trig[2], s_trig[3], bias[2 * b], bias[2 * b + 1], *s_cam);
